@@ -1,0 +1,162 @@
+"""BLIP-2 (EVA-ViT-g + Q-Former + FlanT5-XL) shaped module, random-init.
+
+Plumbing for the hot path: gives the pruner the reference's 588 prunable
+matrices under the reference's names, in the reference's registration order
+(visual_encoder, ln_vision, Qformer, query_tokens, t5_model, t5_proj):
+  LAVIS/lavis/models/blip2_models/blip2_t5.py:42-168 (module + forward)
+  LAVIS/lavis/models/blip2_models/blip2.py:36-44 (maybe_autocast)
+  LAVIS/lavis/models/blip2_models/Qformer.py (BERT-base, cross-attn every 2nd
+  layer to the 1408-wide image tokens, 32 learned queries; query-only path)
+Text comes pre-tokenised: ``text_input`` / ``text_output`` are
+LongTensors of ids, pad id 0, so ``len(samples["text_input"])`` is still the
+batch size the loss closures read (pruners/utils.py:29,42).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .eva_vit import VisionTransformer, half_linear_weights
+from .t5 import T5ForConditionalGeneration, t5_config
+
+
+class _BertAttention(nn.Module):
+    def __init__(self, hidden, heads, kv_width):
+        super().__init__()
+        self.heads = heads
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(kv_width, hidden)
+        self.value = nn.Linear(kv_width, hidden)
+        self.dense = nn.Linear(hidden, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=1e-12)
+
+    def forward(self, x, kv=None):
+        kv = x if kv is None else kv
+        B, L, H = x.shape
+
+        def shape(t):
+            return t.view(B, -1, self.heads, H // self.heads).transpose(1, 2)
+
+        o = F.scaled_dot_product_attention(shape(self.query(x)), shape(self.key(kv)),
+                                           shape(self.value(kv)))
+        o = o.transpose(1, 2).reshape(B, L, H)
+        return self.LayerNorm(self.dense(o) + x)
+
+
+class _QformerLayer(nn.Module):
+    def __init__(self, hidden, heads, inter, encoder_width, has_cross):
+        super().__init__()
+        self.attention = _BertAttention(hidden, heads, hidden)
+        self.crossattention = _BertAttention(hidden, heads, encoder_width) if has_cross else None
+        self.intermediate_query = nn.Linear(hidden, inter)
+        self.output_query = nn.Linear(inter, hidden)
+        self.output_norm = nn.LayerNorm(hidden, eps=1e-12)
+
+    def forward(self, q, enc):
+        q = self.attention(q)
+        if self.crossattention is not None:
+            q = self.crossattention(q, enc)
+        return self.output_norm(self.output_query(F.gelu(self.intermediate_query(q))) + q)
+
+
+class Qformer(nn.Module):
+    def __init__(self, hidden=768, heads=12, inter=3072, layers=12, encoder_width=1408,
+                 cross_attention_freq=2):
+        super().__init__()
+        self.config = type("cfg", (), {"hidden_size": hidden})()
+        self.embeddings_norm = nn.LayerNorm(hidden, eps=1e-12)
+        self.layer = nn.ModuleList(
+            [_QformerLayer(hidden, heads, inter, encoder_width, i % cross_attention_freq == 0)
+             for i in range(layers)])
+
+    def forward(self, query_embeds, encoder_hidden_states):
+        q = self.embeddings_norm(query_embeds)
+        for lyr in self.layer:
+            q = lyr(q, encoder_hidden_states)
+        return q
+
+
+class Blip2T5(nn.Module):
+    def __init__(self, vit_kwargs=None, t5_cfg=None, qformer_kwargs=None, num_query_token=32,
+                 vit_precision="fp16", t5_dtype=torch.bfloat16, init_std=0.02):
+        super().__init__()
+        vit_kwargs = dict(vit_kwargs or {})
+        self.visual_encoder = VisionTransformer(init_std=init_std, **vit_kwargs)
+        self.ln_vision = nn.LayerNorm(self.visual_encoder.num_features)
+        if vit_precision == "fp16":
+            half_linear_weights(self.visual_encoder)
+        qk = dict(qformer_kwargs or {})
+        qk.setdefault("encoder_width", self.visual_encoder.num_features)
+        self.Qformer = Qformer(**qk)
+        self.query_tokens = nn.Parameter(
+            torch.zeros(1, num_query_token, self.Qformer.config.hidden_size))
+        nn.init.normal_(self.query_tokens, std=init_std)
+        self.t5_model = T5ForConditionalGeneration(t5_cfg or t5_config(), init_std=init_std)
+        if t5_dtype is not None:
+            for p in self.t5_model.parameters():
+                p.data = p.data.to(t5_dtype)
+        self.t5_proj = nn.Linear(self.Qformer.config.hidden_size, self.t5_model.config.d_model)
+        self.vit_autocast_dtype = torch.float16
+        self.t5_autocast_dtype = torch.bfloat16
+
+    @property
+    def device(self):
+        return self.query_tokens.device
+
+    def maybe_autocast(self, dtype=torch.float16):
+        if self.device.type == "cpu":
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=dtype)
+
+    # --- staged forward: the scoring loop may re-enter at any stage boundary ---
+    def encode_vision(self, image):
+        with self.maybe_autocast():
+            return self.ln_vision(self.visual_encoder(image))
+
+    def vision_to_t5_inputs(self, image_embeds):
+        q = self.query_tokens.expand(image_embeds.shape[0], -1, -1)
+        q = self.Qformer(q, image_embeds.to(q.dtype))
+        return self.t5_proj(q)
+
+    def language_loss(self, inputs_t5, samples):
+        ids = samples["text_input"].to(self.device)
+        out = samples["text_output"].to(self.device)
+        pad = self.t5_model.config.pad_token_id
+        atts_t5 = torch.ones(inputs_t5.shape[:-1], dtype=torch.long, device=self.device)
+        with self.maybe_autocast(dtype=torch.bfloat16):
+            emb = self.t5_model.encoder.embed_tokens(ids)
+            emb = torch.cat([inputs_t5.to(emb.dtype), emb], dim=1)
+            mask = torch.cat([atts_t5, (ids != pad).long()], dim=1)
+            res = self.t5_model(inputs_embeds=emb, attention_mask=mask,
+                                labels=out.masked_fill(out == pad, -100),
+                                decoder_attention_mask=(out != pad).long())
+        return res
+
+    def forward(self, samples):
+        image = samples["image"].to(self.device)
+        image_embeds = self.encode_vision(image)
+        inputs_t5 = self.vision_to_t5_inputs(image_embeds)
+        res = self.language_loss(inputs_t5, samples)
+        return {"loss": res.loss, "logits": res.logits}
+
+
+def blip2_flant5xl():
+    """Config 3 shape: 588 prunable matrices, 3 701 932 032 prunable elements."""
+    return Blip2T5(vit_kwargs=dict(img_size=224, patch_size=14, embed_dim=1408, depth=39,
+                                   num_heads=16, mlp_hidden=6144))
+
+
+def blip2_toy(depth=2, t5_layers=2, fp32=True):
+    """CPU-sized BLIP-2 shape for parity tests (fp32 everywhere when fp32=True)."""
+    return Blip2T5(
+        vit_kwargs=dict(img_size=28, patch_size=14, embed_dim=32, depth=depth, num_heads=4,
+                        mlp_hidden=64),
+        t5_cfg=t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=t5_layers,
+                         vocab_size=96),
+        qformer_kwargs=dict(hidden=24, heads=4, inter=48, layers=2),
+        num_query_token=4,
+        vit_precision="fp32" if fp32 else "fp16",
+        t5_dtype=None if fp32 else torch.bfloat16,
+        init_std=0.2,
+    )

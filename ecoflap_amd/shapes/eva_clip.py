@@ -1,0 +1,69 @@
+"""EVA-CLIP shaped vision classifier for the ``vit_wanda_pruner`` path (plumbing).
+
+What the pruner touches, mirrored from the reference:
+  LAVIS/lavis/models/clip_models/eva_model.py:398-409 (maybe_autocast, encode_image)
+  LAVIS/lavis/models/clip_models/eva_model.py:512-521 (predict: 100 * normalize(f) @ classifier)
+  prunable prefix ``visual`` with ``visual.blocks[i](x, rel_pos_bias=...)``
+The zero-shot text classifier is replaced by a fixed random ``classifier``
+matrix (the reference deletes ``model.text`` before pruning,
+evaluate_eva_clip.py:366-402).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .eva_vit import VisionTransformer
+
+
+class _VisualTower(VisionTransformer):
+    def __init__(self, out_dim, **kw):
+        super().__init__(**kw)
+        self.norm = nn.LayerNorm(self.embed_dim, eps=1e-6)
+        self.head = nn.Linear(self.embed_dim, out_dim, bias=False)
+        nn.init.normal_(self.head.weight, std=self.embed_dim ** -0.5)
+
+    def forward(self, image):
+        x = self.embed(image)
+        for blk in self.blocks:
+            x = blk(x, rel_pos_bias=None)
+        return self.head(self.norm(x)[:, 0])
+
+
+class EVACLIP(nn.Module):
+    def __init__(self, num_classes=16, out_dim=None, **vit_kwargs):
+        super().__init__()
+        out_dim = out_dim or vit_kwargs.get("embed_dim", 768)
+        self.visual = _VisualTower(out_dim, **vit_kwargs)
+        g = torch.Generator().manual_seed(1234)
+        cls = F.normalize(torch.randn(out_dim, num_classes, generator=g), dim=0)
+        self.register_buffer("classifier", cls)
+
+    @property
+    def device(self):
+        return self.classifier.device
+
+    def maybe_autocast(self, dtype=torch.float32):
+        if self.device.type == "cpu" or dtype == torch.float32:
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=dtype)
+
+    def encode_image(self, image):
+        return self.visual(image.to(self.device))
+
+    def predict(self, samples):
+        feats = F.normalize(self.encode_image(samples["image"]), dim=-1)
+        logits = 100.0 * feats @ self.classifier
+        return {"predictions": logits, "targets": samples["label"].to(self.device)}
+
+
+def vit_b16_clip(num_classes=1000):
+    """Config 1 shape: ViT-B/16 fp32 with EVA parameter names (48 prunable matrices)."""
+    return EVACLIP(num_classes=num_classes, out_dim=512, img_size=224, patch_size=16,
+                   embed_dim=768, depth=12, num_heads=12, mlp_hidden=3072)
+
+
+def vit_toy(depth=3, num_classes=5):
+    return EVACLIP(num_classes=num_classes, out_dim=16, img_size=32, patch_size=16,
+                   embed_dim=32, depth=depth, num_heads=4, mlp_hidden=64, init_std=0.2)

@@ -1,0 +1,129 @@
+"""Shape-compatible EVA ViT tower (plumbing for the hot path, not the product).
+
+Parameter names, shapes, registration order and the block call signature
+``blocks[i](x, rel_pos_bias=...)`` follow the reference's vision tower so the
+sparsity-table keys are identical:
+  LAVIS/lavis/models/eva_vit.py:64-184 (Attention/Block), :254-330, :444-471
+  (create_eva_vit_g: patch 14, dim 1408, depth 39, heads 16, mlp 6144, qkv_bias)
+Random-init only; no checkpoint loading, no drop-path, no window bias.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        # registration order matters: q_bias, v_bias, qkv, proj (eva_vit.py:78-118)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.q_bias = None
+            self.v_bias = None
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, rel_pos_bias=None):
+        B, N, C = x.shape
+        qkv = self.qkv(x)
+        if self.q_bias is not None:
+            qkv = qkv + torch.cat(
+                (self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(qkv.dtype)
+        qkv = qkv.reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        x = F.scaled_dot_product_attention(q, k, v, attn_mask=rel_pos_bias, scale=self.scale)
+        x = x.transpose(1, 2).reshape(B, N, -1)
+        return self.proj(x)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_hidden, qkv_bias=True, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias=qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, mlp_hidden)
+
+    def forward(self, x, rel_pos_bias=None):
+        x = x + self.attn(self.norm1(x), rel_pos_bias=rel_pos_bias)
+        x = x + self.mlp(self.norm2(x))
+        return x
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class VisionTransformer(nn.Module):
+    """``forward`` returns all tokens (BLIP-2 use, eva_vit.py:383-412)."""
+
+    def __init__(self, img_size=224, patch_size=14, embed_dim=1408, depth=39,
+                 num_heads=16, mlp_hidden=6144, qkv_bias=True, init_std=0.02):
+        super().__init__()
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size, patch_size, 3, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList(
+            [Block(embed_dim, num_heads, mlp_hidden, qkv_bias=qkv_bias) for _ in range(depth)])
+        self._init(init_std)
+
+    def _init(self, std):
+        nn.init.normal_(self.pos_embed, std=std)
+        nn.init.normal_(self.cls_token, std=std)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def embed(self, x):
+        x = self.patch_embed(x)
+        cls = self.cls_token.expand(x.shape[0], -1, -1)
+        x = torch.cat((cls.to(x.dtype), x), dim=1)
+        return x + self.pos_embed.to(x.dtype)
+
+    def forward(self, x):
+        x = self.embed(x)
+        for blk in self.blocks:
+            x = blk(x, None)  # positional, as eva_vit.py:404
+        return x
+
+
+def half_linear_weights(model):
+    """fp16 for Linear/Conv weights+biases only (eva_vit.py:427-441); norms stay fp32."""
+    for m in model.modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            m.weight.data = m.weight.data.half()
+            if m.bias is not None:
+                m.bias.data = m.bias.data.half()
+    return model
+
+
+def eva_vit_g(img_size=224, precision="fp16"):
+    vit = VisionTransformer(img_size=img_size, patch_size=14, embed_dim=1408, depth=39,
+                            num_heads=16, mlp_hidden=6144, qkv_bias=True)
+    if precision == "fp16":
+        half_linear_weights(vit)
+    return vit

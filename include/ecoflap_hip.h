@@ -1,0 +1,176 @@
+/*
+ * ecoflap_hip.h — C ABI of the MI355X (gfx950) ECoFLaP scoring + pruning kernels.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (ylsung/ECoFLaP) is pure Python on torch; it has no FFI of its own, so each
+ * entry point below names the reference op chain (file:line, relative to the
+ * reference checkout) that a maintainer would replace with a ctypes call — the
+ * binding stub is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only: raw device pointers (tensor.data_ptr()), element
+ *     counts, a dtype code, and the HIP stream handle as void*
+ *     (torch.cuda.current_stream().cuda_stream); no torch types.
+ *   - every function returns 0 on success, a positive hipError_t value on a
+ *     HIP failure, or a negative ECOFLAP_E* code on a bad argument.
+ *   - nothing is allocated, freed or synchronised inside a launch function
+ *     (graph-capture safe); scratch is a caller-owned workspace whose size
+ *     comes from the matching *_workspace_bytes() query.
+ *   - no global state, re-entrant, no ownership transfer.
+ *   - all float arithmetic is done in fp32 and rounded to the storage dtype
+ *     after EVERY reference op (no fma contraction), so results equal the
+ *     reference's torch op chain bit for bit when the same z is supplied.
+ */
+#ifndef ECOFLAP_HIP_H
+#define ECOFLAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* storage dtype codes (parameter / activation dtype) */
+#define ECOFLAP_F32  0
+#define ECOFLAP_F16  1
+#define ECOFLAP_BF16 2
+
+/* argument errors (negative so they never collide with hipError_t) */
+#define ECOFLAP_EDTYPE  (-1)
+#define ECOFLAP_ENULL   (-2)
+#define ECOFLAP_ESIZE   (-3)
+#define ECOFLAP_EMODE   (-4)
+#define ECOFLAP_EALIGN  (-5)
+#define ECOFLAP_EWORKSPACE (-6)
+
+/* reduce modes of ecoflap_absprod_reduce* */
+#define ECOFLAP_RED_ABSW_ABSG 0 /* sum |w|*|g|   GradMagAbs     layer_single_base_pruner.py:455,467 */
+#define ECOFLAP_RED_SQW_SQG   1 /* sum w^2*g^2   GradMagSquare  :453,465 */
+#define ECOFLAP_RED_ABSG      2 /* sum |g|       GradOnly       :455,469 (w ignored) */
+#define ECOFLAP_RED_ABSW      3 /* sum |w|       MEZO-GradMagAbs    :556 (g ignored) */
+#define ECOFLAP_RED_SQW       4 /* sum w^2       MEZO-GradMagSquare :559 (g ignored) */
+
+const char* ecoflap_version(void);
+const char* ecoflap_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * K1  zeroth-order perturbation
+ * replaces LayerSparsity.zo_perturb_parameters
+ *   LAVIS/lavis/compression/pruners/layer_single_base_pruner.py:473-486
+ *     torch.manual_seed(seed); z = torch.normal(0,1,size,dtype=param.dtype)
+ *     param.data = param.data + scaling_factor * z * zo_eps
+ * Arithmetic per element (rd = round-to-nearest-even to `dtype`):
+ *     t = rd(z * scaling_factor);  u = rd(t * zo_eps);  w = rd(w + u)
+ * z: if `z` != NULL it is a device array of n elements of `dtype` (parity
+ * mode: the caller supplies the reference's own torch.normal draw); if NULL,
+ * z is generated in registers: Philox4x32-10, key = seed, counter = e/4,
+ * Box-Muller, rounded to `dtype` — the stream ecoflap_zo_fill_normal writes.
+ * w must be 16-byte aligned (torch allocations are).
+ * ------------------------------------------------------------------------- */
+int ecoflap_zo_perturb(void* w, int64_t n, int dtype,
+                       float scaling_factor, float zo_eps,
+                       uint64_t seed, const void* z, void* stream);
+
+/* The reference calls K1 three times per (layer, batch, noise) with the same
+ * seed and scaling factors +1, -2, +1 (layer_single_base_pruner.py:530-539).
+ * All three results are elementwise functions of (w, z); this entry point
+ * computes them in ONE pass over w — same three roundings each, so
+ * w_plus / w_minus / w_restored are bit-identical to three ecoflap_zo_perturb
+ * calls — reading w once and generating z once (4*s instead of 6*s bytes per
+ * element).  Outputs may alias w_in (in place) but not each other. */
+int ecoflap_zo_perturb_triple(const void* w_in, void* w_plus, void* w_minus,
+                              void* w_restored, int64_t n, int dtype,
+                              float zo_eps, uint64_t seed, const void* z,
+                              void* stream);
+
+/* Materialise the in-register z stream of K1 for (seed, n, dtype). */
+int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,
+                           void* stream);
+
+/* Raw Philox4x32-10 words (counter = i/4, lane = i%4) — integer, bit-exact
+ * against oracle/ecoflap_oracle.c:philox4x32_10. */
+int ecoflap_philox_u32(uint32_t* out, int64_t n, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K3+K4  fused |grad| (x) |W| per-layer reduction
+ * replaces the accumulate + product + .sum() chain
+ *   layer_single_base_pruner.py:446-471 (first order), :551-559 (MEZO-GradMag*)
+ *   and the per-layer `.sum()` at :370
+ * out_accum[0] += sum_e f(w_e, g_e)   (double, device memory; the caller
+ * zeroes it once per layer and divides by the batch count afterwards).
+ * Deterministic: fixed per-block partials, fixed-order final sum.
+ * ------------------------------------------------------------------------- */
+size_t ecoflap_absprod_reduce_workspace_bytes(int64_t n);
+int ecoflap_absprod_reduce(const void* w, const void* g, int64_t n,
+                           int dtype_w, int dtype_g, int mode,
+                           double* out_accum, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* Multi-tensor form: one launch over every prunable matrix of the model.
+ * table: device array of n_layers rows {w_ptr, g_ptr, numel} (int64 each).
+ * out_accum: device double[n_layers], accumulated into. */
+size_t ecoflap_absprod_reduce_multi_workspace_bytes(int n_layers);
+int ecoflap_absprod_reduce_multi(const int64_t* table, int n_layers,
+                                 int64_t max_numel, int dtype_w, int dtype_g,
+                                 int mode, double* out_accum, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K6  Wanda calibration statistic (running mean of per-input-channel sum x^2)
+ * replaces WrappedGPT.add_batch   LAVIS/lavis/compression/pruners/wanda_pruner.py:71-84
+ *     scaler_row *= n/(n+b); n += b; scaler_row += norm(x, 2, dim=tokens)**2 / n
+ * x: [tokens, cols] row-major of `dtype`; scaler_row: float[cols].
+ * ------------------------------------------------------------------------- */
+size_t ecoflap_colsqnorm_workspace_bytes(int64_t tokens, int64_t cols);
+int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens,
+                            int64_t cols, int dtype, int64_t nsamples_before,
+                            int64_t batch, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K7  Wanda metric + selection + zeroing
+ * metric = |W| * sqrt(scaler_row)  (fp32)          wanda_pruner.py:260, :541
+ *  - rows mode (T5/BERT):  per row, stable ascending sort, zero the first k
+ *    columns (ties: lower column index first)       wanda_pruner.py:272-279
+ *  - matrix mode (ViT): thres = sorted(flatten)[k]; zero metric <= thres
+ *                                                   wanda_pruner.py:555-558
+ * mask_out (optional): uint8[rows*cols], 1 where zeroed.
+ * ------------------------------------------------------------------------- */
+size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols);
+int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
+                             int64_t cols, int dtype, int64_t k,
+                             uint8_t* mask_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
+                               int64_t cols, int dtype, int64_t k,
+                               uint8_t* mask_out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K8  mask apply in masked fine-tuning:  grad *= mask
+ * replaces UPop/ecoflap_compression_vqa.py:124-129
+ * keep_mask: uint8[n], 1 = keep (multiply by 1), 0 = pruned (multiply by 0).
+ * ------------------------------------------------------------------------- */
+int ecoflap_mask_mul(void* g, const uint8_t* keep_mask, int64_t n, int dtype,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K5  sparsity allocator (host, no GPU): keep-counts per group
+ * replaces LayerSparsity.compute_the_sparsity_per_group
+ *   layer_single_base_pruner.py:247-314, replaying its mixed
+ *   float32 / int32 / int64 tensor arithmetic op for op.
+ * group_scores: float[n_groups]; group_num_params: int64[n_groups].
+ * out_sparsity: float[n_groups] (fp32-valued, as `.item()` of a float tensor)
+ * out_keep (optional): double[n_groups] — the final keep vector.
+ * ------------------------------------------------------------------------- */
+int ecoflap_allocate_sparsity(const float* group_scores,
+                              const int64_t* group_num_params, int n_groups,
+                              int64_t total_parameters_to_keep,
+                              double max_sparsity_per_layer,
+                              float* out_sparsity, double* out_keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECOFLAP_HIP_H */

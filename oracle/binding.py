@@ -1,0 +1,105 @@
+"""ctypes binding of oracle/libecoflap_oracle.so over torch CPU tensors."""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libecoflap_oracle.so")
+DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ecoflap_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    return Oracle(ctypes.CDLL(_SO))
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _cpu(t):
+    assert t.device.type == "cpu" and t.is_contiguous(), "oracle works on contiguous CPU tensors"
+    return t
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        i64, f32, u64, vp, ci = (ctypes.c_int64, ctypes.c_float, ctypes.c_uint64,
+                                 ctypes.c_void_p, ctypes.c_int)
+        L.oracle_zo_perturb.argtypes = [vp, i64, ci, f32, f32, vp]
+        L.oracle_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, vp]
+        L.oracle_philox_u32.argtypes = [vp, i64, u64]
+        L.oracle_absprod_reduce.argtypes = [vp, vp, i64, ci, ci, ci]
+        L.oracle_absprod_reduce.restype = ctypes.c_double
+        L.oracle_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64]
+        L.oracle_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp]
+        L.oracle_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp]
+        L.oracle_mask_mul.argtypes = [vp, vp, i64, ci]
+        L.oracle_round_array.argtypes = [vp, i64, ci]
+
+    def zo_perturb(self, w, scaling_factor, zo_eps, z):
+        _cpu(w), _cpu(z)
+        assert z.dtype == w.dtype and z.numel() == w.numel()
+        self.lib.oracle_zo_perturb(_p(w), w.numel(), DT[w.dtype], scaling_factor, zo_eps, _p(z))
+
+    def zo_perturb_triple(self, w, zo_eps, z):
+        _cpu(w), _cpu(z)
+        plus, minus, rest = torch.empty_like(w), torch.empty_like(w), torch.empty_like(w)
+        self.lib.oracle_zo_perturb_triple(_p(w), _p(plus), _p(minus), _p(rest), w.numel(),
+                                          DT[w.dtype], zo_eps, _p(z))
+        return plus, minus, rest
+
+    def philox_u32(self, n, seed):
+        out = torch.empty(n, dtype=torch.int32)
+        self.lib.oracle_philox_u32(_p(out), n, seed)
+        return out
+
+    def absprod_reduce(self, w, g, mode):
+        n = (w if w is not None else g).numel()
+        wp = _p(_cpu(w)) if w is not None else None
+        gp = _p(_cpu(g)) if g is not None else None
+        return self.lib.oracle_absprod_reduce(
+            wp, gp, n, DT[w.dtype] if w is not None else 0, DT[g.dtype] if g is not None else 0,
+            mode)
+
+    def colsqnorm_accum(self, scaler_row, x2d, n_before, batch):
+        _cpu(scaler_row), _cpu(x2d)
+        tokens, cols = x2d.shape
+        self.lib.oracle_colsqnorm_accum(_p(scaler_row), _p(x2d), tokens, cols, DT[x2d.dtype],
+                                        n_before, batch)
+
+    def wanda_prune_rows(self, w, scaler_row, k, want_mask=True):
+        _cpu(w), _cpu(scaler_row)
+        rows, cols = w.shape
+        mask = torch.zeros(rows, cols, dtype=torch.uint8) if want_mask else None
+        self.lib.oracle_wanda_prune_rows(_p(w), _p(scaler_row), rows, cols, DT[w.dtype], k,
+                                         _p(mask) if want_mask else None)
+        return mask
+
+    def wanda_prune_matrix(self, w, scaler_row, k, want_mask=True):
+        _cpu(w), _cpu(scaler_row)
+        rows, cols = w.shape
+        mask = torch.zeros(rows, cols, dtype=torch.uint8) if want_mask else None
+        self.lib.oracle_wanda_prune_matrix(_p(w), _p(scaler_row), rows, cols, DT[w.dtype], k,
+                                           _p(mask) if want_mask else None)
+        return mask
+
+    def mask_mul(self, g, keep):
+        _cpu(g), _cpu(keep)
+        self.lib.oracle_mask_mul(_p(g), _p(keep), g.numel(), DT[g.dtype])
+
+    def round_array(self, x, dtype):
+        _cpu(x)
+        self.lib.oracle_round_array(_p(x), x.numel(), DT[dtype])

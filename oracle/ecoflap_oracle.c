@@ -1,0 +1,251 @@
+/*
+ * ecoflap_oracle.c — CPU restatement of the ECoFLaP hot-path arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * Parity status: PINNED.  Every function here is checked against golden
+ * vectors produced by importing the reference's own Python pruners in the
+ * build container (tests/golden/make_golden.py -> tests/golden/g*.npz;
+ * tests/test_oracle_golden.py).  The reference has no tests of its own for
+ * this path.
+ *
+ * Citations are relative to the reference checkout (ylsung/ECoFLaP):
+ *   P  = LAVIS/lavis/compression/pruners/layer_single_base_pruner.py
+ *   W  = LAVIS/lavis/compression/pruners/wanda_pruner.py
+ *
+ * torch semantics restated: every elementwise torch op on an fp16/bf16 tensor
+ * computes in fp32 and rounds the result to the storage dtype (round to
+ * nearest even); ops are separate kernels, so nothing is fused (build with
+ * -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DT_F32 0
+#define DT_F16 1
+#define DT_BF16 2
+
+/* ------------------------------------------------------------------ scalar conversions */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline float bf16_to_f(uint16_t h) { return u2f((uint32_t)h << 16); }
+static inline uint16_t f_to_bf16(float f) {
+    uint32_t u = f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u); /* quiet NaN */
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float f16_to_f(uint16_t h) {
+    uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return u2f(s);
+        float v = (float)m * 5.9604644775390625e-08f; /* 2^-24 */
+        return (s ? -v : v);
+    }
+    if (e == 31) return u2f(s | 0x7f800000u | (m << 13));
+    return u2f(s | ((e + 112u) << 23) | (m << 13));
+}
+static inline uint16_t f_to_f16(float f) {
+    uint32_t u = f2u(f), s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(s | 0x7e00u);
+    if (a >= 0x477ff000u) return (uint16_t)(s | 0x7c00u);      /* >= 65520 -> inf */
+    if (a < 0x33000001u) return (uint16_t)s;                    /* <= 2^-25 -> 0 (ties to even) */
+    if (a < 0x38800000u) {                                     /* subnormal half */
+        /* value = a_f * 2^24 rounded to nearest even integer */
+        float scaled = u2f(a) * 16777216.0f;                   /* exact: power of two */
+        float r = nearbyintf(scaled);
+        return (uint16_t)(s | (uint32_t)r);
+    }
+    uint32_t m = a & 0x7fffffu, e = (a >> 23) - 112u;
+    uint32_t h = (e << 10) | (m >> 13), rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(s | h);
+}
+
+static inline float load_dt(const void* p, int64_t i, int dt) {
+    if (dt == DT_F32) return ((const float*)p)[i];
+    if (dt == DT_F16) return f16_to_f(((const uint16_t*)p)[i]);
+    return bf16_to_f(((const uint16_t*)p)[i]);
+}
+static inline void store_dt(void* p, int64_t i, int dt, float v) {
+    if (dt == DT_F32) ((float*)p)[i] = v;
+    else if (dt == DT_F16) ((uint16_t*)p)[i] = f_to_f16(v);
+    else ((uint16_t*)p)[i] = f_to_bf16(v);
+}
+static inline float round_dt(float v, int dt) {
+    if (dt == DT_F32) return v;
+    if (dt == DT_F16) return f16_to_f(f_to_f16(v));
+    return bf16_to_f(f_to_bf16(v));
+}
+
+/* exported for tests of the conversions themselves */
+void oracle_round_array(float* x, int64_t n, int dt) {
+    for (int64_t i = 0; i < n; ++i) x[i] = round_dt(x[i], dt);
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10
+ * Published algorithm (Salmon et al., "Parallel random numbers: as easy as
+ * 1, 2, 3", SC'11; Random123 philox.h).  The reference itself draws z with
+ * torch.normal (P:485), whose stream is device specific; the build's
+ * in-register generator is defined here instead and parity with the reference
+ * is taken with z supplied explicitly. */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+void oracle_philox4x32_10(uint32_t out[4], uint64_t counter, uint64_t key) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void oracle_philox_u32(uint32_t* out, int64_t n, uint64_t seed) {
+    uint32_t r[4];
+    for (int64_t i = 0; i < n; ++i) {
+        if ((i & 3) == 0 || i == 0) oracle_philox4x32_10(r, (uint64_t)(i >> 2), seed);
+        out[i] = r[i & 3];
+    }
+}
+
+/* ------------------------------------------------------------------ K1 (P:473-486)
+ * param.data = param.data + scaling_factor * z * zo_eps, three roundings. */
+static inline float k1_step(float w, float z, float sf, float eps, int dt) {
+    float t = round_dt(z * sf, dt);    /* scaling_factor * z   */
+    float u = round_dt(t * eps, dt);   /* (...) * zo_eps       */
+    return round_dt(w + u, dt);        /* param.data + (...)   */
+}
+void oracle_zo_perturb(void* w, int64_t n, int dt, float sf, float eps, const void* z) {
+    for (int64_t i = 0; i < n; ++i)
+        store_dt(w, i, dt, k1_step(load_dt(w, i, dt), load_dt(z, i, dt), sf, eps, dt));
+}
+/* P:530-539: +1, -2, +1 with the same z; all three states from one read. */
+void oracle_zo_perturb_triple(const void* w_in, void* w_plus, void* w_minus, void* w_rest,
+                              int64_t n, int dt, float eps, const void* z) {
+    for (int64_t i = 0; i < n; ++i) {
+        float zz = load_dt(z, i, dt);
+        float a = k1_step(load_dt(w_in, i, dt), zz, 1.0f, eps, dt);
+        float b = k1_step(a, zz, -2.0f, eps, dt);
+        float c = k1_step(b, zz, 1.0f, eps, dt);
+        store_dt(w_plus, i, dt, a);
+        store_dt(w_minus, i, dt, b);
+        store_dt(w_rest, i, dt, c);
+    }
+}
+
+/* ------------------------------------------------------------------ K3+K4 (P:446-471, :551-559, :370)
+ * modes: 0 sum|w||g|  1 sum w^2 g^2  2 sum|g|  3 sum|w|  4 sum w^2.
+ * Element terms are fp32 products as torch computes them (W.float(), g.float());
+ * the running sum is double (the reference's fp32 .sum() is matched to 1e-5 rel). */
+double oracle_absprod_reduce(const void* w, const void* g, int64_t n, int dtw, int dtg, int mode) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float a = (mode == 2) ? 0.f : load_dt(w, i, dtw);
+        float b = (mode >= 3) ? 0.f : load_dt(g, i, dtg);
+        float t;
+        switch (mode) {
+            case 0: t = fabsf(a) * fabsf(b); break;
+            case 1: t = (a * a) * (b * b); break;
+            case 2: t = fabsf(b); break;
+            case 3: t = fabsf(a); break;
+            default: t = a * a; break;
+        }
+        acc += (double)t;
+    }
+    return acc;
+}
+
+/* ------------------------------------------------------------------ K6 (W:71-84)
+ * scaler_row *= n/(n+b); n += b; scaler_row += norm(x,2,dim=tokens)**2 / n */
+void oracle_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
+                            int dt, int64_t n_before, int64_t batch) {
+    float decay = (float)((double)n_before / (double)(n_before + batch));
+    float n_new = (float)(n_before + batch);
+    for (int64_t c = 0; c < cols; ++c) {
+        double s = 0.0;
+        for (int64_t t = 0; t < tokens; ++t) {
+            float v = load_dt(x, t * cols + c, dt);
+            s += (double)(v * v);
+        }
+        float nrm = sqrtf((float)s);
+        float sq = nrm * nrm;
+        float r = scaler_row[c] * decay;
+        scaler_row[c] = r + sq / n_new;
+    }
+}
+
+/* ------------------------------------------------------------------ K7 (W:260-279, W:541-558) */
+static inline float wanda_metric(const void* w, int64_t i, int dt, float sq) {
+    return fabsf(load_dt(w, i, dt)) * sq;   /* abs(W) * sqrt(scaler_row) in fp32 */
+}
+typedef struct { float m; int64_t idx; } mi_t;
+static int cmp_mi(const void* a, const void* b) {
+    const mi_t* x = (const mi_t*)a; const mi_t* y = (const mi_t*)b;
+    /* torch.sort(stable=True) ascending: NaN last, ties by original index */
+    int xn = isnan(x->m), yn = isnan(y->m);
+    if (xn != yn) return xn - yn;
+    if (!xn) { if (x->m < y->m) return -1; if (x->m > y->m) return 1; }
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+/* rows mode: zero the first k columns of each row in stable ascending metric order */
+void oracle_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows, int64_t cols,
+                             int dt, int64_t k, uint8_t* mask) {
+    mi_t* buf = (mi_t*)malloc(sizeof(mi_t) * (size_t)cols);
+    float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
+    for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
+    if (mask) memset(mask, 0, (size_t)(rows * cols));
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int64_t c = 0; c < cols; ++c) {
+            buf[c].m = wanda_metric(w, r * cols + c, dt, sq[c]);
+            buf[c].idx = c;
+        }
+        qsort(buf, (size_t)cols, sizeof(mi_t), cmp_mi);
+        for (int64_t j = 0; j < k && j < cols; ++j) {
+            store_dt(w, r * cols + buf[j].idx, dt, 0.0f);
+            if (mask) mask[r * cols + buf[j].idx] = 1;
+        }
+    }
+    free(buf); free(sq);
+}
+/* matrix mode: thres = sort(flatten)[k]; zero every metric <= thres */
+static int cmp_f(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    int xn = isnan(x), yn = isnan(y);
+    if (xn != yn) return xn - yn;
+    return (x > y) - (x < y);
+}
+void oracle_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows, int64_t cols,
+                               int dt, int64_t k, uint8_t* mask) {
+    int64_t n = rows * cols;
+    float* m = (float*)malloc(sizeof(float) * (size_t)n);
+    float* s = (float*)malloc(sizeof(float) * (size_t)n);
+    float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
+    for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
+    for (int64_t i = 0; i < n; ++i) m[i] = wanda_metric(w, i, dt, sq[i % cols]);
+    memcpy(s, m, sizeof(float) * (size_t)n);
+    qsort(s, (size_t)n, sizeof(float), cmp_f);
+    float thres = s[k];
+    for (int64_t i = 0; i < n; ++i) {
+        int z = (m[i] <= thres);
+        if (z) store_dt(w, i, dt, 0.0f);
+        if (mask) mask[i] = (uint8_t)z;
+    }
+    free(m); free(s); free(sq);
+}
+
+/* ------------------------------------------------------------------ K8 (UPop/ecoflap_compression_vqa.py:124-129) */
+void oracle_mask_mul(void* g, const uint8_t* keep, int64_t n, int dt) {
+    for (int64_t i = 0; i < n; ++i)
+        store_dt(g, i, dt, load_dt(g, i, dt) * (keep[i] ? 1.0f : 0.0f));
+}

@@ -1,0 +1,398 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference's
+own pruners from /root/reference (read-only) and running them on the build's toy
+shape modules with fixed inputs.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box; only the vectors written here do.
+Nothing of the reference's source is copied: the fixtures hold inputs and the
+outputs the reference computed for them.
+
+Reference entry points exercised:
+  UPop/pruners/layer_single_base_pruner.py  LayerSparsity (byte-identical to the LAVIS copy
+      except imports): zo_perturb_parameters, compute_importance_scores_mezo,
+      compute_importance_scores, compute_the_sparsity_per_group, return_sparsity
+  LAVIS/lavis/compression/pruners/wanda_pruner.py  WrappedGPT, T5/VIT/BLIPT5 LayerWandaPruner
+      (loaded by file path with the `lavis` package stubbed in sys.modules)
+"""
+import importlib.util
+import os
+import signal
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from ecoflap_amd.shapes import synthetic as S  # noqa: E402
+from ecoflap_amd.shapes.blip2_t5 import blip2_toy  # noqa: E402
+from ecoflap_amd.shapes.eva_clip import vit_toy  # noqa: E402
+from ecoflap_amd.shapes.t5 import T5, t5_config  # noqa: E402
+
+
+# --------------------------------------------------------------------------- reference import
+def import_upop_pruners():
+    sys.path.insert(0, os.path.join(REF, "UPop"))
+    from pruners.layer_single_base_pruner import LayerSparsity  # type: ignore
+    from pruners.wanda_pruner import WrappedGPT  # type: ignore
+    return LayerSparsity, WrappedGPT
+
+
+def import_lavis_pruners():
+    """Recipe 2 of SURVEY.md §8c: stub the lavis package, load the pruner files by path."""
+    def mod(name):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    for n in ["lavis", "lavis.common", "lavis.datasets", "lavis.models", "lavis.models.blip2_models",
+              "lavis.models.t5_models", "lavis.models.clip_models", "lavis.compression",
+              "lavis.compression.pruners"]:
+        mod(n)
+
+    class _Registry:
+        mapping = {}
+
+        @classmethod
+        def register_pruner(cls, name):
+            def wrap(c):
+                cls.mapping[name] = c
+                return c
+            return wrap
+
+        @classmethod
+        def get_pruner_class(cls, name):
+            return cls.mapping.get(name)
+
+    mod("lavis.common.registry").registry = _Registry
+    mod("lavis.datasets.data_utils").prepare_sample = lambda samples, cuda_enabled=True: samples
+    mod("lavis.models.blip2_models.blip2_t5").Blip2T5 = object
+    mod("lavis.models.t5_models.t5").T5 = object
+    mod("lavis.models.clip_models.eva_model").EVA_CLIP = object
+    base = os.path.join(REF, "LAVIS/lavis/compression/pruners")
+    loaded = {}
+    for f in ["utils", "base_pruner", "layer_single_base_pruner", "wanda_pruner"]:
+        name = f"lavis.compression.pruners.{f}"
+        spec = importlib.util.spec_from_file_location(name, os.path.join(base, f + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        loaded[f] = m
+    return _Registry, loaded
+
+
+def bits(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float32:
+        return t.view(torch.int32).numpy().copy()
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return t.view(torch.int16).numpy().copy()
+    return t.numpy().copy()
+
+
+def state_bits(model):
+    return {k: bits(v) for k, v in model.state_dict().items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", name, f"{os.path.getsize(path)/1024:.1f} KiB")
+
+
+class _Timeout(Exception):
+    pass
+
+
+def _alarm(*_):
+    raise _Timeout()
+
+
+# --------------------------------------------------------------------------- G1: K1 perturb
+def golden_k1(LayerSparsity):
+    out = {}
+    cases = []
+    g = torch.Generator().manual_seed(7)
+    for dt_name, dt in [("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)]:
+        for n, eps, seed in [(5003, 1e-3, 123456789), (4096, 1e-2, 7), (1, 1e-3, 99)]:
+            w0 = (torch.randn(n, generator=g) * 0.05).to(dt)
+            p = nn.Parameter(w0.clone(), requires_grad=False)
+            torch.manual_seed(seed)  # the reference's own draw, layer_single_base_pruner.py:482-485
+            z = torch.normal(mean=0, std=1, size=p.data.size(), device=p.data.device,
+                             dtype=p.data.dtype)
+            key = f"{dt_name}_{n}_{seed}"
+            out[key + "_w0"] = bits(w0)
+            out[key + "_z"] = bits(z)
+            for step, sf in enumerate([1, -2, 1]):
+                LayerSparsity.zo_perturb_parameters(None, [p], random_seed=seed,
+                                                    scaling_factor=sf, zo_eps=eps)
+                out[key + f"_w{step + 1}"] = bits(p.data)
+            cases.append((dt_name, n, eps, seed))
+    out["cases"] = np.array([f"{a}|{b}|{c!r}|{d}" for a, b, c, d in cases])
+    save("g1_zo_perturb.npz", **out)
+
+
+# --------------------------------------------------------------------------- G4: allocator
+def golden_allocator(LayerSparsity):
+    rng = np.random.default_rng(2024)
+    recs = []
+
+    def run(scores, nums, sparsity, max_s):
+        total = int(sum(nums))
+        keep = int(total * (1 - sparsity))
+        gs = {f"g{i}": torch.tensor(float(s), dtype=torch.float32) for i, s in enumerate(scores)}
+        gn = {f"g{i}": int(n) for i, n in enumerate(nums)}
+        signal.signal(signal.SIGALRM, _alarm)
+        signal.alarm(5)
+        try:
+            res = LayerSparsity.compute_the_sparsity_per_group(None, keep, gs, gn, max_s)
+        except _Timeout:
+            return None  # reference does not terminate on this input: not a fixture
+        finally:
+            signal.alarm(0)
+        return keep, np.array([res[f"g{i}"] for i in range(len(nums))], dtype=np.float64)
+
+    def add(scores, nums, sparsity, max_s, tag):
+        scores = np.asarray(scores, dtype=np.float32)
+        nums = np.asarray(nums, dtype=np.int64)
+        r = run(scores, nums, sparsity, max_s)
+        if r is None:
+            print("  skipped non-terminating case", tag)
+            return
+        recs.append(dict(tag=tag, scores=scores, nums=nums, sparsity=sparsity, max_s=max_s,
+                         keep=r[0], out=r[1]))
+
+    # BLIP-2 scale: 39 ViT-g blocks (25 231 360 params each, > 2**24) + 24 enc + 24 dec blocks
+    vit = 4224 * 1408 + 1408 * 1408 + 6144 * 1408 + 1408 * 6144
+    enc = 4 * 2048 * 2048 + 3 * 5120 * 2048
+    dec = 8 * 2048 * 2048 + 3 * 5120 * 2048
+    blip2_nums = [vit] * 39 + [enc] * 24 + [dec] * 24
+    for t in range(12):
+        sc = rng.random(87).astype(np.float32) * 10.0 ** rng.integers(-2, 4)
+        if t % 3 == 0:
+            sc[:39] *= 20  # vision-heavy scores: hits the clamp / full-group path
+        add(sc, blip2_nums, 0.5, 0.6, f"blip2_{t}")
+        add(sc, blip2_nums, 0.5, 0.8, f"blip2_max08_{t}")
+    add(rng.random(87), blip2_nums, 0.4, 0.5, "blip2_s04")
+    add(rng.random(48), [enc] * 24 + [dec] * 24, 0.5, 0.6, "flant5xl")
+    add(rng.random(12), [2304 * 768 + 768 * 768 + 2 * 3072 * 768] * 12, 0.5, 0.6, "vitb16")
+    # avg-normalised scores (tiny magnitudes), zeros, single group, equal max
+    add(rng.random(87) * 1e-8, blip2_nums, 0.5, 0.6, "blip2_avg_small")
+    add([0.0, 1.0, 2.0, 0.0, 5.0], [100, 200, 300, 400, 500], 0.5, 0.6, "zeros_in_scores")
+    add([1.0], [1000], 0.5, 0.6, "single_group")
+    add(rng.random(9), rng.integers(10, 2000, 9), 0.5, 0.5, "max_equals_original")
+    add([100.0, 1e-3, 1e-3, 1e-3], [1000, 1000, 1000, 1000], 0.5, 0.9, "dominant_group")
+    add([1.0, 1.0, 1.0, 1.0], [10, 20, 30, 40], 0.3, 1.0, "max_one")
+    for t in range(160):
+        G = int(rng.integers(1, 100))
+        hi = int(10 ** rng.integers(2, 8))
+        nums = rng.integers(1, hi, G)
+        sc = rng.random(G).astype(np.float32) * 10.0 ** rng.integers(-6, 6)
+        if t % 5 == 0:
+            sc[rng.random(G) < 0.3] = 0
+        if t % 7 == 0:
+            sc = sc ** 6  # very skewed: stuck / over-target branches
+        sp = float(rng.choice([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7]))
+        mx = float(rng.choice([sp, round(sp + 0.1, 1), 0.8, 0.9, 1.0]))
+        if mx < sp:
+            mx = sp
+        add(sc, nums, sp, mx, f"rand_{t}")
+    out = {"n": np.array(len(recs))}
+    for i, r in enumerate(recs):
+        out[f"{i}_scores"] = r["scores"]
+        out[f"{i}_nums"] = r["nums"]
+        out[f"{i}_out"] = r["out"]
+        out[f"{i}_meta"] = np.array([r["sparsity"], r["max_s"], float(r["keep"])], dtype=np.float64)
+        out[f"{i}_tag"] = np.array(r["tag"])
+    save("g4_allocator.npz", **out)
+
+
+# --------------------------------------------------------------------------- G5: WrappedGPT
+def golden_wrapped(WrappedGPT):
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    cases = []
+    for dt_name, dt in [("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)]:
+        for cols, shapes in [(48, [(2, 7, 48), (2, 7, 48), (3, 5, 48)]), (130, [(4, 33, 130)] * 2),
+                             (8, [(5, 8)])]:
+            lin = nn.Linear(cols, 4)
+            wg = WrappedGPT(lin)
+            key = f"{dt_name}_{cols}"
+            for i, shp in enumerate(shapes):
+                x = (torch.randn(*shp, generator=g) * 1.7).to(dt)
+                wg.add_batch(x, None)
+                out[f"{key}_x{i}"] = bits(x)
+                out[f"{key}_s{i}"] = wg.scaler_row.numpy().copy()
+            cases.append(f"{key}|{len(shapes)}")
+    out["cases"] = np.array(cases)
+    save("g5_wrapped_gpt.npz", **out)
+
+
+# --------------------------------------------------------------------------- G2/G3: scoring
+class LossLog:
+    def __init__(self, fn):
+        self.fn = fn
+        self.values = []
+
+    def __call__(self, model, batch, cuda_enabled):
+        loss, n = self.fn(model, batch, cuda_enabled)
+        self.values.append(float(loss.detach()))
+        return loss, n
+
+
+def block_mapping(model, prefixes, depth_of):
+    m = {}
+    for k, v in model.named_parameters():
+        if v.dim() == 2 and ".block" in k and "relative_attention_bias.weight" not in k:
+            for p in prefixes:
+                if k.startswith(p):
+                    m[k] = ".".join(k.split(".")[:depth_of[p]])
+    return m
+
+
+def golden_scoring(LayerSparsity, lavis):
+    utils = lavis["utils"]
+    out = {}
+    # --- toy ViT, vision loss
+    torch.manual_seed(3)
+    vit = vit_toy().eval()
+    vit_batches = S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5)
+    # --- toy BLIP-2, vision-language loss
+    torch.manual_seed(4)
+    blip = blip2_toy().eval()
+    blip_batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    for tag, model, batches, loss_fn, prefixes, depth in [
+        ("vit", vit, vit_batches, utils.loss_vision, ["visual"], {"visual": 3}),
+        ("blip2", blip, blip_batches, utils.loss_vision_language,
+         ["t5_model", "visual_encoder"], {"t5_model": 4, "visual_encoder": 3}),
+    ]:
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        for k, v in init.items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        mapping = block_mapping(model, prefixes, depth)
+        names = [k for k, _ in model.named_parameters() if k in mapping]
+        out[f"{tag}_names"] = np.array(names)
+        out[f"{tag}_groups"] = np.array([mapping[k] for k in names])
+        for method, num_noise, num_samples in [
+            ("MEZO-GradOnly_sum", 1, 8), ("MEZO-GradOnly_avg", 1, 4), ("MEZO-GradMagAbs_sum", 2, 8),
+            ("MEZO-GradMagSquare_avg", 1, 6),
+            ("GradOnly_sum", 1, 8), ("GradMagAbs_sum", 1, 6), ("GradMagSquare_avg", 1, 8),
+        ]:
+            model.load_state_dict(init)
+            for p in model.parameters():
+                p.requires_grad = True
+            log = LossLog(loss_fn)
+            np_seed = 42
+            np.random.seed(np_seed)
+            ls = LayerSparsity(model, batches, log, num_samples, 0.5, 0.6, method, num_noise,
+                               1e-3, mapping)
+            sp = ls.return_sparsity()
+            key = f"{tag}_{method}_n{num_noise}_s{num_samples}"
+            out[key + "_losses"] = np.array(log.values, dtype=np.float64)
+            out[key + "_layer_sums"] = np.array(
+                [float(ls.importance_measure[k].sum()) for k in names], dtype=np.float64)
+            out[key + "_sparsity"] = np.array([sp[k] for k in names], dtype=np.float64)
+            if method.startswith("MEZO"):
+                # weights carry the reference's +eps/-2eps/+eps rounding drift
+                for k, v in model.state_dict().items():
+                    if k in mapping:
+                        out[key + f"_final::{k}"] = bits(v)
+            out[key + "_cfg"] = np.array([np_seed, num_noise, num_samples])
+    save("g2_scoring.npz", **out)
+
+
+# --------------------------------------------------------------------------- G6/G7: end to end
+def golden_end_to_end(registry):
+    out = {}
+
+    def run(tag, name, model, batches, cfg, quantise=None):
+        if quantise:
+            with torch.no_grad():
+                for k, p in model.named_parameters():
+                    if p.dim() == 2 and ".block" in k:
+                        p.copy_(torch.round(p * quantise) / quantise)  # massive metric ties
+        for k, v in model.state_dict().items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        pruner = registry.get_pruner_class(name)(model=model, data_loader=batches, **cfg)
+        model2, sp = pruner.prune()
+        names = sorted(sp.keys()) if isinstance(sp, dict) else []
+        out[f"{tag}_sparsity_names"] = np.array(names)
+        out[f"{tag}_sparsity"] = np.array([sp[k] for k in names], dtype=np.float64)
+        for k, v in model2.state_dict().items():
+            out[f"{tag}_final::{k}"] = bits(v)
+
+    base = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1,
+                num_noise=1, noise_eps=1e-3)
+    torch.manual_seed(21)
+    run("vit_block", "vit_wanda_pruner", vit_toy().eval(),
+        S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5),
+        dict(base, prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+             max_sparsity_per_layer=0.6, score_method="MEZO-GradOnly_sum", num_data_first_stage=8))
+    torch.manual_seed(22)
+    run("vit_ties_uniform", "vit_wanda_pruner", vit_toy().eval(),
+        S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5),
+        dict(base, prune_spec="3-0.6-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+             max_sparsity_per_layer=0.6, score_method="MEZO-GradOnly_sum", num_data_first_stage=8),
+        quantise=4.0)
+    t5cfg = t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, vocab_size=96)
+    t5_batches = S.image_text_batches(8, 2, img_size=4, vocab=96, in_len=6, out_len=4, seed=8)
+    torch.manual_seed(23)
+    run("t5_layer", "t5_wanda_pruner", T5(t5cfg, dtype=None, init_std=0.2).eval(), t5_batches,
+        dict(base, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="layer",
+             max_sparsity_per_layer=0.7, score_method="MEZO-GradOnly_avg", num_data_first_stage=4))
+    torch.manual_seed(24)
+    run("t5_ties_first", "t5_wanda_pruner", T5(t5cfg, dtype=None, init_std=0.2).eval(), t5_batches,
+        dict(base, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+             max_sparsity_per_layer=0.6, score_method="GradMagAbs_sum", num_data_first_stage=8),
+        quantise=4.0)
+    blip_batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    bl = dict(base, t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+              t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+              max_sparsity_per_layer=0.6, num_data_first_stage=8)
+    torch.manual_seed(25)
+    run("blip2_block", "blipt5_wanda_pruner", blip2_toy().eval(), blip_batches,
+        dict(bl, sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum"))
+    torch.manual_seed(26)
+    run("blip2_permodel", "blipt5_wanda_pruner", blip2_toy().eval(), blip_batches,
+        dict(bl, sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum",
+             prune_per_model=True))
+    save("g7_end_to_end.npz", **out)
+
+
+def golden_names():
+    d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
+                   map_location="cpu", weights_only=False)
+    with open(os.path.join(HERE, "g8_blip2_prunable_names.txt"), "w") as f:
+        f.write("\n".join(d.keys()) + "\n")
+    print("wrote g8_blip2_prunable_names.txt", len(d))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)  # fixed reduction order for the committed vectors
+    LayerSparsity, WrappedGPT = import_upop_pruners()
+    registry, lavis = import_lavis_pruners()
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names"]
+    if "k1" in only:
+        golden_k1(LayerSparsity)
+    if "alloc" in only:
+        golden_allocator(LayerSparsity)
+    if "wrapped" in only:
+        golden_wrapped(WrappedGPT)
+    if "scoring" in only:
+        golden_scoring(lavis["layer_single_base_pruner"].LayerSparsity, lavis)
+    if "e2e" in only:
+        golden_end_to_end(registry)
+    if "names" in only:
+        golden_names()
