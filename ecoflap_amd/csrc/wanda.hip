@@ -1,0 +1,420 @@
+// wanda.hip — K6 / K7 / K8: Wanda calibration statistic, metric + selection +
+// zeroing, and mask apply, for gfx950.
+//
+// Replaces
+//   K6  WrappedGPT.add_batch           LAVIS/lavis/compression/pruners/wanda_pruner.py:71-84
+//   K7  |W| * sqrt(scaler_row), sort, select, zero
+//         rows mode   (T5/BERT)         wanda_pruner.py:260, :272-279
+//         matrix mode (ViT)             wanda_pruner.py:541, :555-558
+//   K8  grad *= mask                    UPop/ecoflap_compression_vqa.py:124-129
+//
+// All HBM-bound byte/element work: 16-byte coalesced loads, selection by radix
+// select on the fp32 metric's bit pattern (metrics are >= +0 so the unsigned
+// order of the bits IS the float order; NaN sorts last like torch.sort), LDS
+// histograms, no GEMM reshaping.
+// Algorithmic bytes: K6 tokens*cols*s_x; K7 2*s per element + 4*cols.
+#include "common.h"
+
+// =====================================================================================
+// K6  column sum of squares -> running mean
+// =====================================================================================
+// stage 1: partial[chunk][col] = sum over the chunk's rows of x^2 (fp32)
+template <int DT, bool VECTOR>
+__global__ __launch_bounds__(256) void colsq_partial_kernel(const void* __restrict__ x,
+                                                            int64_t tokens, int64_t cols,
+                                                            int rows_per_chunk,
+                                                            float* __restrict__ partial) {
+    constexpr int N = VECTOR ? Vec<DT>::N : 1;
+    __shared__ float lds[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t cvec = (int64_t)blockIdx.x * 64 + lane;  // column vector handled by this lane
+    const int64_t ncvec = cols / N;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk;
+    if (r1 > tokens) r1 = tokens;
+    float acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    if (cvec < ncvec) {
+        for (int64_t r = r0 + wave; r < r1; r += 4) {
+            float f[N];
+            if (VECTOR) {
+                Vec<DT>::unpack(ld16(x, r * ncvec + cvec), f);
+            } else {
+                f[0] = Vec<DT>::load1(x, r * cols + cvec);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] += f[i] * f[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) lds[wave][lane * N + i] = acc[i];
+    __syncthreads();
+    if (wave == 0 && cvec < ncvec) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float s = (lds[0][lane * N + i] + lds[1][lane * N + i]) +
+                            (lds[2][lane * N + i] + lds[3][lane * N + i]);
+            partial[(int64_t)blockIdx.y * cols + cvec * N + i] = s;
+        }
+    }
+}
+
+// stage 2: fixed-order sum over chunks, then the reference's update (W:80-84)
+__global__ __launch_bounds__(256) void colsq_final_kernel(float* __restrict__ scaler_row,
+                                                          const float* __restrict__ partial,
+                                                          int64_t cols, int nchunks, float decay,
+                                                          float n_new) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
+    const float nrm = __builtin_sqrtf(s);  // torch.norm(...): sqrt of the sum of squares
+    const float sq = nrm * nrm;            // ... ** 2
+    const float r = scaler_row[c] * decay;  // scaler_row *= n / (n + b)
+    scaler_row[c] = r + sq / n_new;         // += ... / nsamples
+}
+
+static inline int colsq_rows_per_chunk(int64_t tokens, int64_t cols) {
+    // aim for >= ~1024 workgroups over the 256 CUs, at least 8 rows per workgroup
+    const int64_t colblocks = (cols / 4 + 63) / 64 + 1;
+    int64_t want_chunks = 1024 / colblocks;
+    if (want_chunks < 1) want_chunks = 1;
+    int64_t rpc = (tokens + want_chunks - 1) / want_chunks;
+    if (rpc < 8) rpc = 8;
+    return (int)rpc;
+}
+static inline int colsq_nchunks(int64_t tokens, int64_t cols) {
+    const int rpc = colsq_rows_per_chunk(tokens, cols);
+    return (int)((tokens + rpc - 1) / rpc);
+}
+
+extern "C" size_t ecoflap_colsqnorm_workspace_bytes(int64_t tokens, int64_t cols) {
+    if (tokens <= 0 || cols <= 0) return 0;
+    return (size_t)colsq_nchunks(tokens, cols) * (size_t)cols * sizeof(float);
+}
+
+extern "C" int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens,
+                                       int64_t cols, int dtype, int64_t nsamples_before,
+                                       int64_t batch, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (tokens <= 0 || cols <= 0 || nsamples_before < 0 || batch <= 0) return ECOFLAP_ESIZE;
+    if (!scaler_row || !x || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_colsqnorm_workspace_bytes(tokens, cols)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int rpc = colsq_rows_per_chunk(tokens, cols);
+    const int nchunks = colsq_nchunks(tokens, cols);
+    const int nvec = dtype == ECOFLAP_F32 ? 4 : 8;
+    const bool vector = (cols % nvec == 0) && aligned16(x);
+    const int64_t ncv = vector ? cols / nvec : cols;
+    const dim3 grid((unsigned)((ncv + 63) / 64), (unsigned)nchunks);
+    float* partial = (float*)workspace;
+#define COLSQ(DT_)                                                                              \
+    if (vector)                                                                                 \
+        hipLaunchKernelGGL((colsq_partial_kernel<DT_, true>), grid, dim3(256), 0, s, x, tokens, \
+                           cols, rpc, partial);                                                 \
+    else                                                                                        \
+        hipLaunchKernelGGL((colsq_partial_kernel<DT_, false>), grid, dim3(256), 0, s, x, tokens, \
+                           cols, rpc, partial);
+    if (dtype == ECOFLAP_F32) { COLSQ(ECOFLAP_F32) }
+    else if (dtype == ECOFLAP_F16) { COLSQ(ECOFLAP_F16) }
+    else { COLSQ(ECOFLAP_BF16) }
+#undef COLSQ
+    ECO_CHECK_LAUNCH();
+    const float decay = (float)((double)nsamples_before / (double)(nsamples_before + batch));
+    const float n_new = (float)(nsamples_before + batch);
+    hipLaunchKernelGGL(colsq_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
+                       scaler_row, partial, cols, nchunks, decay, n_new);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// =====================================================================================
+// K7 common: sqrt(scaler_row) once per matrix (correctly rounded, = torch.sqrt)
+// =====================================================================================
+__global__ __launch_bounds__(256) void sqrt_cols_kernel(const float* __restrict__ scaler_row,
+                                                        float* __restrict__ sq, int64_t cols) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) sq[c] = __builtin_sqrtf(scaler_row[c]);
+}
+
+template <int DT>
+static __device__ __forceinline__ uint32_t metric_bits(const void* w, int64_t i, float sq) {
+    return __float_as_uint(__builtin_fabsf(Vec<DT>::load1(w, i)) * sq);
+}
+
+// inclusive scan of one value per thread over a 256-thread block; returns (inclusive, total)
+static __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* lds_wave4,
+                                                          uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();  // protect lds_wave4 reuse
+    if (lane == 63) lds_wave4[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < wave) base += lds_wave4[k];
+    }
+    total = lds_wave4[0] + lds_wave4[1] + lds_wave4[2] + lds_wave4[3];
+    return x + base;
+}
+
+// =====================================================================================
+// K7 rows mode: one 256-thread workgroup per row; the row's metric bits live in LDS.
+// =====================================================================================
+#define WANDA_ROWS_MAX_COLS 15360  // metric bits + histogram stay under 64 KiB of LDS
+
+template <int DT>
+__global__ __launch_bounds__(256) void wanda_rows_kernel(void* w, const float* __restrict__ sq,
+                                                         int64_t cols, int64_t k,
+                                                         uint8_t* mask_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* m = smem;                 // [cols] metric bits
+    uint32_t* hist = smem + cols;       // [256]
+    uint32_t* wave4 = hist + 256;       // [4]
+    uint32_t* sel = wave4 + 4;          // [2] selected digit / remaining rank
+    const int64_t row = blockIdx.x;
+    void* wrow = (char*)w + row * cols * Vec<DT>::BYTES;
+    const int tid = threadIdx.x;
+
+    for (int64_t c = tid; c < cols; c += 256) m[c] = metric_bits<DT>(wrow, c, sq[c]);
+    __syncthreads();
+
+    // (k)-th smallest, 1-indexed, by 4 passes of 8-bit MSB-first radix select
+    uint32_t prefix = 0, prefix_mask = 0;
+    uint32_t remaining = (uint32_t)k;
+    if (k > 0 && k < cols) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int64_t c = tid; c < cols; c += 256) {
+                const uint32_t b = m[c];
+                if ((b & prefix_mask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            uint32_t total;
+            const uint32_t cnt = hist[tid];
+            const uint32_t incl = block_scan_256(cnt, wave4, total);
+            const uint32_t excl = incl - cnt;
+            if (excl < remaining && remaining <= incl) {  // exactly one thread
+                sel[0] = (uint32_t)tid;
+                sel[1] = remaining - excl;
+            }
+            __syncthreads();
+            prefix |= sel[0] << shift;
+            prefix_mask |= 255u << shift;
+            remaining = sel[1];
+            __syncthreads();
+        }
+    }
+    // prefix = bits of the k-th smallest metric T; `remaining` of the elements equal to T are
+    // pruned, lowest column first (stable sort order, W:272-277).
+    if (k <= 0) return;
+    const bool all = (k >= cols);
+    // count of elements equal to T decides whether column order matters
+    uint32_t running = 0;  // equal-to-T elements in columns before this 256-column tile
+    for (int64_t c0 = 0; c0 < cols; c0 += 256) {
+        const int64_t c = c0 + tid;
+        const uint32_t b = (c < cols) ? m[c] : 0xffffffffu;
+        const bool eq = !all && (c < cols) && (b == prefix);
+        uint32_t total;
+        const uint32_t incl = block_scan_256(eq ? 1u : 0u, wave4, total);
+        const bool prune = (c < cols) && (all || b < prefix || (eq && (running + incl) <= remaining));
+        if (prune) Vec<DT>::store1(wrow, c, 0.0f);
+        if (mask_out && c < cols) mask_out[row * cols + c] = prune ? 1 : 0;
+        running += total;
+    }
+}
+
+// =====================================================================================
+// K7 matrix mode: global (k+1)-th smallest over rows*cols by 3 histogram passes
+// (11 + 11 + 10 bits), then zero metric <= threshold.
+// =====================================================================================
+struct MatrixSelState {
+    uint32_t prefix;       // selected high bits so far
+    uint32_t remaining;    // 1-indexed rank still to resolve inside the selected bin
+    uint32_t hist[3][2048];
+};
+
+template <int DT, int PASS>
+__global__ __launch_bounds__(256) void wanda_matrix_hist_kernel(const void* __restrict__ w,
+                                                                const float* __restrict__ sq,
+                                                                int64_t n, int64_t cols,
+                                                                MatrixSelState* st) {
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr int BITS = PASS == 2 ? 10 : 11;
+    constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    __shared__ uint32_t h[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = (PASS == 0) ? 0u : st->prefix;
+    const int64_t rows = n / cols;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        for (int64_t c = threadIdx.x; c < cols; c += 256) {
+            const uint32_t b = metric_bits<DT>(w, r * cols + c, sq[c]);
+            if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << BITS); i += 256)
+        if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void wanda_matrix_pick_kernel(MatrixSelState* st, uint32_t rank0) {
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr int BINS = PASS == 2 ? 1024 : 2048;
+    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t carry;
+    const uint32_t remaining = (PASS == 0) ? rank0 : st->remaining;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < BINS; base += 256) {
+        const uint32_t cnt = st->hist[PASS][base + threadIdx.x];
+        uint32_t total;
+        const uint32_t incl = block_scan_256(cnt, wave4, total) + carry;
+        const uint32_t excl = incl - cnt;
+        if (excl < remaining && remaining <= incl) {
+            st->prefix = ((PASS == 0) ? 0u : st->prefix) | ((uint32_t)(base + threadIdx.x) << SHIFT);
+            st->remaining = remaining - excl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void wanda_matrix_apply_kernel(void* w,
+                                                                 const float* __restrict__ sq,
+                                                                 int64_t n, int64_t cols,
+                                                                 const MatrixSelState* st,
+                                                                 uint8_t* mask_out) {
+    const uint32_t thres = st->prefix;
+    const int64_t rows = n / cols;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        for (int64_t c = threadIdx.x; c < cols; c += 256) {
+            const int64_t i = r * cols + c;
+            // W_metric <= thres (W:556): false for NaN metrics, as in torch
+            const float mval = __uint_as_float(metric_bits<DT>(w, i, sq[c]));
+            const bool prune = mval <= __uint_as_float(thres);
+            if (prune) Vec<DT>::store1(w, i, 0.0f);
+            if (mask_out) mask_out[i] = prune ? 1 : 0;
+        }
+    }
+}
+
+extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
+    (void)rows;
+    if (cols <= 0) return 0;
+    // sqrt table (padded to 256 B) + matrix-mode selection state
+    return (((size_t)cols * sizeof(float) + 255) / 256) * 256 + sizeof(MatrixSelState);
+}
+
+static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
+
+extern "C" int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
+                                        int64_t cols, int dtype, int64_t k, uint8_t* mask_out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (rows <= 0 || cols <= 0 || k < 0 || cols > WANDA_ROWS_MAX_COLS) return ECOFLAP_ESIZE;
+    if (!w || !scaler_row || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_wanda_workspace_bytes(rows, cols)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* sq = (float*)workspace;
+    hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
+                       scaler_row, sq, cols);
+    ECO_CHECK_LAUNCH();
+    const size_t lds = ((size_t)cols + 256 + 4 + 4) * sizeof(uint32_t);
+    if (dtype == ECOFLAP_F32)
+        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_F32>), dim3((unsigned)rows), dim3(256), lds, s,
+                           w, sq, cols, k, mask_out);
+    else if (dtype == ECOFLAP_F16)
+        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_F16>), dim3((unsigned)rows), dim3(256), lds, s,
+                           w, sq, cols, k, mask_out);
+    else
+        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_BF16>), dim3((unsigned)rows), dim3(256), lds,
+                           s, w, sq, cols, k, mask_out);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int DT>
+static int wanda_matrix_launch(void* w, const float* sq, int64_t n, int64_t cols, int64_t k,
+                               MatrixSelState* st, uint8_t* mask_out, hipStream_t s) {
+    int64_t b = n / cols;  // one row per workgroup per sweep
+    if (b > 2048) b = 2048;
+    const dim3 grid((unsigned)b), blk(256);
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 0>), grid, blk, 0, s, w, sq, n, cols, st);
+    hipLaunchKernelGGL((wanda_matrix_pick_kernel<0>), dim3(1), blk, 0, s, st, (uint32_t)(k + 1));
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 1>), grid, blk, 0, s, w, sq, n, cols, st);
+    hipLaunchKernelGGL((wanda_matrix_pick_kernel<1>), dim3(1), blk, 0, s, st, 0u);
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 2>), grid, blk, 0, s, w, sq, n, cols, st);
+    hipLaunchKernelGGL((wanda_matrix_pick_kernel<2>), dim3(1), blk, 0, s, st, 0u);
+    hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT>), grid, blk, 0, s, w, sq, n, cols, st,
+                       mask_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
+                                          int64_t cols, int dtype, int64_t k, uint8_t* mask_out,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    const int64_t n = rows * cols;
+    // the reference indexes sorted[k]: k == numel raises IndexError there (W:555)
+    if (rows <= 0 || cols <= 0 || k < 0 || k >= n || n >= (int64_t)0xffffffffLL) return ECOFLAP_ESIZE;
+    if (!w || !scaler_row || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_wanda_workspace_bytes(rows, cols)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* sq = (float*)workspace;
+    MatrixSelState* st = (MatrixSelState*)((char*)workspace + sq_bytes(cols));
+    hipError_t e = hipMemsetAsync(st, 0, sizeof(MatrixSelState), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
+                       scaler_row, sq, cols);
+    ECO_CHECK_LAUNCH();
+    if (dtype == ECOFLAP_F32) return wanda_matrix_launch<ECOFLAP_F32>(w, sq, n, cols, k, st, mask_out, s);
+    if (dtype == ECOFLAP_F16) return wanda_matrix_launch<ECOFLAP_F16>(w, sq, n, cols, k, st, mask_out, s);
+    return wanda_matrix_launch<ECOFLAP_BF16>(w, sq, n, cols, k, st, mask_out, s);
+}
+
+// =====================================================================================
+// K8  grad *= mask
+// =====================================================================================
+template <int DT>
+__global__ __launch_bounds__(256) void mask_mul_kernel(void* g, const uint8_t* __restrict__ keep,
+                                                       int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float m = keep[i] ? 1.0f : 0.0f;
+        Vec<DT>::store1(g, i, Vec<DT>::load1(g, i) * m);
+    }
+}
+
+extern "C" int ecoflap_mask_mul(void* g, const uint8_t* keep_mask, int64_t n, int dtype,
+                                void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (n < 0) return ECOFLAP_ESIZE;
+    if (n == 0) return 0;
+    if (!g || !keep_mask) return ECOFLAP_ENULL;
+    int64_t b = (n + 256 * 4 - 1) / (256 * 4);
+    if (b > 2048) b = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ECOFLAP_F32)
+        hipLaunchKernelGGL((mask_mul_kernel<ECOFLAP_F32>), dim3((unsigned)b), dim3(256), 0, s, g, keep_mask, n);
+    else if (dtype == ECOFLAP_F16)
+        hipLaunchKernelGGL((mask_mul_kernel<ECOFLAP_F16>), dim3((unsigned)b), dim3(256), 0, s, g, keep_mask, n);
+    else
+        hipLaunchKernelGGL((mask_mul_kernel<ECOFLAP_BF16>), dim3((unsigned)b), dim3(256), 0, s, g, keep_mask, n);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,246 @@
+"""ctypes binding of libecoflap_hip.so (include/ecoflap_hip.h) over PyTorch-ROCm tensors.
+
+This is the ONLY compute backend of the product.  There is no CPU fallback: if
+the shared library is missing, or a tensor handed to a kernel is not on the GPU,
+the call raises.  PyTorch is plumbing here — it owns device memory and the HIP
+stream; the kernels receive raw pointers (`tensor.data_ptr()`) and
+`torch.cuda.current_stream().cuda_stream`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libecoflap_hip.so")
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
+    "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
+    "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
+    "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
+    "ecoflap_colsqnorm_accum", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
+    "ecoflap_wanda_prune_matrix", "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
+]
+
+
+class EcoflapHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises if it has not been built (`make -C ecoflap_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EcoflapHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C ecoflap_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, u64, f32, f64, ci, sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+                                      ctypes.c_float, ctypes.c_double, ctypes.c_int,
+                                      ctypes.c_size_t)
+    lib.ecoflap_version.restype = ctypes.c_char_p
+    lib.ecoflap_error_string.restype = ctypes.c_char_p
+    lib.ecoflap_error_string.argtypes = [ci]
+    lib.ecoflap_zo_perturb.argtypes = [vp, i64, ci, f32, f32, u64, vp, vp]
+    lib.ecoflap_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, u64, vp, vp]
+    lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
+    lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
+    lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
+    lib.ecoflap_absprod_reduce_workspace_bytes.argtypes = [i64]
+    lib.ecoflap_absprod_reduce.argtypes = [vp, vp, i64, ci, ci, ci, vp, vp, sz, vp]
+    lib.ecoflap_absprod_reduce_multi_workspace_bytes.restype = sz
+    lib.ecoflap_absprod_reduce_multi_workspace_bytes.argtypes = [ci]
+    lib.ecoflap_absprod_reduce_multi.argtypes = [vp, ci, i64, ci, ci, ci, vp, vp, sz, vp]
+    lib.ecoflap_colsqnorm_workspace_bytes.restype = sz
+    lib.ecoflap_colsqnorm_workspace_bytes.argtypes = [i64, i64]
+    lib.ecoflap_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
+    lib.ecoflap_wanda_workspace_bytes.restype = sz
+    lib.ecoflap_wanda_workspace_bytes.argtypes = [i64, i64]
+    lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
+    lib.ecoflap_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
+    lib.ecoflap_mask_mul.argtypes = [vp, vp, i64, ci, vp]
+    lib.ecoflap_allocate_sparsity.argtypes = [vp, vp, ci, i64, f64, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().ecoflap_error_string(rc).decode()
+        raise EcoflapHipError(f"{what} failed: {msg} (code {rc})")
+
+
+def _gpu(t, name):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise EcoflapHipError(
+            f"{name} must be a GPU tensor: the ECoFLaP kernels are HIP-only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise EcoflapHipError(f"{name} must be contiguous")
+    if t.dtype not in DTYPE_CODE and t.dtype not in (torch.uint8, torch.int32, torch.int64,
+                                                     torch.float64):
+        raise EcoflapHipError(f"{name}: unsupported dtype {t.dtype}")
+    return t
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Workspace:
+    """Caller-owned scratch, grown on demand and reused (no allocation inside launches)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class HipKernels:
+    """The HIP backend behind LayerSparsity / the Wanda pruners."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load_library()
+        self.ws = Workspace()
+
+    # ---- K1 ---------------------------------------------------------------------------
+    def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
+        _gpu(w, "w")
+        if z is not None:
+            _gpu(z, "z")
+            if z.dtype != w.dtype or z.numel() != w.numel():
+                raise EcoflapHipError("z must match w in dtype and numel")
+        _check(self.lib.ecoflap_zo_perturb(_ptr(w), w.numel(), DTYPE_CODE[w.dtype],
+                                           float(scaling_factor), float(zo_eps), int(seed),
+                                           _ptr(z), _stream()), "ecoflap_zo_perturb")
+
+    def zo_perturb_triple(self, w_in, w_plus, w_minus, w_restored, zo_eps, seed, z=None):
+        for t, n in ((w_in, "w_in"), (w_plus, "w_plus"), (w_minus, "w_minus"),
+                     (w_restored, "w_restored")):
+            if t is None and n in ("w_plus", "w_minus"):
+                continue                      # drift-only form
+            _gpu(t, n)
+            if t.dtype != w_in.dtype or t.numel() != w_in.numel():
+                raise EcoflapHipError("triple buffers must match w_in in dtype and numel")
+        if z is not None:
+            _gpu(z, "z")
+        _check(self.lib.ecoflap_zo_perturb_triple(
+            _ptr(w_in), _ptr(w_plus), _ptr(w_minus), _ptr(w_restored), w_in.numel(),
+            DTYPE_CODE[w_in.dtype], float(zo_eps), int(seed), _ptr(z), _stream()),
+            "ecoflap_zo_perturb_triple")
+
+    def zo_fill_normal(self, z_out, seed):
+        _gpu(z_out, "z_out")
+        _check(self.lib.ecoflap_zo_fill_normal(_ptr(z_out), z_out.numel(),
+                                               DTYPE_CODE[z_out.dtype], int(seed), _stream()),
+               "ecoflap_zo_fill_normal")
+
+    def philox_u32(self, n, seed, device="cuda"):
+        out = torch.empty(n, dtype=torch.int32, device=device)
+        _check(self.lib.ecoflap_philox_u32(_ptr(out), n, int(seed), _stream()),
+               "ecoflap_philox_u32")
+        return out
+
+    # ---- K3+K4 ------------------------------------------------------------------------
+    def absprod_reduce(self, w, g, mode, out_accum):
+        """out_accum (float64[1], GPU) += sum_e f(w_e, g_e)."""
+        ref = w if w is not None else g
+        _gpu(ref, "w/g")
+        _gpu(out_accum, "out_accum")
+        if out_accum.dtype != torch.float64:
+            raise EcoflapHipError("out_accum must be float64")
+        n = ref.numel()
+        nb = self.lib.ecoflap_absprod_reduce_workspace_bytes(n)
+        ws = self.ws.get(nb, ref.device)
+        _check(self.lib.ecoflap_absprod_reduce(
+            _ptr(_gpu(w, "w")) if w is not None else None,
+            _ptr(_gpu(g, "g")) if g is not None else None, n,
+            DTYPE_CODE[w.dtype] if w is not None else 0,
+            DTYPE_CODE[g.dtype] if g is not None else 0, int(mode), _ptr(out_accum), _ptr(ws),
+            ws.numel(), _stream()), "ecoflap_absprod_reduce")
+
+    def absprod_reduce_multi(self, table, max_numel, dtype_w, dtype_g, mode, out_accum):
+        """table: int64[n_layers, 3] GPU rows {w_ptr, g_ptr, numel}; out_accum float64[n_layers]."""
+        _gpu(table, "table")
+        _gpu(out_accum, "out_accum")
+        n_layers = table.shape[0]
+        nb = self.lib.ecoflap_absprod_reduce_multi_workspace_bytes(n_layers)
+        ws = self.ws.get(nb, table.device)
+        _check(self.lib.ecoflap_absprod_reduce_multi(
+            _ptr(table), n_layers, int(max_numel), DTYPE_CODE[dtype_w], DTYPE_CODE[dtype_g],
+            int(mode), _ptr(out_accum), _ptr(ws), ws.numel(), _stream()),
+            "ecoflap_absprod_reduce_multi")
+
+    # ---- K6 ---------------------------------------------------------------------------
+    def colsqnorm_accum(self, scaler_row, x2d, nsamples_before, batch):
+        _gpu(scaler_row, "scaler_row")
+        _gpu(x2d, "x")
+        tokens, cols = x2d.shape
+        nb = self.lib.ecoflap_colsqnorm_workspace_bytes(tokens, cols)
+        ws = self.ws.get(nb, x2d.device)
+        _check(self.lib.ecoflap_colsqnorm_accum(
+            _ptr(scaler_row), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype],
+            int(nsamples_before), int(batch), _ptr(ws), ws.numel(), _stream()),
+            "ecoflap_colsqnorm_accum")
+
+    # ---- K7 ---------------------------------------------------------------------------
+    def _wanda(self, fn, name, w, scaler_row, k, mask_out):
+        _gpu(w, "w")
+        _gpu(scaler_row, "scaler_row")
+        if mask_out is not None:
+            _gpu(mask_out, "mask_out")
+        rows, cols = w.shape
+        nb = self.lib.ecoflap_wanda_workspace_bytes(rows, cols)
+        ws = self.ws.get(nb, w.device)
+        _check(fn(_ptr(w), _ptr(scaler_row), rows, cols, DTYPE_CODE[w.dtype], int(k),
+                  _ptr(mask_out), _ptr(ws), ws.numel(), _stream()), name)
+
+    def wanda_prune_rows(self, w, scaler_row, k, mask_out=None):
+        self._wanda(self.lib.ecoflap_wanda_prune_rows, "ecoflap_wanda_prune_rows", w, scaler_row,
+                    k, mask_out)
+
+    def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
+        self._wanda(self.lib.ecoflap_wanda_prune_matrix, "ecoflap_wanda_prune_matrix", w,
+                    scaler_row, k, mask_out)
+
+    # ---- K8 ---------------------------------------------------------------------------
+    def mask_mul(self, g, keep_mask):
+        _gpu(g, "g")
+        _gpu(keep_mask, "keep_mask")
+        _check(self.lib.ecoflap_mask_mul(_ptr(g), _ptr(keep_mask), g.numel(),
+                                         DTYPE_CODE[g.dtype], _stream()), "ecoflap_mask_mul")
+
+
+def allocate_sparsity(group_scores, group_num_params, total_parameters_to_keep,
+                      max_sparsity_per_layer):
+    """K5 on the host through the C ABI -> (list of python floats, list of keep counts)."""
+    import numpy as np
+    lib = load_library()
+    sc = np.ascontiguousarray(group_scores, dtype=np.float32)
+    nums = np.ascontiguousarray(group_num_params, dtype=np.int64)
+    out = np.zeros(len(sc), dtype=np.float32)
+    keep = np.zeros(len(sc), dtype=np.float64)
+    _check(lib.ecoflap_allocate_sparsity(sc.ctypes.data, nums.ctypes.data, len(sc),
+                                         int(total_parameters_to_keep),
+                                         float(max_sparsity_per_layer), out.ctypes.data,
+                                         keep.ctypes.data), "ecoflap_allocate_sparsity")
+    return [float(v) for v in out], [float(v) for v in keep]

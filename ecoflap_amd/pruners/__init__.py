@@ -1,0 +1,7 @@
+from .base_pruner import BasePruner, LayerWiseBasePruner  # noqa: F401
+from .layer_sparsity import LayerSparsity  # noqa: F401
+from .wanda import (  # noqa: F401
+    BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPruner, WrappedGPT, find_layers,
+    get_module_recursive,
+)
+from .losses import loss_language, loss_vision, loss_vision_language  # noqa: F401

@@ -1,0 +1,85 @@
+"""`BasePruner` / `LayerWiseBasePruner`: configuration holders of the pruner API
+(LAVIS/lavis/compression/pruners/base_pruner.py:18-92 and
+layer_single_base_pruner.py:19-117)."""
+import time
+
+
+def print_time(func):
+    """Wall-clock print around a stage, as the reference's decorator (pruners/utils.py:6-18)."""
+    def wrapper(*args, **kwargs):
+        start = time.time()
+        ret = func(*args, **kwargs)
+        print(f"{func.__name__} spent {time.time() - start:.3f} s")
+        return ret
+    wrapper.__name__ = func.__name__
+    return wrapper
+
+
+class BasePruner:
+    def __init__(self, model, data_loader, is_strct_pruning, keep_indices_or_masks_cache,
+                 importance_scores_cache, is_global, num_samples):
+        self.model = model
+        self.data_loader = data_loader
+        self.is_strct_pruning = is_strct_pruning
+        self.is_global = is_global
+        self.num_samples = num_samples
+        self.keep_indices_or_masks_cache = keep_indices_or_masks_cache
+        self.importance_scores_cache = importance_scores_cache
+
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        raise NotImplementedError
+
+
+class LayerWiseBasePruner(BasePruner):
+    def __init__(self, model, data_loader, prune_spec=None, importance_scores_cache=None,
+                 keep_indices_or_masks_cache=None, is_strct_pruning=False, num_samples=64,
+                 is_global=False, model_prefix="t5_model", sparsity_ratio_granularity=None,
+                 max_sparsity_per_layer=0.8, score_method="GradMagSquare_avg",
+                 num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
+                 prune_per_model=False, kernels=None, z_source="philox", process_group=None,
+                 **kwargs):
+        super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
+                         importance_scores_cache=importance_scores_cache,
+                         keep_indices_or_masks_cache=keep_indices_or_masks_cache,
+                         is_global=is_global, num_samples=num_samples)
+        self.sparsity_ratio_granularity = sparsity_ratio_granularity
+        self.max_sparsity_per_layer = max_sparsity_per_layer
+        self.score_method = score_method
+        self.num_data_first_stage = num_data_first_stage
+        self.num_noise = num_noise
+        self.sparsity_dict = sparsity_dict
+        self.noise_eps = noise_eps
+        self.prune_per_model = prune_per_model
+        self.prune_spec = prune_spec
+        self.model_prefix = model_prefix
+        self.prune_n = 0
+        self.prune_m = 0
+        self.model_stem = getattr(self.model, model_prefix, None)
+        # build-side extras (keyword only in the reference's **kwargs slot)
+        self.kernels = kernels
+        self.z_source = z_source
+        self.process_group = process_group
+        self.stage_stats = {}
+
+    def model_setup_and_record_attributes(self, model):
+        """Record dtypes / requires_grad and enable grads on everything (:79-95)."""
+        dtype_record = {n: p.data.dtype for n, p in model.named_parameters()}
+        requires_grad_record = {}
+        for n, p in model.named_parameters():
+            requires_grad_record[n] = p.requires_grad
+            p.requires_grad = True
+        device = next(iter(model.parameters())).device
+        return dtype_record, requires_grad_record, device
+
+    def model_reset(self, model, dtype_record, requires_grad_record, device):
+        for n, p in model.named_parameters():
+            p.requires_grad = requires_grad_record[n]
+        for n, p in model.named_parameters():
+            if p.data.dtype != dtype_record[n]:
+                p.data = p.data.type(dtype_record[n])
+        model.to(device)
+
+    def convert_spec_to_list(self, spec):
+        """"<n_layers>-<keep>-<attn>-<ffn>" (:108-114)."""
+        num_layers, res_keep, attn_keep, ffn_keep = spec.split("-")
+        return int(num_layers), float(res_keep), float(attn_keep), float(ffn_keep)

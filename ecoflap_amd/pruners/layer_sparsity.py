@@ -1,0 +1,436 @@
+"""Stage 1 of ECoFLaP: global importance scores -> per-layer sparsity table.
+
+Host-side mirror of the reference's `LayerSparsity`
+(LAVIS/lavis/compression/pruners/layer_single_base_pruner.py:120-561): same
+constructor arguments, method names and return values, so the reference's pruners
+(and its tests-as-scripts) can drive it unchanged.  What differs is HOW it runs:
+
+  * every tensor op of the hot loops is one of the HIP kernels behind the C ABI
+    (include/ecoflap_hip.h); there is no torch arithmetic on weights or gradients
+    and no CPU fallback;
+  * the +eps / -2eps / +eps perturbation triple (:530-539) is ONE kernel pass that
+    emits theta+, theta- and the reference's drifted "restored" theta into three
+    buffers the parameter pointer rotates through (bit-identical to three passes);
+  * losses stay on the device in a [units, 2] table — one host sync per run
+    instead of one `.item()` per loss pair (:544);
+  * first-order gradients are never copied to the host nor accumulated per element
+    (:453-461): each batch's (W, g) pairs are reduced to one double per layer by a
+    single multi-tensor launch;
+  * calibration batches may be sharded over ranks (one process per GPU); the
+    exchange is ONE all-reduce of the loss table / the per-layer sums over RCCL.
+
+The order in which the global NumPy RNG is consumed, the fp32/python-float
+arithmetic of the score reduction (:544-549, :362-377) and the allocator (:247-314,
+through `ecoflap_allocate_sparsity`) replay the reference exactly.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import hip as _hip
+
+_f32 = np.float32
+
+
+def _default_batch_len(batch):
+    """Sample count of a calibration batch, as the reference's loss closures report it
+    (pruners/utils.py:29,42: len(samples["text_input"]); :65: len(targets))."""
+    for key in ("text_input", "label", "image"):
+        if key in batch:
+            return len(batch[key])
+    raise ValueError("cannot infer the batch length; pass batch_len_fn")
+
+
+class _UniformSparsity:
+    """`return_sparsity()` result when no grouping is requested (:327-331)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __getitem__(self, key):
+        return self.value
+
+
+class LayerSparsity:
+    def __init__(
+        self,
+        model,
+        data_loader,
+        loss_func,
+        num_samples,
+        original_sparsity,
+        max_sparsity_per_layer=0.8,
+        score_method="GradMagSquare_avg",
+        num_noise=1,
+        noise_eps=1e-3,
+        layer_to_group_mapping={},
+        prune_per_model=False,
+        per_model_group=[],
+        *,
+        kernels=None,
+        z_source="philox",
+        batch_len_fn=None,
+        process_group=None,
+        fused_triple=True,
+    ):
+        """Positional arguments are the reference's (:120-135).  Keyword-only extras:
+
+        kernels       backend object; None = the HIP library (raises if it is not built).
+        z_source      "philox": z generated in registers by the kernel (production);
+                      "torch": z = torch.normal after torch.manual_seed(seed) on the
+                      parameter's device, exactly as the reference draws it (:482-485);
+                      or a callable (seed, param) -> z tensor (parity tests).
+        process_group torch.distributed group to shard calibration batches over
+                      (None = use the default group if initialised, else single process).
+        fused_triple  False: three single-pass launches, like the reference's call pattern.
+        """
+        self.importance_measure = {}
+        self.model = model
+        self.data_loader = data_loader
+        self.loss_func = loss_func
+        self.num_samples = num_samples
+        self.original_sparsity = original_sparsity
+        self.layer_to_group_mapping = layer_to_group_mapping
+        self.max_sparsity_per_layer = max_sparsity_per_layer
+        self.num_noise = num_noise
+        self.noise_eps = noise_eps
+        self.prune_per_model = prune_per_model
+        self.score_method = score_method
+        self.per_model_group = per_model_group
+        if score_method is not None:
+            self.score_compute, self.score_aggregate = score_method.split("_")
+        assert self.max_sparsity_per_layer >= self.original_sparsity
+
+        self.kernels = kernels if kernels is not None else _hip.HipKernels()
+        self.z_source = z_source
+        self.batch_len_fn = batch_len_fn or _default_batch_len
+        self.process_group = process_group
+        self.fused_triple = fused_triple
+        self.stats = {}          # wall-clock + unit counts of the last run (reference: @print_time)
+        self.loss_table = None   # [units, 2] fp32 (host copy) of the last zeroth-order run
+        self.seed_schedule = None
+
+    # ------------------------------------------------------------------ distributed helpers
+    def _dist(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            group = self.process_group
+            return dist, dist.get_rank(group), dist.get_world_size(group)
+        return None, 0, 1
+
+    def _all_reduce_sum(self, t):
+        dist, _, world = self._dist()
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        return t
+
+    # ------------------------------------------------------------------ K1
+    def _draw_z(self, seed, param):
+        if self.z_source == "philox":
+            return None
+        if self.z_source == "torch":
+            torch.manual_seed(seed)
+            return torch.normal(mean=0, std=1, size=param.data.size(), device=param.data.device,
+                                dtype=param.data.dtype)
+        z = self.z_source(seed, param)
+        return z.to(device=param.data.device, dtype=param.data.dtype).contiguous()
+
+    def zo_perturb_parameters(self, params, random_seed=1, scaling_factor=1, zo_eps=1e-3):
+        """theta <- theta + scaling_factor * z * zo_eps, in place, one HIP launch per
+        parameter (same name and arguments as the reference method, :473-486)."""
+        if self.z_source != "philox":
+            torch.manual_seed(random_seed)
+        for param in params:
+            z = None
+            if self.z_source == "torch":
+                z = torch.normal(mean=0, std=1, size=param.data.size(),
+                                 device=param.data.device, dtype=param.data.dtype)
+            elif self.z_source != "philox":
+                z = self._draw_z(random_seed, param)
+            self.kernels.zo_perturb(param.data, scaling_factor, zo_eps, random_seed, z)
+
+    # ------------------------------------------------------------------ schedule
+    def _select(self, layer_to_group_mapping):
+        names, params = [], []
+        for k, v in self.model.named_parameters():
+            if k in layer_to_group_mapping:
+                names.append(k)
+                params.append(v)
+        return names, params
+
+    def build_zeroth_order_schedule(self, names):
+        """Replay the reference's loop nest (:512-549) on the host only, consuming the
+        global NumPy RNG at exactly the points it does, and return the list of units
+        (layer index, batch index, noise index, seed, batch_len)."""
+        batches = list(self.data_loader)
+        lens = [self.batch_len_fn(b) for b in batches]
+        units = []
+        for li, _ in enumerate(names):
+            accum = 0
+            for bi in range(len(batches)):
+                if accum >= self.num_samples:
+                    break
+                for ni in range(self.num_noise):
+                    if accum >= self.num_samples:
+                        break
+                    seed = int(np.random.randint(1000000000))
+                    units.append((li, bi, ni, seed, lens[bi]))
+                    accum += lens[bi]
+        return batches, units
+
+    # ------------------------------------------------------------------ zeroth order
+    def compute_importance_scores_mezo(self, layer_to_group_mapping):
+        t0 = time.time()
+        model = self.model
+        model.eval()
+        names, params = self._select(layer_to_group_mapping)
+        device = next(iter(model.parameters())).device
+        cuda_enabled = device.type != "cpu"
+        zo_eps = self.noise_eps
+        _, rank, world = self._dist()
+
+        batches, units = self.build_zeroth_order_schedule(names)
+        self.seed_schedule = units
+        n_units = len(units)
+        table = torch.zeros((max(n_units, 1), 2), dtype=torch.float32, device=device)
+
+        by_layer = {}
+        for u, unit in enumerate(units):
+            by_layer.setdefault(unit[0], []).append(u)
+
+        n_forward = 0
+        for li, (name, param) in enumerate(zip(names, params)):
+            home = param.data
+            cur = home
+            spare = [torch.empty_like(home), torch.empty_like(home)]
+            for u in by_layer.get(li, []):
+                _, bi, _, seed, blen = units[u]
+                mine = (bi % world) == rank
+                z = self._draw_z(seed, param)
+                if not self.fused_triple:
+                    # reference call pattern: three in-place passes (:530-539)
+                    param.data = cur
+                    self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
+                    if mine:
+                        self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                    self.kernels.zo_perturb(cur, -2, zo_eps, seed, z)
+                    if mine:
+                        self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                    self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
+                    n_forward += 2 * int(mine)
+                    continue
+                if mine:
+                    minus, restored = spare
+                    self.kernels.zo_perturb_triple(cur, cur, minus, restored, zo_eps, seed, z)
+                    param.data = cur            # theta + eps z
+                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                    param.data = minus          # theta - eps z
+                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                    param.data = restored       # "recovered" weights, with the reference's drift
+                    cur, spare = restored, [minus, cur]
+                    n_forward += 2
+                else:
+                    # another rank evaluates this batch; only carry the rounding drift so
+                    # every replica ends with the weights the single-process run leaves
+                    self.kernels.zo_perturb_triple(cur, None, None, spare[1], zo_eps, seed, z)
+                    cur, spare = spare[1], [spare[0], cur]
+                    param.data = cur
+            if cur is not home:                  # keep the parameter's own storage
+                home.copy_(cur)
+            param.data = home
+            del spare
+
+        if world > 1:
+            self._all_reduce_sum(table)          # each entry is written by exactly one rank
+        # (loss1 - loss2) / (2 eps) with torch's own fp32 tensor ops on the loss tensors'
+        # device, as the reference evaluates it per pair (:544); ONE sync for the run.
+        projected = ((table[:, 0] - table[:, 1]) / (2 * zo_eps)).cpu().numpy()
+        self.loss_table = table.cpu().numpy()
+
+        grad_sum = {}
+        for li, name in enumerate(names):
+            acc = _f32(0)                        # gradients_dict[name], fp32 tensor (:549)
+            started = False
+            per_batch = {}
+            for u in by_layer.get(li, []):
+                per_batch.setdefault(units[u][1], []).append(u)
+            for bi in sorted(per_batch):
+                s = 0                            # python number accumulates |pg| over noise (:547)
+                for u in per_batch[bi]:
+                    s += abs(float(projected[u]))
+                v = abs(_f32(s))                 # torch.FloatTensor([s]).abs()
+                acc = v if not started else _f32(acc + v)
+                started = True
+            grad_sum[name] = acc if started else 0
+        # a loader with no batch leaves the int 0 of the reference's dict (:501)
+
+        importance = {}
+        if self.score_compute == "MEZO-GradOnly":
+            for name in names:
+                importance[name] = torch.tensor([abs(float(grad_sum[name]))], dtype=torch.float32)
+        elif self.score_compute in ("MEZO-GradMagAbs", "MEZO-GradMagSquare"):
+            mode = _hip.RED_ABSW if self.score_compute == "MEZO-GradMagAbs" else _hip.RED_SQW
+            sums = self._weight_sums(params, mode)
+            for name, wsum in zip(names, sums):
+                s = float(grad_sum[name])
+                factor = abs(s) if mode == _hip.RED_ABSW else s * s
+                # sum_e |W_e| * s  (:556)  /  sum_e W_e^2 * s^2  (:559), reduced on the device
+                importance[name] = torch.tensor([_f32(wsum * factor)], dtype=torch.float32)
+        else:
+            raise ValueError(f"unknown zeroth-order score_method {self.score_method!r}")
+        self.stats = {"seconds": time.time() - t0, "layers": len(names), "units": n_units,
+                      "forwards": n_forward, "world_size": world}
+        return importance
+
+    def _loss_into(self, table, unit, col, batch, cuda_enabled, expected_len):
+        with torch.no_grad():
+            loss, batch_len = self.loss_func(self.model, batch, cuda_enabled)
+        if batch_len != expected_len:
+            raise RuntimeError(
+                f"loss_func reported batch_len {batch_len}, schedule assumed {expected_len}; "
+                "pass batch_len_fn matching the loss closure")
+        table[unit, col].copy_(loss.detach().float(), non_blocking=True)
+
+    def _weight_sums(self, params, mode):
+        device = params[0].device
+        out = torch.zeros(len(params), dtype=torch.float64, device=device)
+        for i, p in enumerate(params):
+            self.kernels.absprod_reduce(p.data, None, mode, out[i:i + 1])
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------ first order
+    def compute_importance_scores(self, layer_to_group_mapping):
+        t0 = time.time()
+        model = self.model
+        names, params = self._select(layer_to_group_mapping)
+        device = next(iter(model.parameters())).device
+        cuda_enabled = device.type != "cpu"
+        _, rank, world = self._dist()
+        mode = {"GradMagSquare": _hip.RED_SQW_SQG, "GradMagAbs": _hip.RED_ABSW_ABSG,
+                "GradOnly": _hip.RED_ABSG}.get(self.score_compute)
+        if mode is None:
+            raise ValueError(f"unknown first-order score_method {self.score_method!r}")
+
+        sums = torch.zeros(len(names), dtype=torch.float64, device=device)
+        accum_samples = 0
+        n_batches = 0
+        for bi, d in enumerate(self.data_loader):
+            if accum_samples >= self.num_samples:
+                break
+            blen = self.batch_len_fn(d)
+            accum_samples += blen
+            n_batches += 1
+            if (bi % world) != rank:
+                continue
+            loss, batch_len = self.loss_func(model, d, cuda_enabled)
+            if batch_len != blen:
+                raise RuntimeError("loss_func batch_len differs from batch_len_fn")
+            grads = torch.autograd.grad(loss, params)
+            assert len(grads) == len(names) == len(params)
+            self._reduce_pairs(params, grads, mode, sums)
+            del grads, loss
+        self._all_reduce_sum(sums)
+        host = sums.cpu().numpy()
+        importance = {}
+        for name, s in zip(names, host):
+            # (sum_b term_b) / n_batches: the reference divides the accumulator by the batch
+            # count (:461) before the product; the product is linear in it
+            importance[name] = torch.tensor([_f32(s / max(n_batches, 1))], dtype=torch.float32)
+        self.stats = {"seconds": time.time() - t0, "layers": len(names), "batches": n_batches,
+                      "world_size": world}
+        return importance
+
+    def _reduce_pairs(self, params, grads, mode, sums):
+        """One multi-tensor launch per (weight dtype, grad dtype) class of the model."""
+        classes = {}
+        for i, (p, g) in enumerate(zip(params, grads)):
+            g = g if g.is_contiguous() else g.contiguous()
+            classes.setdefault((p.dtype, g.dtype), []).append((i, p.data, g))
+        for (dw, dg), items in classes.items():
+            rows = [[p.data_ptr(), g.data_ptr(), p.numel()] for _, p, g in items]
+            table = torch.tensor(rows, dtype=torch.int64, device=sums.device)
+            part = torch.zeros(len(items), dtype=torch.float64, device=sums.device)
+            self.kernels.absprod_reduce_multi(table, max(r[2] for r in rows), dw, dg, mode, part)
+            sums.index_add_(0, torch.tensor([i for i, _, _ in items], device=sums.device), part)
+
+    # ------------------------------------------------------------------ allocation
+    def compute_the_sparsity_per_group(self, total_parameters_to_keep, group_scores,
+                                       group_num_parameters, max_sparsity_per_layer=0.8):
+        """dict group -> sparsity (python float holding an fp32 value), via the C ABI's
+        host allocator, which replays the reference's mixed-dtype arithmetic (:247-314)."""
+        keys = list(group_num_parameters.keys())
+        scores = [float(group_scores[k]) for k in group_scores]
+        nums = [int(group_num_parameters[k]) for k in keys]
+        sparsity, keep = _hip.allocate_sparsity(scores, nums, total_parameters_to_keep,
+                                                max_sparsity_per_layer)
+        self.last_keep = dict(zip(keys, keep))
+        return dict(zip(keys, sparsity))
+
+    def return_sparsity(self):
+        t0 = time.time()
+        original_sparsity = self.original_sparsity
+        mapping = self.layer_to_group_mapping
+        if self.score_compute.startswith("Real"):
+            raise NotImplementedError(
+                "Real-* (global iterative pruning, :156-245) is outside this build's hot path "
+                "(SURVEY.md §8f row 3)")
+        if mapping is None or len(mapping) == 0:
+            return _UniformSparsity(original_sparsity)
+
+        if len(self.importance_measure) == 0:
+            if self.score_compute.startswith("MEZO"):
+                self.importance_measure = self.compute_importance_scores_mezo(mapping)
+            else:
+                self.importance_measure = self.compute_importance_scores(mapping)
+
+        group_to_layers = {}
+        for layer, group in mapping.items():
+            group_to_layers.setdefault(group, []).append(layer)
+
+        numel = {}
+        total_parameters = 0
+        for k, v in self.model.named_parameters():
+            if k in mapping:
+                numel[k] = v.numel()
+                total_parameters += v.numel()
+        total_parameters_to_keep = int(total_parameters * (1 - original_sparsity))
+
+        group_scores, group_num_parameters = {}, {}
+        for group, layers in group_to_layers.items():
+            acc = _f32(0)                      # 0 + fp32 0-dim tensors, added in mapping order (:370)
+            count = 0
+            for layer in layers:
+                acc = _f32(acc + _f32(self._layer_sum(layer)))
+                count += numel[layer]
+            if self.score_aggregate == "avg":
+                acc = _f32(acc / _f32(count))  # tensor /= python int, fp32 (:375)
+            group_scores[group] = acc
+            group_num_parameters[group] = count
+
+        if self.prune_per_model:
+            group_sparsity = {}
+            for prefix in self.per_model_group:
+                sub_scores = {k: v for k, v in group_scores.items() if k.startswith(prefix)}
+                sub_nums = {k: v for k, v in group_num_parameters.items() if k.startswith(prefix)}
+                sub_keep = int(sum(sub_nums.values()) * (1 - original_sparsity))
+                group_sparsity.update(self.compute_the_sparsity_per_group(
+                    sub_keep, sub_scores, sub_nums,
+                    max_sparsity_per_layer=self.max_sparsity_per_layer))
+        else:
+            group_sparsity = self.compute_the_sparsity_per_group(
+                total_parameters_to_keep, group_scores, group_num_parameters,
+                max_sparsity_per_layer=self.max_sparsity_per_layer)
+
+        kept = 0
+        for g in group_num_parameters:
+            kept += (1 - group_sparsity[g]) * group_num_parameters[g]
+        self.stats["kept_vs_target"] = (kept, total_parameters_to_keep)   # reference prints it (:407)
+        self.stats["return_sparsity_seconds"] = time.time() - t0
+        return {layer: group_sparsity[group] for layer, group in mapping.items()}
+
+    def _layer_sum(self, layer):
+        v = self.importance_measure[layer]
+        if torch.is_tensor(v):
+            return float(v.sum()) if v.numel() != 1 else float(v.reshape(()))
+        return float(v)

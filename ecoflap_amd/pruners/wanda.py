@@ -1,0 +1,402 @@
+"""Stage 2 of ECoFLaP: Wanda local pruning, block by block, driven by the stage-1
+sparsity table; plus the three registered pruners of the reference.
+
+Host-side mirror of LAVIS/lavis/compression/pruners/wanda_pruner.py:
+  WrappedGPT (:54-84)                      -> K6 `ecoflap_colsqnorm_accum`
+  T5LayerWandaPruner (:87-375)             -> rows mode of K7 (:272-279)
+  VITLayerWandaPruner (:378-657)           -> matrix mode of K7 (:555-558)
+  BLIPT5LayerWandaPruner (:660-875)        -> ViT blocks, T5 encoder, T5 decoder
+Same registered names, constructor keywords, `prune()` contract
+(`-> (model, sparsity_dict_or_None)`, weights pruned in place) and sparsity-table
+keys.  The column statistics, the metric, the k-smallest selection and the zeroing
+run as HIP kernels on the weight's own storage; nothing is sorted and no
+metric/mask tensor is materialised.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip as _hip
+from ..registry import registry
+from .base_pruner import LayerWiseBasePruner, print_time
+from .layer_sparsity import LayerSparsity, _default_batch_len
+from .losses import loss_language, loss_vision, loss_vision_language
+
+
+def get_module_recursive(base, module_to_process):
+    for part in [p for p in module_to_process.split(".") if p]:
+        base = getattr(base, part)
+    return base
+
+
+def find_layers(module, layers=(nn.Linear,), name=""):
+    """name -> module for every nn.Linear below `module` (wanda_pruner.py:33-52)."""
+    if type(module) in tuple(layers):
+        return {name: module}
+    res = {}
+    for child_name, child in module.named_children():
+        res.update(find_layers(child, layers=layers,
+                               name=name + "." + child_name if name != "" else child_name))
+    return res
+
+
+class WrappedGPT:
+    """Running mean of the per-input-channel sum of squares of a Linear's inputs."""
+
+    def __init__(self, layer, layer_id=0, layer_name="none", kernels=None):
+        self.layer = layer
+        self.dev = self.layer.weight.device
+        self.rows = layer.weight.data.shape[0]
+        self.columns = layer.weight.data.shape[1]
+        self.scaler_row = torch.zeros((self.columns), device=self.dev)
+        self.nsamples = 0
+        self.layer_id = layer_id
+        self.layer_name = layer_name
+        self.kernels = kernels if kernels is not None else _hip.HipKernels()
+
+    def add_batch(self, inp, out):
+        if len(inp.shape) == 2:
+            inp = inp.unsqueeze(0)
+        tmp = inp.shape[0]
+        x = inp.reshape((-1, inp.shape[-1]))
+        if not x.is_contiguous():
+            x = x.contiguous()
+        self.kernels.colsqnorm_accum(self.scaler_row, x, self.nsamples, tmp)
+        self.nsamples += tmp
+
+
+class _StopForward(Exception):
+    """Raised from the block-0 pre-hook once its inputs are recorded."""
+
+
+T5_BLOCK_KWARGS = [
+    "attention_mask", "position_bias", "encoder_attention_mask", "encoder_decoder_position_bias",
+    "layer_head_mask", "cross_attn_layer_head_mask", "encoder_hidden_states",
+]
+
+
+class _BlockwiseWanda:
+    """Calibration capture + per-block statistics + selection, shared by the pruners."""
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.kernels = owner.kernels if owner.kernels is not None else _hip.HipKernels()
+        owner.kernels = self.kernels
+
+    def capture(self, model, dataloader, blocks, forward_fn, cache_keys, n_samples):
+        """Record the inputs of block 0 for the first n_samples calibration samples
+        (the reference swaps block 0 for a `Catcher`, :184-209 / :469-493; a pre-hook
+        leaves the ModuleList untouched)."""
+        inps, caches = [], []
+
+        def grab(_module, args, kwargs):
+            x = args[0]
+            inps.append(x.detach())
+            cache = {}
+            for key in cache_keys:
+                if key in kwargs:
+                    cache[key] = kwargs[key]
+                elif len(cache_keys) == 1 and len(args) > 1:
+                    cache[key] = args[1]          # ViT: blk(x, rel_pos_bias) positional
+                else:
+                    raise KeyError(key)           # as the reference's Catcher would
+            caches.append(cache)
+            raise _StopForward()
+
+        handle = blocks[0].register_forward_pre_hook(grab, with_kwargs=True)
+        total = 0
+        try:
+            for batch in dataloader:
+                if total >= n_samples:
+                    break
+                total += _default_batch_len(batch) if "image" not in batch else batch["image"].shape[0]
+                try:
+                    forward_fn(model, batch)
+                except _StopForward:
+                    pass
+        finally:
+            handle.remove()
+        return inps, [None] * len(inps), caches
+
+    def run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
+            cache_keys, autocast, take_first, mode):
+        with torch.no_grad():
+            blocks = get_module_recursive(model, module_to_process)
+            inps, outs, caches = self.capture(model, dataloader, blocks, forward_fn, cache_keys,
+                                              n_samples)
+        n_batches = min(n_samples, len(inps))     # (:226/:505: compared against the batch count)
+
+        def call(block, j):
+            with torch.no_grad(), autocast():
+                y = block(inps[j], **caches[j])
+            return y[0] if take_first else y
+
+        for i in range(len(blocks)):
+            block = blocks[i]
+            subset = find_layers(block)
+            wrapped = {name: WrappedGPT(subset[name], kernels=self.kernels) for name in subset}
+            handles = [
+                subset[name].register_forward_hook(
+                    lambda _m, inp, out, _n=name: wrapped[_n].add_batch(inp[0].data, out.data))
+                for name in wrapped
+            ]
+            for j in range(n_batches):
+                outs[j] = call(block, j)
+            for h in handles:
+                h.remove()
+            for name in subset:
+                assert wrapped[name].nsamples == len(inps) * inps[0].shape[0]
+                weight = subset[name].weight.data
+                ratio = sparsity_ratio[f"{module_to_process}.{i}.{name}.weight"]
+                if mode == "rows":      # per output row, k smallest by stable order (:272-279)
+                    k = int(weight.shape[1] * ratio)
+                    self.kernels.wanda_prune_rows(weight, wrapped[name].scaler_row, k)
+                else:                   # whole matrix, metric <= sorted[k] (:555-558)
+                    k = int(weight.numel() * ratio)
+                    self.kernels.wanda_prune_matrix(weight, wrapped[name].scaler_row, k)
+            for j in range(n_batches):
+                outs[j] = call(block, j)
+            inps, outs = outs, inps
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        return model
+
+
+def _t5_block_mapping(names, granularity, depth=4):
+    if granularity == "layer":
+        return {k: k for k in names}
+    if granularity == "block":
+        return {k: ".".join(k.split(".")[:depth]) for k in names}
+    raise NotImplementedError
+
+
+class _StageOneMixin:
+    def _layer_sparsity(self, loss_func, original_sparsity, mapping, per_model_group=()):
+        ls = LayerSparsity(
+            self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
+            self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,
+            mapping, prune_per_model=self.prune_per_model, per_model_group=list(per_model_group),
+            kernels=self.kernels, z_source=self.z_source, process_group=self.process_group)
+        self.kernels = ls.kernels
+        out = ls.return_sparsity()
+        self.stage_stats["stage1"] = dict(ls.stats)
+        self.layer_sparsity_engine = ls
+        return out
+
+    def _load_sparsity_yaml(self):
+        import yaml
+        with open(self.sparsity_dict, "r") as f:
+            return yaml.load(f, Loader=yaml.FullLoader)
+
+
+@registry.register_pruner("t5_wanda_pruner")
+class T5LayerWandaPruner(_StageOneMixin, LayerWiseBasePruner):
+    pruner_name = "t5_wanda_pruner"
+
+    def __init__(self, model, data_loader, model_prefix="t5_model", **kwargs):
+        super().__init__(model=model, data_loader=data_loader, model_prefix=model_prefix, **kwargs)
+        self.loss_func = loss_language
+
+    def forward_to_cache(self, model, batch):
+        return model(batch)
+
+    @print_time
+    def _prune(self, model, dataloader, device, model_prefix, module_to_process="encoder.block",
+               n_samples=64, sparsity_ratio=0.5):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        try:
+            _BlockwiseWanda(self).run(
+                model, dataloader, module_to_process, n_samples, sparsity_ratio,
+                forward_fn=lambda m, b: self.forward_to_cache(m, b), cache_keys=T5_BLOCK_KWARGS,
+                autocast=lambda: model.maybe_autocast(dtype=torch.bfloat16), take_first=True,
+                mode="rows")
+        finally:
+            cfg.use_cache = use_cache
+        return model
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        if self.sparsity_dict is not None:
+            return self._load_sparsity_yaml()
+        if sparsity_ratio_granularity is None:
+            mapping = {}
+        else:
+            names = [k for k, v in self.model.named_parameters()
+                     if len(v.shape) == 2 and ".block" in k
+                     and "relative_attention_bias.weight" not in k
+                     and k.startswith(self.model_prefix)]
+            mapping = _t5_block_mapping(names, sparsity_ratio_granularity, depth=4)
+        return self._layer_sparsity(loss_language, original_sparsity, mapping)
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        print("In: ", self.pruner_name)
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+        if self.prune_spec is None:
+            return self.model, None
+        _, keep_ratio, _, _ = self.convert_spec_to_list(self.prune_spec)
+        sparsity_dict = self.get_sparsity(1 - keep_ratio,
+                                          sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+        for part in ("encoder", "decoder"):
+            self.model = self._prune(self.model, self.data_loader, device,
+                                     model_prefix=self.model_prefix,
+                                     module_to_process=f"{self.model_prefix}.{part}.block",
+                                     n_samples=self.num_samples, sparsity_ratio=sparsity_dict)
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        return self.model, sparsity_dict
+
+
+@registry.register_pruner("vit_wanda_pruner")
+class VITLayerWandaPruner(_StageOneMixin, LayerWiseBasePruner):
+    pruner_name = "vit_wanda_pruner"
+
+    def __init__(self, model, data_loader, model_prefix="visual", **kwargs):
+        super().__init__(model=model, data_loader=data_loader, model_prefix=model_prefix, **kwargs)
+        self.loss_func = loss_vision
+
+    def forward_to_cache(self, model, batch):
+        return model.encode_image(batch["image"])
+
+    @print_time
+    def _prune(self, model, dataloader, device, model_prefix, module_to_process="encoder.block",
+               n_samples=64, sparsity_ratio=0.5):
+        return _BlockwiseWanda(self).run(
+            model, dataloader, module_to_process, n_samples, sparsity_ratio,
+            forward_fn=lambda m, b: self.forward_to_cache(m, b), cache_keys=["rel_pos_bias"],
+            autocast=lambda: model.maybe_autocast(), take_first=False, mode="matrix")
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        if self.sparsity_dict is not None:
+            sparsity_dict = self._load_sparsity_yaml()
+            # tables written by the multi-modal pruner use the BLIP-2 prefix (:576-583)
+            sparsity_dict = {k.replace("visual_encoder.", "visual."): v
+                             for k, v in sparsity_dict.items()}
+            if "visual.blocks.39.attn.qkv.weight" not in sparsity_dict:
+                for leaf in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+                    sparsity_dict[f"visual.blocks.39.{leaf}.weight"] = 0
+            return sparsity_dict
+        if sparsity_ratio_granularity is None:
+            mapping = {}
+        else:
+            names = [k for k, v in self.model.named_parameters()
+                     if len(v.shape) == 2 and ".blocks" in k and k.startswith(self.model_prefix)]
+            mapping = _t5_block_mapping(names, sparsity_ratio_granularity, depth=3)
+        return self._layer_sparsity(loss_vision, original_sparsity, mapping)
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        print("In: ", self.pruner_name)
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+        if self.prune_spec is None:
+            return self.model, None
+        _, keep_ratio, _, _ = self.convert_spec_to_list(self.prune_spec)
+        sparsity_dict = self.get_sparsity(1 - keep_ratio,
+                                          sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+        self.model = self._prune(self.model, self.data_loader, device,
+                                 model_prefix=self.model_prefix,
+                                 module_to_process=f"{self.model_prefix}.blocks",
+                                 n_samples=self.num_samples, sparsity_ratio=sparsity_dict)
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        return self.model, sparsity_dict
+
+
+@registry.register_pruner("blipt5_wanda_pruner")
+class BLIPT5LayerWandaPruner(_StageOneMixin, LayerWiseBasePruner):
+    pruner_name = "blipt5_wanda_pruner"
+
+    def __init__(self, model, data_loader, t5_prune_spec=None, vit_prune_spec=None,
+                 t5_pruning_method=None, vit_pruning_method=None, t5_model_prefix="t5_model",
+                 vit_model_prefix="visual_encoder", **kwargs):
+        kwargs.pop("prune_spec", None)
+        kwargs.pop("model_prefix", None)
+        super().__init__(model=model, data_loader=data_loader, prune_spec=None,
+                         model_prefix="tmp", **kwargs)
+        self.t5_prune_spec = t5_prune_spec
+        self.vit_prune_spec = vit_prune_spec
+        assert t5_pruning_method is not None
+        assert vit_pruning_method is not None
+        self.t5_model_prefix = t5_model_prefix
+        self.vit_model_prefix = vit_model_prefix
+
+    def forward_to_cache(self, model, batch):
+        return model(batch)
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        if self.sparsity_dict is not None:
+            return self._load_sparsity_yaml()
+        t5p, vitp = self.t5_model_prefix, self.vit_model_prefix
+        if sparsity_ratio_granularity is None:
+            mapping = {}
+        else:
+            names = [k for k, v in self.model.named_parameters()
+                     if len(v.shape) == 2 and ".block" in k
+                     and "relative_attention_bias.weight" not in k
+                     and (k.startswith(t5p) or k.startswith(vitp))]
+
+            def group_of(name):
+                is_t5 = name.startswith(t5p)
+                if sparsity_ratio_granularity == "model":
+                    return t5p if is_t5 else vitp
+                if sparsity_ratio_granularity == "layer":
+                    return name
+                if sparsity_ratio_granularity == "block":
+                    return ".".join(name.split(".")[:4 if is_t5 else 3])
+                raise NotImplementedError
+
+            mapping = {k: group_of(k) for k in names}
+        return self._layer_sparsity(loss_vision_language, original_sparsity, mapping,
+                                    per_model_group=[t5p, vitp])
+
+    def _vit_prune(self, model, dataloader, device, model_prefix, module_to_process, n_samples,
+                   sparsity_ratio):
+        return _BlockwiseWanda(self).run(
+            model, dataloader, module_to_process, n_samples, sparsity_ratio,
+            forward_fn=lambda m, b: self.forward_to_cache(m, b), cache_keys=["rel_pos_bias"],
+            autocast=lambda: model.maybe_autocast(), take_first=False, mode="matrix")
+
+    def _t5_prune(self, model, dataloader, device, model_prefix, module_to_process, n_samples,
+                  sparsity_ratio):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        try:
+            _BlockwiseWanda(self).run(
+                model, dataloader, module_to_process, n_samples, sparsity_ratio,
+                forward_fn=lambda m, b: self.forward_to_cache(m, b), cache_keys=T5_BLOCK_KWARGS,
+                autocast=lambda: model.maybe_autocast(dtype=torch.bfloat16), take_first=True,
+                mode="rows")
+        finally:
+            cfg.use_cache = use_cache
+        return model
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        print("In: ", self.pruner_name)
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+
+        global_sparsity_dict = None
+        if self.sparsity_ratio_granularity is not None:
+            _, vit_keep_ratio, _, _ = self.convert_spec_to_list(self.vit_prune_spec)
+            _, t5_keep_ratio, _, _ = self.convert_spec_to_list(self.t5_prune_spec)
+            assert vit_keep_ratio == t5_keep_ratio
+            global_sparsity_dict = self.get_sparsity(
+                1 - vit_keep_ratio, sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+
+        def table_for(spec):
+            if global_sparsity_dict is not None:
+                return global_sparsity_dict
+            _, keep_ratio, _, _ = self.convert_spec_to_list(spec)
+            return self.get_sparsity(1 - keep_ratio, sparsity_ratio_granularity=None)
+
+        if self.vit_prune_spec is not None:
+            self.model = self._vit_prune(
+                self.model, self.data_loader, device, model_prefix=self.vit_model_prefix,
+                module_to_process=f"{self.vit_model_prefix}.blocks", n_samples=self.num_samples,
+                sparsity_ratio=table_for(self.vit_prune_spec))
+        if self.t5_prune_spec is not None:
+            table = table_for(self.t5_prune_spec)
+            for part in ("encoder", "decoder"):
+                self.model = self._t5_prune(
+                    self.model, self.data_loader, device, model_prefix=self.t5_model_prefix,
+                    module_to_process=f"{self.t5_model_prefix}.{part}.block",
+                    n_samples=self.num_samples, sparsity_ratio=table)
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        return self.model, global_sparsity_dict

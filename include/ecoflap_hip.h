@@ -78,7 +78,11 @@ int ecoflap_zo_perturb(void* w, int64_t n, int dtype,
  * computes them in ONE pass over w — same three roundings each, so
  * w_plus / w_minus / w_restored are bit-identical to three ecoflap_zo_perturb
  * calls — reading w once and generating z once (4*s instead of 6*s bytes per
- * element).  Outputs may alias w_in (in place) but not each other. */
+ * element).  Outputs may alias w_in (in place) but not each other.
+ * w_plus and w_minus may BOTH be NULL: drift-only form that stores just
+ * w_restored (2*s bytes per element) — used by data-parallel ranks that do not
+ * evaluate a batch but must carry the reference's rounding drift so that every
+ * replica ends with the single-process weights. */
 int ecoflap_zo_perturb_triple(const void* w_in, void* w_plus, void* w_minus,
                               void* w_restored, int64_t n, int dtype,
                               float zo_eps, uint64_t seed, const void* z,

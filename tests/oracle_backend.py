@@ -1,0 +1,86 @@
+"""Checker backend for the tests: the CPU oracle behind the same interface as
+`ecoflap_amd.hip.HipKernels`.  Lives under tests/ on purpose — the product never
+imports oracle/.  Tensors on the GPU are round-tripped through the host so the
+same model forward (on the GPU) can be driven by either backend."""
+import ctypes
+
+import torch
+
+import oracle as _oracle
+
+
+class OracleKernels:
+    name = "oracle"
+
+    def __init__(self, z_from=None):
+        self.o = _oracle.load()
+        self.z_from = z_from      # callable (seed, like_tensor) -> z, used when z is None
+
+    @staticmethod
+    def _host(t):
+        return t.detach().cpu().contiguous()
+
+    def _z(self, z, seed, like):
+        if z is None:
+            if self.z_from is None:
+                raise RuntimeError("oracle backend needs z (it has no in-register generator)")
+            z = self.z_from(seed, like)
+        return self._host(z)
+
+    def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
+        h = self._host(w)
+        self.o.zo_perturb(h, float(scaling_factor), float(zo_eps), self._z(z, seed, w))
+        w.copy_(h)
+
+    def zo_perturb_triple(self, w_in, w_plus, w_minus, w_restored, zo_eps, seed, z=None):
+        plus, minus, rest = self.o.zo_perturb_triple(self._host(w_in), float(zo_eps),
+                                                     self._z(z, seed, w_in))
+        if w_plus is not None:
+            w_plus.copy_(plus)
+        if w_minus is not None:
+            w_minus.copy_(minus)
+        w_restored.copy_(rest)
+
+    def absprod_reduce(self, w, g, mode, out_accum):
+        v = self.o.absprod_reduce(self._host(w) if w is not None else None,
+                                  self._host(g) if g is not None else None, mode)
+        out_accum += v
+
+    def absprod_reduce_multi(self, table, max_numel, dtype_w, dtype_g, mode, out_accum):
+        assert table.device.type == "cpu", "multi-tensor oracle path takes host pointers"
+        code = _oracle.binding.DT
+        for i, (wp, gp, n) in enumerate(table.tolist()):
+            v = self.o.lib.oracle_absprod_reduce(ctypes.c_void_p(wp), ctypes.c_void_p(gp), n,
+                                                 code[dtype_w], code[dtype_g], mode)
+            out_accum[i] += v
+
+    def colsqnorm_accum(self, scaler_row, x2d, nsamples_before, batch):
+        s = self._host(scaler_row)
+        self.o.colsqnorm_accum(s, self._host(x2d), nsamples_before, batch)
+        scaler_row.copy_(s)
+
+    def wanda_prune_rows(self, w, scaler_row, k, mask_out=None):
+        h = self._host(w)
+        m = self.o.wanda_prune_rows(h, self._host(scaler_row), k, want_mask=True)
+        w.copy_(h)
+        if mask_out is not None:
+            mask_out.copy_(m)
+
+    def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
+        h = self._host(w)
+        m = self.o.wanda_prune_matrix(h, self._host(scaler_row), k, want_mask=True)
+        w.copy_(h)
+        if mask_out is not None:
+            mask_out.copy_(m)
+
+    def mask_mul(self, g, keep_mask):
+        h = self._host(g)
+        self.o.mask_mul(h, self._host(keep_mask))
+        g.copy_(h)
+
+
+def torch_cpu_normal(seed, like):
+    """z exactly as the reference draws it for a CPU parameter
+    (layer_single_base_pruner.py:482-485)."""
+    torch.manual_seed(seed)
+    return torch.normal(mean=0, std=1, size=like.size(), device="cpu", dtype=like.dtype)
