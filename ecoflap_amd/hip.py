@@ -190,6 +190,25 @@ class HipKernels:
             int(mode), _ptr(out_accum), _ptr(ws), ws.numel(), _stream()),
             "ecoflap_absprod_reduce_multi")
 
+    def absprod_reduce_pairs(self, weights, grads, mode, out_accum):
+        """out_accum[l] += sum_e f(weights[l], grads[l]) for every layer l, with one
+        multi-tensor launch per (weight dtype, grad dtype) class of the model."""
+        _gpu(out_accum, "out_accum")
+        classes = {}
+        keep_alive = []
+        for i, (w, g) in enumerate(zip(weights, grads)):
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep_alive.append(g)
+            classes.setdefault((w.dtype, g.dtype), []).append((i, _gpu(w, "w"), _gpu(g, "g")))
+        for (dw, dg), items in classes.items():
+            rows = [[w.data_ptr(), g.data_ptr(), w.numel()] for _, w, g in items]
+            table = torch.tensor(rows, dtype=torch.int64, device=out_accum.device)
+            part = torch.zeros(len(items), dtype=torch.float64, device=out_accum.device)
+            self.absprod_reduce_multi(table, max(r[2] for r in rows), dw, dg, mode, part)
+            index = torch.tensor([i for i, _, _ in items], device=out_accum.device)
+            out_accum.index_add_(0, index, part)
+
     # ---- K6 ---------------------------------------------------------------------------
     def colsqnorm_accum(self, scaler_row, x2d, nsamples_before, batch):
         _gpu(scaler_row, "scaler_row")

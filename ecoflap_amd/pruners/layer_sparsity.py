@@ -342,17 +342,8 @@ class LayerSparsity:
         return importance
 
     def _reduce_pairs(self, params, grads, mode, sums):
-        """One multi-tensor launch per (weight dtype, grad dtype) class of the model."""
-        classes = {}
-        for i, (p, g) in enumerate(zip(params, grads)):
-            g = g if g.is_contiguous() else g.contiguous()
-            classes.setdefault((p.dtype, g.dtype), []).append((i, p.data, g))
-        for (dw, dg), items in classes.items():
-            rows = [[p.data_ptr(), g.data_ptr(), p.numel()] for _, p, g in items]
-            table = torch.tensor(rows, dtype=torch.int64, device=sums.device)
-            part = torch.zeros(len(items), dtype=torch.float64, device=sums.device)
-            self.kernels.absprod_reduce_multi(table, max(r[2] for r in rows), dw, dg, mode, part)
-            sums.index_add_(0, torch.tensor([i for i, _, _ in items], device=sums.device), part)
+        """sums[l] += sum_e f(W_l, g_l): one multi-tensor launch per dtype class."""
+        self.kernels.absprod_reduce_pairs([p.data for p in params], list(grads), mode, sums)
 
     # ------------------------------------------------------------------ allocation
     def compute_the_sparsity_per_group(self, total_parameters_to_keep, group_scores,

@@ -2,8 +2,6 @@
 `ecoflap_amd.hip.HipKernels`.  Lives under tests/ on purpose — the product never
 imports oracle/.  Tensors on the GPU are round-tripped through the host so the
 same model forward (on the GPU) can be driven by either backend."""
-import ctypes
-
 import torch
 
 import oracle as _oracle
@@ -46,13 +44,9 @@ class OracleKernels:
                                   self._host(g) if g is not None else None, mode)
         out_accum += v
 
-    def absprod_reduce_multi(self, table, max_numel, dtype_w, dtype_g, mode, out_accum):
-        assert table.device.type == "cpu", "multi-tensor oracle path takes host pointers"
-        code = _oracle.binding.DT
-        for i, (wp, gp, n) in enumerate(table.tolist()):
-            v = self.o.lib.oracle_absprod_reduce(ctypes.c_void_p(wp), ctypes.c_void_p(gp), n,
-                                                 code[dtype_w], code[dtype_g], mode)
-            out_accum[i] += v
+    def absprod_reduce_pairs(self, weights, grads, mode, out_accum):
+        for i, (w, g) in enumerate(zip(weights, grads)):
+            out_accum[i] += self.o.absprod_reduce(self._host(w), self._host(g), mode)
 
     def colsqnorm_accum(self, scaler_row, x2d, nsamples_before, batch):
         s = self._host(scaler_row)

@@ -1,0 +1,372 @@
+"""GPU parity: the HIP kernels, called through the C ABI, against the CPU oracle and the
+reference's golden vectors.  Run on an MI355X with `pytest -m gpu`.
+
+Integer / bit / index results: exact.  Float reductions: 1e-6 relative vs the oracle's
+double accumulation (north_star: 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import NP2T, from_bits, to_bits
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def kern():
+    from ecoflap_amd import hip
+    assert torch.cuda.is_available()
+    return hip.HipKernels()
+
+
+def gpu(t):
+    return t.to("cuda").contiguous()
+
+
+# ------------------------------------------------------------------------------ K1
+def test_philox_words_bit_exact(kern, oracle):
+    for n, seed in [(1, 0), (7, 123), (4096, 2**40 + 5), (100003, 999999999)]:
+        got = kern.philox_u32(n, seed).cpu()
+        assert torch.equal(got, oracle.philox_u32(n, seed)), (n, seed)
+
+
+def test_k1_reference_goldens_bit_exact(kern, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_zo_perturb.npz"))
+    for case in g["cases"]:
+        dt_name, n, eps, seed = str(case).split("|")
+        dt = NP2T[dt_name]
+        key = f"{dt_name}_{n}_{seed}"
+        z = gpu(from_bits(g[key + "_z"], dt))
+        w = gpu(from_bits(g[key + "_w0"], dt).clone())
+        for step, sf in enumerate([1, -2, 1]):        # the reference's three passes
+            kern.zo_perturb(w, sf, float(eps), int(seed), z)
+            assert np.array_equal(to_bits(w), g[key + f"_w{step + 1}"]), (key, step)
+        w0 = gpu(from_bits(g[key + "_w0"], dt).clone())
+        plus, minus, rest = torch.empty_like(w0), torch.empty_like(w0), torch.empty_like(w0)
+        kern.zo_perturb_triple(w0, plus, minus, rest, float(eps), int(seed), z)
+        assert np.array_equal(to_bits(plus), g[key + "_w1"])
+        assert np.array_equal(to_bits(minus), g[key + "_w2"])
+        assert np.array_equal(to_bits(rest), g[key + "_w3"])
+        # in place (w_plus aliases w_in) and drift-only forms
+        w1 = gpu(from_bits(g[key + "_w0"], dt).clone())
+        kern.zo_perturb_triple(w1, w1, minus, rest, float(eps), int(seed), z)
+        assert np.array_equal(to_bits(w1), g[key + "_w1"])
+        w2 = gpu(from_bits(g[key + "_w0"], dt).clone())
+        only = torch.empty_like(w2)
+        kern.zo_perturb_triple(w2, None, None, only, float(eps), int(seed), z)
+        assert np.array_equal(to_bits(only), g[key + "_w3"])
+        assert np.array_equal(to_bits(w2), g[key + "_w0"])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [1, 5, 8, 1000, 4099, 2048 * 512 + 3])
+def test_k1_in_register_z_equals_materialised_stream(kern, oracle, dt, n):
+    """perturb(seed) with z generated in registers == oracle perturb fed the stream that
+    ecoflap_zo_fill_normal writes for the same seed (bit exact, ragged sizes)."""
+    torch.manual_seed(n)
+    seed = 1234567 + n
+    w0 = (torch.randn(n) * 0.05).to(dt)
+    z = torch.empty(n, dtype=dt, device="cuda")
+    kern.zo_fill_normal(z, seed)
+    zc = z.cpu()
+    w = gpu(w0.clone())
+    ref = w0.clone()
+    for sf in (1.0, -2.0, 1.0):
+        kern.zo_perturb(w, sf, 1e-3, seed)
+        oracle.zo_perturb(ref, sf, 1e-3, zc)
+        assert torch.equal(w.cpu().view(torch.uint8), ref.view(torch.uint8)), sf
+    plus, minus, rest = (torch.empty(n, dtype=dt, device="cuda") for _ in range(3))
+    kern.zo_perturb_triple(gpu(w0.clone()), plus, minus, rest, 1e-3, seed)
+    p, m, r = oracle.zo_perturb_triple(w0.clone(), 1e-3, zc)
+    for a, b in ((plus, p), (minus, m), (rest, r)):
+        assert torch.equal(a.cpu().view(torch.uint8), b.view(torch.uint8))
+
+
+def test_k1_normal_stream_statistics(kern):
+    n = 1 << 22
+    z = torch.empty(n, dtype=torch.float32, device="cuda")
+    kern.zo_fill_normal(z, 42)
+    zd = z.double()
+    assert abs(zd.mean().item()) < 3e-3
+    assert abs(zd.var().item() - 1.0) < 5e-3
+    assert abs((zd ** 3).mean().item()) < 1e-2              # skewness
+    assert abs((zd ** 4).mean().item() - 3.0) < 3e-2        # kurtosis
+    # Kolmogorov-Smirnov against N(0,1)
+    from scipy import stats
+    sample = z[: 200000].cpu().numpy()
+    assert stats.kstest(sample, "norm").pvalue > 1e-3
+    # tails exist and are finite
+    assert torch.isfinite(z).all() and z.abs().max().item() > 4.5
+    # another seed: independent stream
+    z2 = torch.empty_like(z)
+    kern.zo_fill_normal(z2, 43)
+    assert abs((zd * z2.double()).mean().item()) < 3e-3
+    # lag-1 autocorrelation (pairs come from one Box-Muller draw)
+    assert abs((zd[:-1] * zd[1:]).mean().item()) < 3e-3
+    # storage dtypes are the rounded fp32 stream
+    for dt in (torch.float16, torch.bfloat16):
+        zh = torch.empty(4096, dtype=dt, device="cuda")
+        kern.zo_fill_normal(zh, 42)
+        assert torch.equal(zh, z[:4096].to(dt))
+
+
+@pytest.mark.parametrize("dt,shape", [(torch.bfloat16, (5120, 2048)), (torch.float16, (6144, 1408))])
+def test_k1_full_size_properties(kern, dt, shape):
+    """BASELINE-size matrices: fused triple == three passes == drift-only, bit for bit;
+    the restore is NOT exact and the perturbation has the right scale."""
+    torch.manual_seed(1)
+    w0 = (torch.randn(shape, device="cuda") * 0.02).to(dt)
+    seed = 987654321
+    a = w0.clone()
+    states = []
+    for sf in (1, -2, 1):
+        kern.zo_perturb(a, sf, 1e-3, seed)
+        states.append(a.clone())
+    plus, minus, rest = torch.empty_like(w0), torch.empty_like(w0), torch.empty_like(w0)
+    kern.zo_perturb_triple(w0, plus, minus, rest, 1e-3, seed)
+    assert torch.equal(plus, states[0]) and torch.equal(minus, states[1]) and torch.equal(rest, states[2])
+    only = torch.empty_like(w0)
+    kern.zo_perturb_triple(w0, None, None, only, 1e-3, seed)
+    assert torch.equal(only, rest)
+    d = (plus.float() - minus.float())
+    assert 1.5e-3 < d.std().item() < 2.5e-3                  # 2 * eps * z
+    assert (rest != w0).float().mean().item() > 0.05         # rounding drift exists
+    assert (rest.float() - w0.float()).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------ K3+K4
+@pytest.mark.parametrize("dtw,dtg", [(torch.float32, torch.float32), (torch.float16, torch.float16),
+                                     (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                     (torch.float16, torch.float32)])
+@pytest.mark.parametrize("n", [1, 9, 4099, 1 << 20])
+def test_absprod_reduce_vs_oracle(kern, oracle, dtw, dtg, n):
+    torch.manual_seed(n)
+    w = (torch.randn(n) * 0.05).to(dtw)
+    g = (torch.randn(n) * 0.01).to(dtg)
+    for mode in range(5):
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        kern.absprod_reduce(gpu(w), gpu(g), mode, out)
+        kern.absprod_reduce(gpu(w), gpu(g), mode, out)       # accumulates
+        want = 2 * oracle.absprod_reduce(w, g, mode)
+        assert abs(out.item() - want) <= 1e-6 * abs(want) + 1e-300, (mode, out.item(), want)
+
+
+def test_absprod_reduce_multi_vs_oracle(kern, oracle):
+    torch.manual_seed(0)
+    sizes = [1, 7, 2048 * 2048, 5120 * 2048 + 5, 333]
+    ws = [gpu((torch.randn(n) * 0.05).to(torch.bfloat16)) for n in sizes]
+    gs = [gpu((torch.randn(n) * 0.01).to(torch.bfloat16)) for n in sizes]
+    table = torch.tensor([[w.data_ptr(), g.data_ptr(), w.numel()] for w, g in zip(ws, gs)],
+                         dtype=torch.int64, device="cuda")
+    for mode in (0, 1, 2):
+        out = torch.zeros(len(sizes), dtype=torch.float64, device="cuda")
+        kern.absprod_reduce_multi(table, max(sizes), torch.bfloat16, torch.bfloat16, mode, out)
+        for i, (w, g) in enumerate(zip(ws, gs)):
+            want = oracle.absprod_reduce(w.cpu(), g.cpu(), mode)
+            assert abs(out[i].item() - want) <= 1e-6 * abs(want) + 1e-300, (mode, i)
+    # split invariance at full size: sum(first half) + sum(second half) == sum(all)
+    w, g = ws[3], gs[3]
+    h = (w.numel() // 16) * 8
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    kern.absprod_reduce(w, g, 0, acc[0:1])
+    kern.absprod_reduce(w[:h], g[:h], 0, acc[1:2])
+    kern.absprod_reduce(w[h:], g[h:], 0, acc[2:3])
+    assert abs(acc[0].item() - (acc[1] + acc[2]).item()) <= 1e-12 * acc[0].item()
+
+
+# ------------------------------------------------------------------------------ K6
+def test_colsqnorm_reference_goldens(kern, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_wrapped_gpt.npz"))
+    for case in g["cases"]:
+        key, steps = str(case).split("|")
+        dt = NP2T[key.split("_")[0]]
+        cols = int(key.split("_")[1])
+        s = torch.zeros(cols, dtype=torch.float32, device="cuda")
+        n = 0
+        for i in range(int(steps)):
+            x = from_bits(g[f"{key}_x{i}"], dt)
+            b = 1 if x.dim() == 2 else x.shape[0]
+            kern.colsqnorm_accum(s, gpu(x.reshape(-1, x.shape[-1])), n, b)
+            n += b
+            np.testing.assert_allclose(s.cpu().numpy(), g[f"{key}_s{i}"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tokens,cols", [(8 * 257, 1408), (8 * 257, 6144), (37, 130), (1, 8), (513, 2048)])
+def test_colsqnorm_vs_oracle(kern, oracle, dt, tokens, cols):
+    torch.manual_seed(tokens + cols)
+    s_ref = torch.rand(cols)
+    s = gpu(s_ref.clone())
+    for step in range(2):
+        x = (torch.randn(tokens, cols) * 1.3).to(dt)
+        kern.colsqnorm_accum(s, gpu(x), 8 * step, 8)
+        oracle.colsqnorm_accum(s_ref, x, 8 * step, 8)
+    np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------ K7
+def _ties(w, levels):
+    return (torch.round(w * levels) / levels)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,cols,frac,levels", [
+    (7, 64, 0.5, None), (5, 100, 0.37, 4), (3, 1, 0.5, None), (16, 5120, 0.5, None),
+    (9, 3000, 0.61, 8), (4, 257, 0.0, None), (4, 257, 1.0, None), (6, 15360, 0.5, 16)])
+def test_wanda_rows_vs_oracle(kern, oracle, dt, rows, cols, frac, levels):
+    torch.manual_seed(rows * cols)
+    w = torch.randn(rows, cols) * 0.05
+    if levels:
+        w = _ties(w, levels * 10)          # few distinct |w| -> many equal metrics
+    w = w.to(dt)
+    s = torch.rand(cols) + 0.1
+    if levels:
+        s = torch.round(s * 2) / 2 + 0.5
+    k = int(cols * frac)
+    wg = gpu(w.clone())
+    mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    kern.wanda_prune_rows(wg, gpu(s), k, mask)
+    wr = w.clone()
+    mref = oracle.wanda_prune_rows(wr, s, k)
+    assert torch.equal(mask.cpu(), mref)
+    assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8))
+    assert (mask.sum(1) == min(k, cols)).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,cols,frac,levels", [
+    (7, 64, 0.5, None), (5, 100, 0.37, 4), (3, 1, 0.5, None), (64, 1408, 0.5, None),
+    (33, 300, 0.61, 8), (4, 257, 0.0, None), (12, 96, 0.999, 2)])
+def test_wanda_matrix_vs_oracle(kern, oracle, dt, rows, cols, frac, levels):
+    torch.manual_seed(rows * cols + 1)
+    w = torch.randn(rows, cols) * 0.05
+    if levels:
+        w = _ties(w, levels * 10)
+    w = w.to(dt)
+    s = torch.rand(cols) + 0.1
+    k = int(rows * cols * frac)
+    wg = gpu(w.clone())
+    mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    kern.wanda_prune_matrix(wg, gpu(s), k, mask)
+    wr = w.clone()
+    mref = oracle.wanda_prune_matrix(wr, s, k)
+    assert torch.equal(mask.cpu(), mref)
+    assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8))
+    assert int(mask.sum()) >= k + 1
+
+
+def test_wanda_full_size_properties(kern):
+    """BASELINE-size matrices against size-independent properties and torch.sort itself."""
+    torch.manual_seed(3)
+    # rows mode: FlanT5-XL wo [2048, 5120] bf16 at ratio 0.5
+    w = (torch.randn(2048, 5120, device="cuda") * 0.02).to(torch.bfloat16)
+    s = torch.rand(5120, device="cuda") + 0.05
+    metric = w.abs().float() * torch.sqrt(s).reshape(1, -1)
+    k = int(5120 * 0.5)
+    idx = torch.sort(metric, dim=-1, stable=True)[1][:, :k]        # the reference's selection
+    want = torch.zeros_like(metric, dtype=torch.bool).scatter_(1, idx, True)
+    mask = torch.zeros(2048, 5120, dtype=torch.uint8, device="cuda")
+    w2 = w.clone()
+    kern.wanda_prune_rows(w2, s, k, mask)
+    assert torch.equal(mask.bool(), want)
+    assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
+    w3 = w2.clone()
+    kern.wanda_prune_rows(w3, s, k)                                 # idempotent
+    assert torch.equal(w3, w2)
+    # matrix mode: ViT-g fc1 [6144, 1408] fp16 at ratio 0.5
+    w = (torch.randn(6144, 1408, device="cuda") * 0.02).half()
+    s = torch.rand(1408, device="cuda") + 0.05
+    metric = w.abs().float() * torch.sqrt(s).reshape(1, -1)
+    k = int(metric.numel() * 0.5)
+    thres = torch.sort(metric.flatten())[0][k]
+    want = metric <= thres
+    mask = torch.zeros(6144, 1408, dtype=torch.uint8, device="cuda")
+    w2 = w.clone()
+    kern.wanda_prune_matrix(w2, s, k, mask)
+    assert torch.equal(mask.bool(), want)
+    assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
+
+
+# ------------------------------------------------------------------------------ K8
+@pytest.mark.parametrize("dt", DTYPES)
+def test_mask_mul(kern, oracle, dt):
+    torch.manual_seed(5)
+    g = torch.randn(4099).to(dt)
+    keep = (torch.rand(4099) > 0.5).to(torch.uint8)
+    gg = gpu(g.clone())
+    kern.mask_mul(gg, gpu(keep))
+    ref = g.clone()
+    oracle.mask_mul(ref, keep)
+    assert torch.equal(gg.cpu().view(torch.uint8), ref.view(torch.uint8))
+
+
+# ------------------------------------------------------------------------------ whole path
+def _z_from_hip(kern):
+    def f(seed, like):
+        z = torch.empty_like(like, device="cuda")
+        kern.zo_fill_normal(z, seed)
+        return z
+    return f
+
+
+@pytest.mark.parametrize("tag", ["vit_block", "t5_layer", "t5_ties_first", "blip2_block",
+                                 "blip2_permodel", "vit_ties_uniform"])
+def test_pruner_end_to_end_hip_equals_oracle(kern, golden_dir, tag):
+    """Same GPU model forward on both sides; HIP kernels vs oracle arithmetic:
+    sparsity table, drifted weights and pruning masks bit-identical."""
+    from oracle_backend import OracleKernels
+    from test_host_parity import run_e2e
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model, sp = run_e2e(tag, golden_dir, backend, device="cuda")
+        res[name] = (sp, {k: v.cpu() for k, v in model.state_dict().items()})
+    sp_h, w_h = res["hip"]
+    sp_o, w_o = res["oracle"]
+    if isinstance(sp_h, dict):
+        assert sp_h == sp_o
+    for k in w_h:
+        assert torch.equal(w_h[k], w_o[k]), k
+    pruned = sum(int((v == 0).sum()) for k, v in w_h.items() if v.dim() == 2 and ".block" in k)
+    assert pruned > 0
+
+
+@pytest.mark.parametrize("method", ["MEZO-GradOnly_sum", "MEZO-GradMagAbs_sum", "GradMagAbs_sum",
+                                    "GradMagSquare_avg", "GradOnly_sum"])
+def test_stage1_philox_mode_hip_equals_oracle(kern, method):
+    """Production mode (z generated in registers) on a bf16/fp16 BLIP-2 shape."""
+    from oracle_backend import OracleKernels
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    out = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        for p in model.parameters():
+            p.requires_grad = True
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        np.random.seed(7)
+        ls = LayerSparsity(model, batches, loss_vision_language, 8, 0.5, 0.6, method, 1, 1e-3,
+                           mapping, kernels=backend, z_source="philox")
+        sp = ls.return_sparsity()
+        out[name] = (sp, {k: float(v.sum()) for k, v in ls.importance_measure.items()},
+                     {k: v.detach().cpu() for k, v in model.state_dict().items()})
+    assert out["hip"][0] == out["oracle"][0]
+    for k, v in out["hip"][1].items():
+        assert abs(v - out["oracle"][1][k]) <= 1e-5 * abs(v) + 1e-30, k
+    for k, v in out["hip"][2].items():
+        assert torch.equal(v, out["oracle"][2][k]), k
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
