@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py — layers scored / second, zeroth-order ECoFLaP on a BLIP-2 (EVA-ViT-g +
+Q-Former + FlanT5-XL) shaped random-init model at 0.5 sparsity (BASELINE.json configs[2];
+SURVEY.md §8d).
+
+A "step" = one prunable weight matrix taken through the whole of the reference's inner
+loops (layer_single_base_pruner.py:512-549): for each of its calibration batches one
++eps/-2eps/+eps perturbation triple (K1), two full forward losses, and its row of the loss
+table.  The K timed steps are K matrices strided evenly over the model's 588 (ViT, T5
+encoder, T5 decoder alike); the closing all-reduce of the loss table, the single host sync,
+the score reduction and the allocator are inside the timed region.
+
+    python bench.py --gpus 1 --steps 12 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Weak scaling: every rank holds a full weight replica and scores the SAME matrices on its
+own 128 calibration pairs (16 batches of 8); N ranks = 128*N pairs per matrix
+(configs[3] at N=8).  `value` counts a matrix scored on 128 pairs as one unit, so the
+whole-job aggregate is N * K / seconds.  One process per GPU, RCCL only for the one
+all-reduce of the loss table.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--num-data", type=int, default=128, help="calibration pairs per rank")
+    ap.add_argument("--batch-size", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-layer", type=int, default=-1)
+    ap.add_argument("--single-pass", action="store_true",
+                    help="three in-place K1 launches per unit instead of the fused triple")
+    ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
+    return ap.parse_args()
+
+
+def strided(n_total, k, offset=0):
+    return [min(n_total - 1, int((i + 0.5) * n_total / k) + offset) for i in range(k)]
+
+
+class TimedKernels:
+    """Wraps the HIP backend and brackets every K1 launch with events on the launch stream."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.enabled = False
+        self.records = []   # (start_event, end_event, algorithmic_bytes, kind)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def _timed(self, kind, nbytes, fn, *a, **kw):
+        if not self.enabled:
+            return fn(*a, **kw)
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn(*a, **kw)
+        e.record()
+        self.records.append((s, e, nbytes, kind))
+        return r
+
+    def zo_perturb_triple(self, w_in, w_plus, w_minus, w_restored, zo_eps, seed, z=None):
+        s = w_in.element_size()
+        full = w_plus is not None
+        nbytes = (4 if full else 2) * s * w_in.numel()     # read W, write theta+, theta-, theta
+        return self._timed("triple" if full else "drift", nbytes, self.inner.zo_perturb_triple,
+                           w_in, w_plus, w_minus, w_restored, zo_eps, seed, z)
+
+    def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
+        nbytes = 2 * w.element_size() * w.numel()          # read W, write W
+        return self._timed("single", nbytes, self.inner.zo_perturb, w, scaling_factor, zo_eps,
+                           seed, z)
+
+    def summary(self, kind):
+        recs = [(s.elapsed_time(e) * 1e-3, b) for s, e, b, k in self.records if k == kind]
+        if not recs:
+            return None
+        t = sum(r[0] for r in recs)
+        b = sum(r[1] for r in recs)
+        return {"launches": len(recs), "avg_us": 1e6 * t / len(recs), "bytes_per_launch": b / len(recs),
+                "gbs": b / t / 1e9}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+
+    from ecoflap_amd import hip
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_flant5xl, blip2_toy
+
+    torch.manual_seed(0)
+    t_build = time.time()
+    with torch.device(dev):
+        model = (blip2_toy(fp32=False) if args.toy else blip2_flant5xl()).eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    img = 28 if args.toy else 224
+    vocab = 96 if args.toy else 32128
+    # every rank its own shard of the global calibration set (global batch index = rank + N*j)
+    batches_local = S.image_text_batches(args.num_data, args.batch_size, img_size=img, vocab=vocab,
+                                         in_len=16, out_len=16, seed=42 + rank, device=dev)
+    nb_local = len(batches_local)
+    # global list seen by the schedule: batch j*world + r lives on rank r (placeholders elsewhere)
+    batches = []
+    for j in range(nb_local):
+        for r in range(world):
+            batches.append(batches_local[j] if r == rank else
+                           {"text_input": batches_local[j]["text_input"]})
+    num_samples_global = args.num_data * world
+
+    prunable = [k for k, v in model.named_parameters()
+                if v.dim() == 2 and ".block" in k and "relative_attention_bias.weight" not in k
+                and (k.startswith("t5_model") or k.startswith("visual_encoder"))]
+    group_of = lambda k: ".".join(k.split(".")[:4 if k.startswith("t5_model") else 3])  # noqa: E731
+    full_mapping = {k: group_of(k) for k in prunable}
+    n_total = len(prunable)
+    numel_total = sum(dict(model.named_parameters())[k].numel() for k in prunable)
+    build_s = time.time() - t_build
+
+    kern = TimedKernels(hip.HipKernels())
+
+    def run(layer_ids, timed):
+        mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
+        np.random.seed(42)
+        ls = LayerSparsity(model, batches, loss_vision_language, num_samples_global, 0.5, 0.6,
+                           "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
+                           z_source="philox", fused_triple=not args.single_pass)
+        kern.enabled = timed
+        out = ls.return_sparsity()
+        kern.enabled = False
+        return ls, out
+
+    # ---- warmup (untimed) ---------------------------------------------------------------
+    if args.warmup > 0:
+        run(strided(n_total, args.warmup, offset=1), timed=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    # ---- timed region: exactly K steps -----------------------------------------------------
+    layer_ids = strided(n_total, args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ls, table = run(layer_ids, timed=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kind = "single" if args.single_pass else "triple"
+    k1 = kern.summary(kind)
+    drift = kern.summary("drift")
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "layers scored/sec (zeroth-order, BLIP-2 @0.5)",
+        "value": value,
+        "unit": "layers/s (one layer = one weight matrix scored on 128 calibration pairs)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16/fp16 weights (T5 bf16, ViT-g fp16), fp32 arithmetic per op",
+        "data": "synthetic",
+        "config": {
+            "workload": ("toy shapes" if args.toy else
+                         "BASELINE configs[2]: BLIP-2 (EVA-ViT-g fp16 + Q-Former + FlanT5-XL bf16) "
+                         "zeroth-order MEZO-GradOnly_sum, block groups, max 0.6, eps 1e-3, "
+                         "128 synthetic image-text pairs per GPU, batch 8 -> 16 batches per layer"),
+            "prunable_matrices": n_total,
+            "prunable_elements": numel_total,
+            "layers_timed": layer_ids,
+            "pairs_per_gpu": args.num_data,
+            "batch_size": args.batch_size,
+            "forwards_per_step": 2 * nb_local,
+            "k1_form": "single-pass x3" if args.single_pass else "fused triple",
+            "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
+        },
+        "breakdown": {
+            "model_build_s": build_s,
+            "forwards_total": ls.stats.get("forwards"),
+            "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
+            "drift_only": drift,
+        },
+    }
+    if k1:
+        out["roofline"] = {
+            "kernel": "zo_perturb_triple_kernel" if kind == "triple" else "zo_perturb_kernel",
+            "bound": "hbm",
+            "achieved": k1["gbs"],
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": k1["gbs"] / HBM_PEAK_GBS,
+            "traffic": load_pmc_traffic(kind),
+            "launches": k1["launches"],
+            "avg_launch_us": k1["avg_us"],
+            "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
+            "bytes_rule": ("4*s*numel (read W; write theta+, theta-, restored)" if kind == "triple"
+                           else "2*s*numel per pass (read W, write W)"),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, prunable, batches_local, args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def load_pmc_traffic(kind):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if any."""
+    path = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(kind)
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(model, prunable, batches_local, args):
+    """The oracle (CPU restatement of the reference path, scalar C for K1 + the same torch
+    module forward on the host cores) timed on ONE (matrix, batch) unit and extrapolated to a
+    full layer.  Checker code is used here only as the measured CPU baseline."""
+    import copy
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+
+    idx = args.cpu_baseline_layer if args.cpu_baseline_layer >= 0 else len(prunable) // 2
+    name = prunable[idx]
+    t0 = time.time()
+    cpu_model = copy.deepcopy(model).to("cpu").float().eval()   # host forward in fp32
+    cpu_batches = [{k: v.cpu() for k, v in batches_local[0].items()}]
+    copy_s = time.time() - t0
+    mapping = {name: name}
+    np.random.seed(42)
+    ls = LayerSparsity(cpu_model, cpu_batches, loss_vision_language, args.batch_size, 0.5, 0.6,
+                       "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=OracleKernels(),
+                       z_source=torch_cpu_normal, fused_triple=False)
+    t0 = time.perf_counter()
+    ls.compute_importance_scores_mezo(mapping)
+    unit_s = time.perf_counter() - t0
+    nb = len(batches_local)
+    return {
+        "value": 1.0 / (unit_s * nb),
+        "unit": "layers/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": (f"1 of {len(prunable)} matrices ({name}) x 1 of {nb} batches: 3 oracle K1 passes "
+                   f"(scalar C, 1 thread, z from torch.normal) + 2 fp32 forwards on "
+                   f"{torch.get_num_threads()} host threads = {unit_s:.2f} s, x{nb} batches per layer"),
+        "unit_seconds": unit_s,
+        "host_copy_seconds": copy_s,
+        "nproc": os.cpu_count(),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -18,8 +18,8 @@
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // ---- storage dtype traits: 16-byte vector <-> fp32 lanes -------------------------------
-// Conversions are plain casts: on gfx950 hipcc emits v_cvt_pk_bf16_f32 / v_cvt_f16_f32,
-// both round-to-nearest-even and NaN-preserving.
+// bf16: plain casts (hipcc emits v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-preserving;
+// gfx950 has no bf16 VALU arithmetic to narrow into).  f16: explicit v_cvt asm, see below.
 template <int DT> struct Vec;
 
 template <> struct Vec<ECOFLAP_F32> {
@@ -53,8 +53,19 @@ template <> struct Vec<ECOFLAP_F16> {
         uint16_t b = (uint16_t)bits;
         return (float)__builtin_bit_cast(_Float16, b);
     }
+    // f32 -> f16 through an explicit v_cvt instruction.  A plain cast lets hipcc fold
+    // `(half)(a_f32 * b_f32)` into v_fma_mixlo_f16, which rounds the EXACT product once;
+    // torch rounds the product to f32 first and then to f16 (the reference's arithmetic,
+    // differs at ties ~1e-4 of elements).  The asm operand forces the f32 result to exist.
     static __device__ __forceinline__ uint32_t f2h(float x) {
-        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x);
+        uint32_t h;
+        asm("v_cvt_f16_f32_e32 %0, %1" : "=v"(h) : "v"(x));
+        return h & 0xffffu;
+    }
+    static __device__ __forceinline__ uint32_t f2h_pk(float lo, float hi) {
+        uint32_t h;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(lo), "v"(hi));
+        return h;
     }
     static __device__ __forceinline__ void unpack(const u32x4& v, float* f) {
 #pragma unroll
@@ -66,15 +77,15 @@ template <> struct Vec<ECOFLAP_F16> {
     static __device__ __forceinline__ u32x4 pack(const float* f) {
         u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = f2h(f[2 * i]) | (f2h(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) v[i] = f2h_pk(f[2 * i], f[2 * i + 1]);
         return v;
     }
-    static __device__ __forceinline__ float round(float x) { return (float)(_Float16)x; }
+    static __device__ __forceinline__ float round(float x) { return h2f(f2h(x)); }
     static __device__ __forceinline__ float load1(const void* p, int64_t i) {
         return (float)((const _Float16*)p)[i];
     }
     static __device__ __forceinline__ void store1(void* p, int64_t i, float x) {
-        ((_Float16*)p)[i] = (_Float16)x;
+        ((uint16_t*)p)[i] = (uint16_t)f2h(x);
     }
 };
 

@@ -86,6 +86,28 @@ def test_k1_in_register_z_equals_materialised_stream(kern, oracle, dt, n):
         assert torch.equal(a.cpu().view(torch.uint8), b.view(torch.uint8))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_k1_million_elements_vs_oracle(kern, oracle, dt):
+    """Rounding ties (~1e-4 of elements) only show up at scale: f32 product first, then the
+    storage rounding — never a single rounding of the exact product."""
+    n = (1 << 20) + 3
+    torch.manual_seed(11)
+    w0 = (torch.randn(n) * 0.05).to(dt)
+    z = torch.randn(n).to(dt)
+    for eps in (1e-3, 3.3e-3):
+        w = gpu(w0.clone())
+        ref = w0.clone()
+        for sf in (1.0, -2.0, 1.0):
+            kern.zo_perturb(w, sf, eps, 5, gpu(z))
+            oracle.zo_perturb(ref, sf, eps, z)
+        assert torch.equal(w.cpu().view(torch.uint8), ref.view(torch.uint8)), eps
+        plus, minus, rest = (torch.empty(n, dtype=dt, device="cuda") for _ in range(3))
+        kern.zo_perturb_triple(gpu(w0.clone()), plus, minus, rest, eps, 5, gpu(z))
+        p, m, r = oracle.zo_perturb_triple(w0.clone(), eps, z)
+        for a, b in ((plus, p), (minus, m), (rest, r)):
+            assert torch.equal(a.cpu().view(torch.uint8), b.view(torch.uint8))
+
+
 def test_k1_normal_stream_statistics(kern):
     n = 1 << 22
     z = torch.empty(n, dtype=torch.float32, device="cuda")
@@ -175,7 +197,7 @@ def test_absprod_reduce_multi_vs_oracle(kern, oracle):
     kern.absprod_reduce(w, g, 0, acc[0:1])
     kern.absprod_reduce(w[:h], g[:h], 0, acc[1:2])
     kern.absprod_reduce(w[h:], g[h:], 0, acc[2:3])
-    assert abs(acc[0].item() - (acc[1] + acc[2]).item()) <= 1e-12 * acc[0].item()
+    assert abs(acc[0].item() - (acc[1] + acc[2]).item()) <= 1e-9 * acc[0].item()
 
 
 # ------------------------------------------------------------------------------ K6
