@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-layer", type=int, default=-1)
-    ap.add_argument("--single-pass", action="store_true",
-                    help="three in-place K1 launches per unit instead of the fused triple")
+    ap.add_argument("--k1-form", default="units", choices=["units", "triple", "single"],
+                    help="units: one K1 launch per layer (default); triple: one fused launch per "
+                         "(layer,batch) unit; single: the reference's three in-place passes")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
     return ap.parse_args()
 
@@ -82,6 +83,13 @@ class TimedKernels:
         nbytes = (4 if full else 2) * s * w_in.numel()     # read W, write theta+, theta-, theta
         return self._timed("triple" if full else "drift", nbytes, self.inner.zo_perturb_triple,
                            w_in, w_plus, w_minus, w_restored, zo_eps, seed, z)
+
+    def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
+        owned = sum(1 for t in w_plus if t is not None)
+        assert len(seeds) <= self.inner.MAX_UNITS, "one launch per layer expected in the bench"
+        nbytes = (2 * owned + 2) * w.element_size() * w.numel()   # read W; write 2/unit + final
+        return self._timed("units", nbytes, self.inner.zo_perturb_units, w, zo_eps, seeds, w_plus,
+                           w_minus, z)
 
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         nbytes = 2 * w.element_size() * w.numel()          # read W, write W
@@ -153,7 +161,7 @@ def main():
         np.random.seed(42)
         ls = LayerSparsity(model, batches, loss_vision_language, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
-                           z_source="philox", fused_triple=not args.single_pass)
+                           z_source="philox", k1_form=args.k1_form)
         kern.enabled = timed
         out = ls.return_sparsity()
         kern.enabled = False
@@ -181,7 +189,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kind = "single" if args.single_pass else "triple"
+    kind = args.k1_form
     k1 = kern.summary(kind)
     drift = kern.summary("drift")
     value = world * args.steps / elapsed
@@ -210,7 +218,7 @@ def main():
             "pairs_per_gpu": args.num_data,
             "batch_size": args.batch_size,
             "forwards_per_step": 2 * nb_local,
-            "k1_form": "single-pass x3" if args.single_pass else "fused triple",
+            "k1_form": args.k1_form,
             "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
         },
         "breakdown": {
@@ -222,7 +230,8 @@ def main():
     }
     if k1:
         out["roofline"] = {
-            "kernel": "zo_perturb_triple_kernel" if kind == "triple" else "zo_perturb_kernel",
+            "kernel": {"units": "zo_perturb_units_kernel", "triple": "zo_perturb_triple_kernel",
+                       "single": "zo_perturb_kernel"}[kind],
             "bound": "hbm",
             "achieved": k1["gbs"],
             "peak": HBM_PEAK_GBS,
@@ -232,8 +241,11 @@ def main():
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
-            "bytes_rule": ("4*s*numel (read W; write theta+, theta-, restored)" if kind == "triple"
-                           else "2*s*numel per pass (read W, write W)"),
+            "bytes_rule": {
+                "units": "(2*U+2)*s*numel per launch: read W once, write theta+/theta- for each of "
+                         "the layer's U units, write the final drifted W",
+                "triple": "4*s*numel (read W; write theta+, theta-, restored)",
+                "single": "2*s*numel per pass (read W, write W)"}[kind],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, prunable, batches_local, args)
@@ -274,7 +286,7 @@ def cpu_baseline(model, prunable, batches_local, args):
     np.random.seed(42)
     ls = LayerSparsity(cpu_model, cpu_batches, loss_vision_language, args.batch_size, 0.5, 0.6,
                        "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=OracleKernels(),
-                       z_source=torch_cpu_normal, fused_triple=False)
+                       z_source=torch_cpu_normal, k1_form="single")
     t0 = time.perf_counter()
     ls.compute_importance_scores_mezo(mapping)
     unit_s = time.perf_counter() - t0

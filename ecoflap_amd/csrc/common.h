@@ -81,6 +81,13 @@ template <> struct Vec<ECOFLAP_F16> {
         return v;
     }
     static __device__ __forceinline__ float round(float x) { return h2f(f2h(x)); }
+    // round two values with ONE packed convert; returns the packed pair (ready to store)
+    static __device__ __forceinline__ uint32_t round_pair(float x0, float x1, float& r0, float& r1) {
+        const uint32_t pk = f2h_pk(x0, x1);
+        r0 = h2f(pk & 0xffffu);
+        r1 = h2f(pk >> 16);
+        return pk;
+    }
     static __device__ __forceinline__ float load1(const void* p, int64_t i) {
         return (float)((const _Float16*)p)[i];
     }
@@ -111,6 +118,12 @@ template <> struct Vec<ECOFLAP_BF16> {
     }
     static __device__ __forceinline__ float round(float x) {
         return __uint_as_float(f2b(x) << 16);
+    }
+    static __device__ __forceinline__ uint32_t round_pair(float x0, float x1, float& r0, float& r1) {
+        const uint32_t pk = f2b(x0) | (f2b(x1) << 16);   // one v_cvt_pk_bf16_f32
+        r0 = __uint_as_float(pk << 16);
+        r1 = __uint_as_float(pk & 0xffff0000u);
+        return pk;
     }
     static __device__ __forceinline__ float load1(const void* p, int64_t i) {
         return __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16);

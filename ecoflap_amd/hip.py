@@ -20,7 +20,7 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
-    "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
+    "ecoflap_zo_perturb_units", "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
@@ -53,6 +53,7 @@ def load_library():
     lib.ecoflap_error_string.argtypes = [ci]
     lib.ecoflap_zo_perturb.argtypes = [vp, i64, ci, f32, f32, u64, vp, vp]
     lib.ecoflap_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, u64, vp, vp]
+    lib.ecoflap_zo_perturb_units.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
@@ -147,6 +148,35 @@ class HipKernels:
             _ptr(w_in), _ptr(w_plus), _ptr(w_minus), _ptr(w_restored), w_in.numel(),
             DTYPE_CODE[w_in.dtype], float(zo_eps), int(seed), _ptr(z), _stream()),
             "ecoflap_zo_perturb_triple")
+
+    MAX_UNITS = 32
+
+    def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
+        """All units of one layer in one launch (chunks of MAX_UNITS); w is updated in place
+        to the final drifted weights, unit u's theta+/theta- land in w_plus[u]/w_minus[u]
+        (None, None = drift only)."""
+        _gpu(w, "w")
+        n_units = len(seeds)
+        assert len(w_plus) == n_units and len(w_minus) == n_units
+        for t in list(w_plus) + list(w_minus) + (list(z) if z is not None else []):
+            if t is not None:
+                _gpu(t, "unit buffer")
+                if t.dtype != w.dtype or t.numel() != w.numel():
+                    raise EcoflapHipError("unit buffers must match w in dtype and numel")
+        for c0 in range(0, n_units, self.MAX_UNITS):
+            c1 = min(n_units, c0 + self.MAX_UNITS)
+            m = c1 - c0
+            seeds_a = (ctypes.c_uint64 * m)(*[int(x) for x in seeds[c0:c1]])
+            plus_a = (ctypes.c_void_p * m)(*[t.data_ptr() if t is not None else None
+                                             for t in w_plus[c0:c1]])
+            minus_a = (ctypes.c_void_p * m)(*[t.data_ptr() if t is not None else None
+                                              for t in w_minus[c0:c1]])
+            z_a = None
+            if z is not None:
+                z_a = (ctypes.c_void_p * m)(*[t.data_ptr() for t in z[c0:c1]])
+            _check(self.lib.ecoflap_zo_perturb_units(
+                _ptr(w), w.numel(), DTYPE_CODE[w.dtype], float(zo_eps), m, seeds_a, plus_a,
+                minus_a, z_a, _stream()), "ecoflap_zo_perturb_units")
 
     def zo_fill_normal(self, z_out, seed):
         _gpu(z_out, "z_out")

@@ -72,7 +72,7 @@ class LayerSparsity:
         z_source="philox",
         batch_len_fn=None,
         process_group=None,
-        fused_triple=True,
+        k1_form="units",
     ):
         """Positional arguments are the reference's (:120-135).  Keyword-only extras:
 
@@ -83,7 +83,11 @@ class LayerSparsity:
                       or a callable (seed, param) -> z tensor (parity tests).
         process_group torch.distributed group to shard calibration batches over
                       (None = use the default group if initialised, else single process).
-        fused_triple  False: three single-pass launches, like the reference's call pattern.
+        k1_form       "units"  (default) one launch per layer: every unit's theta+ / theta-
+                               precomputed into scratch, W read once;
+                      "triple" one fused launch per (layer, batch, noise) unit;
+                      "single" three in-place launches per unit, the reference's call pattern.
+                      All three are bit-identical.
         """
         self.importance_measure = {}
         self.model = model
@@ -106,7 +110,8 @@ class LayerSparsity:
         self.z_source = z_source
         self.batch_len_fn = batch_len_fn or _default_batch_len
         self.process_group = process_group
-        self.fused_triple = fused_triple
+        assert k1_form in ("units", "triple", "single")
+        self.k1_form = k1_form
         self.stats = {}          # wall-clock + unit counts of the last run (reference: @print_time)
         self.loss_table = None   # [units, 2] fp32 (host copy) of the last zeroth-order run
         self.seed_schedule = None
@@ -202,13 +207,42 @@ class LayerSparsity:
         n_forward = 0
         for li, (name, param) in enumerate(zip(names, params)):
             home = param.data
+            layer_units = by_layer.get(li, [])
+            owned = [(units[u][1] % world) == rank for u in layer_units]
+            if self.k1_form == "units":
+                # one launch: theta+/theta- of every owned unit into scratch, final drifted theta
+                # back into the parameter's own storage; then only forwards remain
+                n_owned = sum(owned)
+                scratch = torch.empty((2 * max(n_owned, 1),) + tuple(home.shape), dtype=home.dtype,
+                                      device=home.device)
+                plus, minus, zs, k = [], [], [], 0
+                for u, mine in zip(layer_units, owned):
+                    plus.append(scratch[2 * k] if mine else None)
+                    minus.append(scratch[2 * k + 1] if mine else None)
+                    k += int(mine)
+                    zs.append(self._draw_z(units[u][3], param))
+                if layer_units:
+                    self.kernels.zo_perturb_units(
+                        home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
+                        None if self.z_source == "philox" else zs)
+                for j, (u, mine) in enumerate(zip(layer_units, owned)):
+                    if not mine:
+                        continue
+                    _, bi, _, _, blen = units[u]
+                    param.data = plus[j]        # theta + eps z
+                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                    param.data = minus[j]       # theta - eps z
+                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                    n_forward += 2
+                param.data = home               # "recovered" weights, with the reference's drift
+                del scratch, plus, minus, zs
+                continue
             cur = home
             spare = [torch.empty_like(home), torch.empty_like(home)]
-            for u in by_layer.get(li, []):
+            for u, mine in zip(layer_units, owned):
                 _, bi, _, seed, blen = units[u]
-                mine = (bi % world) == rank
                 z = self._draw_z(seed, param)
-                if not self.fused_triple:
+                if self.k1_form == "single":
                     # reference call pattern: three in-place passes (:530-539)
                     param.data = cur
                     self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)

@@ -88,6 +88,21 @@ int ecoflap_zo_perturb_triple(const void* w_in, void* w_plus, void* w_minus,
                               float zo_eps, uint64_t seed, const void* z,
                               void* stream);
 
+/* Layer-batched form: n_units consecutive triples of the SAME matrix in one pass
+ * (bit-identical to n_units ecoflap_zo_perturb_triple calls chained through
+ * w_restored).  w is read once and rewritten in place with the final drifted
+ * weights; unit u's theta+ / theta- go to w_plus[u] / w_minus[u] (host arrays
+ * of device pointers; a NULL pair = carry the drift only, for units another
+ * rank evaluates).  seeds: host array of n_units seeds; z: NULL (in-register
+ * Philox) or host array of n_units device pointers (parity mode).
+ * n_units <= ECOFLAP_MAX_UNITS; callers chunk longer schedules.
+ * Algorithmic bytes: (2*owned_units + 2) * s per element. */
+#define ECOFLAP_MAX_UNITS 32
+int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_eps,
+                             int n_units, const uint64_t* seeds,
+                             void* const* w_plus, void* const* w_minus,
+                             const void* const* z, void* stream);
+
 /* Materialise the in-register z stream of K1 for (seed, n, dtype). */
 int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,
                            void* stream);

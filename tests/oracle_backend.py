@@ -39,6 +39,16 @@ class OracleKernels:
             w_minus.copy_(minus)
         w_restored.copy_(rest)
 
+    def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
+        cur = self._host(w)
+        for u, seed in enumerate(seeds):
+            zz = self._z(z[u] if z is not None else None, seed, w)
+            plus, minus, cur = self.o.zo_perturb_triple(cur, float(zo_eps), zz)
+            if w_plus[u] is not None:
+                w_plus[u].copy_(plus)
+                w_minus[u].copy_(minus)
+        w.copy_(cur)
+
     def absprod_reduce(self, w, g, mode, out_accum):
         v = self.o.absprod_reduce(self._host(w) if w is not None else None,
                                   self._host(g) if g is not None else None, mode)

@@ -160,6 +160,44 @@ def test_k1_full_size_properties(kern, dt, shape):
     assert (rest.float() - w0.float()).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n,n_units", [(5, 3), (4099, 16), (2048 * 2048, 16), (100003, 40)])
+def test_k1_layer_batched_equals_chained_triples(kern, oracle, dt, n, n_units):
+    """ecoflap_zo_perturb_units == n_units chained triples (HIP) == oracle chain, bit for bit,
+    with some units drift-only (not owned by this rank), in-register z and supplied z."""
+    torch.manual_seed(n + n_units)
+    w0 = (torch.randn(n) * 0.05).to(dt)
+    seeds = [1000 + 7 * u for u in range(n_units)]
+    owned = [(u % 3) != 1 for u in range(n_units)]
+    for supplied in (False, True):
+        zs = None
+        if supplied:
+            zs = [gpu(torch.randn(n).to(dt)) for _ in range(n_units)]
+        w = gpu(w0.clone())
+        plus = [torch.empty(n, dtype=dt, device="cuda") if o else None for o in owned]
+        minus = [torch.empty(n, dtype=dt, device="cuda") if o else None for o in owned]
+        kern.zo_perturb_units(w, 1e-3, seeds, plus, minus, zs)
+        cur = gpu(w0.clone())
+        ref = w0.clone()
+        for u in range(n_units):
+            p, m, r = (torch.empty_like(cur) for _ in range(3))
+            kern.zo_perturb_triple(cur, p, m, r, 1e-3, seeds[u], zs[u] if supplied else None)
+            if supplied:
+                zc = zs[u].cpu()
+            else:
+                zc = torch.empty(n, dtype=dt, device="cuda")
+                kern.zo_fill_normal(zc, seeds[u])
+                zc = zc.cpu()
+            po, mo, ref = oracle.zo_perturb_triple(ref, 1e-3, zc)
+            if owned[u]:
+                assert torch.equal(plus[u], p) and torch.equal(minus[u], m), (u, supplied)
+                assert torch.equal(p.cpu().view(torch.uint8), po.view(torch.uint8))
+                assert torch.equal(m.cpu().view(torch.uint8), mo.view(torch.uint8))
+            cur = r
+        assert torch.equal(w, cur)
+        assert torch.equal(w.cpu().view(torch.uint8), ref.view(torch.uint8))
+
+
 # ------------------------------------------------------------------------------ K3+K4
 @pytest.mark.parametrize("dtw,dtg", [(torch.float32, torch.float32), (torch.float16, torch.float16),
                                      (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),

@@ -57,10 +57,10 @@ def _setup(tag):
 
 @pytest.mark.parametrize("tag", ["vit", "blip2"])
 @pytest.mark.parametrize("method,num_noise,num_samples", SCORING)
-@pytest.mark.parametrize("fused", [True, False])
-def test_stage1_matches_reference(golden_dir, tag, method, num_noise, num_samples, fused):
-    if not fused and not method.startswith("MEZO"):
-        pytest.skip("fused flag only affects the zeroth-order loop")
+@pytest.mark.parametrize("k1_form", ["units", "triple", "single"])
+def test_stage1_matches_reference(golden_dir, tag, method, num_noise, num_samples, k1_form):
+    if k1_form != "units" and not method.startswith("MEZO"):
+        pytest.skip("k1_form only affects the zeroth-order loop")
     g = np.load(os.path.join(golden_dir, "g2_scoring.npz"))
     model, batches, loss_fn = _setup(tag)
     load_state(model, g, f"{tag}_init")
@@ -79,7 +79,7 @@ def test_stage1_matches_reference(golden_dir, tag, method, num_noise, num_sample
 
     ls = LayerSparsity(model, batches, logging_loss, num_samples, 0.5, 0.6, method, num_noise,
                        1e-3, mapping, kernels=OracleKernels(), z_source=torch_cpu_normal,
-                       fused_triple=fused)
+                       k1_form=k1_form)
     sp = ls.return_sparsity()
     np.testing.assert_allclose(np.array(losses), g[key + "_losses"], rtol=1e-6)
     sums = np.array([float(ls.importance_measure[k].sum()) for k in names])
