@@ -62,6 +62,7 @@ class TimedKernels:
         self.inner = inner
         self.enabled = False
         self.records = []   # (start_event, end_event, algorithmic_bytes, kind)
+        self.blocker = None
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
@@ -69,6 +70,12 @@ class TimedKernels:
     def _timed(self, kind, nbytes, fn, *a, **kw):
         if not self.enabled:
             return fn(*a, **kw)
+        # The loop is host-bound (the GPU drains its queue while Python prepares the next
+        # launch), so an event pair would also time the host gap between its two records.
+        # A ~0.2 ms GEMM queued first keeps the GPU busy while the host enqueues
+        # start-event, kernel and stop-event back to back; it is not part of the timed span.
+        if self.blocker is not None:
+            torch.mm(self.blocker, self.blocker)
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -155,6 +162,7 @@ def main():
     build_s = time.time() - t_build
 
     kern = TimedKernels(hip.HipKernels())
+    kern.blocker = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 
     def run(layer_ids, timed):
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
@@ -237,7 +245,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": k1["gbs"] / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(kind),
+            "traffic": load_pmc_traffic(kind, k1["bytes_per_launch"]),
+            "traffic_source": "profiles/k1_pmc_traffic.json (rocprofv3 --pmc, separate passes)",
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
@@ -255,15 +264,20 @@ def main():
         dist.destroy_process_group()
 
 
-def load_pmc_traffic(kind):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if any."""
+def load_pmc_traffic(kind, algorithmic_bytes_per_launch=None):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/
+    k1_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes over
+    tools/k1_launches.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    The counters cannot be read live; the measured traffic/algorithmic ratio of the same
+    kernel is applied to this run's average launch."""
     path = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path)).get(kind)
-        except Exception:
-            return None
-    return None
+    if not os.path.exists(path) or algorithmic_bytes_per_launch is None:
+        return None
+    try:
+        ratio = json.load(open(path)).get(kind, {}).get("traffic_over_algorithmic")
+        return None if ratio is None else ratio * algorithmic_bytes_per_launch
+    except Exception:
+        return None
 
 
 def cpu_baseline(model, prunable, batches_local, args):
