@@ -72,10 +72,11 @@ class TimedKernels:
             return fn(*a, **kw)
         # The loop is host-bound (the GPU drains its queue while Python prepares the next
         # launch), so an event pair would also time the host gap between its two records.
-        # A ~0.2 ms GEMM queued first keeps the GPU busy while the host enqueues
+        # ~0.6 ms of GEMMs queued first keep the GPU busy while the host enqueues
         # start-event, kernel and stop-event back to back; it is not part of the timed span.
         if self.blocker is not None:
-            torch.mm(self.blocker, self.blocker)
+            for _ in range(4):
+                torch.mm(self.blocker, self.blocker)
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
