@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--k1-form", default="units", choices=["units", "triple", "single"],
                     help="units: one K1 launch per layer (default); triple: one fused launch per "
                          "(layer,batch) unit; single: the reference's three in-place passes")
+    ap.add_argument("--full-forward", action="store_true",
+                    help="two full forwards per unit like the reference, instead of the exact "
+                         "suffix-only re-forward (pruners/prefix_cache.py)")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
     return ap.parse_args()
 
@@ -165,10 +168,13 @@ def main():
     kern = TimedKernels(hip.HipKernels())
     kern.blocker = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+
     def run(layer_ids, timed):
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
         np.random.seed(42)
-        ls = LayerSparsity(model, batches, loss_vision_language, num_samples_global, 0.5, 0.6,
+        loss_fn = loss_vision_language if args.full_forward else PrefixCachedLoss(model)
+        ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
                            z_source="philox", k1_form=args.k1_form)
         kern.enabled = timed
@@ -228,6 +234,9 @@ def main():
             "batch_size": args.batch_size,
             "forwards_per_step": 2 * nb_local,
             "k1_form": args.k1_form,
+            "forward_form": ("2 full forwards per unit" if args.full_forward else
+                             "exact suffix-only re-forward from the owning block (activations "
+                             "at the block boundary cached per batch)"),
             "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
         },
         "breakdown": {

@@ -205,9 +205,12 @@ class LayerSparsity:
             by_layer.setdefault(unit[0], []).append(u)
 
         n_forward = 0
+        begin_layer = getattr(self.loss_func, "begin_layer", None)
         for li, (name, param) in enumerate(zip(names, params)):
             home = param.data
             layer_units = by_layer.get(li, [])
+            if begin_layer is not None:
+                begin_layer(name)     # exact suffix-only re-forward (pruners/prefix_cache.py)
             owned = [(units[u][1] % world) == rank for u in layer_units]
             if self.k1_form == "units":
                 # one launch: theta+/theta- of every owned unit into scratch, final drifted theta

@@ -1,0 +1,87 @@
+"""Exact suffix-only re-forward for the zeroth-order loop.
+
+The reference evaluates two FULL forwards per (layer, batch, noise) unit
+(layer_single_base_pruner.py:530-536), although only one weight matrix differs from
+the previous evaluation and everything upstream of the block that owns it is unchanged.
+With 288 GB of HBM the activations at every stage boundary of every calibration batch
+fit trivially (BLIP-2: 16 batches x 5.8 MB), so the loss closure below
+
+  * keeps, per calibration batch, the state entering the stage (ViT block, T5 block, ...)
+    that owns the matrix being scored, computed with the CURRENT weights — i.e. with the
+    drifted weights every earlier layer was left with, exactly what a full forward would
+    see, because layers are scored in parameter order and never change again;
+  * evaluates each loss by running only the stages from there to the end.
+
+In eval mode this is bit-identical to the full forward (the stage functions ARE the
+model's forward: `forward` is their composition) and removes on average ~78 % of the
+FLOPs of BLIP-2's scoring pass.  It is a drop-in `loss_func`: `(model, samples,
+cuda_enabled) -> (loss, batch_len)`; `LayerSparsity` tells it which matrix is being
+perturbed through the optional `begin_layer(name)` hook.
+"""
+import torch
+
+
+def _vision_language_result(state):
+    return state["loss"]
+
+
+def _vision_result(state):
+    """-log softmax(logits / 100)[target], the reference's loss_vision (pruners/utils.py:47-67)."""
+    logits = state["predictions"] / 100
+    targets = state["targets"]
+    probs = torch.nn.functional.softmax(logits, -1)
+    idx = torch.arange(len(targets)).to(targets.device)
+    return -probs[idx, targets].log().mean()
+
+
+class PrefixCachedLoss:
+    def __init__(self, model, kind="vision_language", batch_len_fn=None):
+        self.model = model
+        self.plan = model.stage_plan()
+        self.result = _vision_result if kind == "vision" else _vision_language_result
+        self.batch_len_fn = batch_len_fn
+        self.entry = 0              # stage that owns the parameter being perturbed
+        self.cache = {}             # id(batch) -> (stage index, state entering that stage)
+        self.stats = {"stage_calls": 0, "stage_calls_full": 0, "advance_calls": 0}
+
+    # ---- hook called by LayerSparsity before the units of a layer --------------------------
+    def begin_layer(self, name):
+        self.entry = self.stage_of(name)
+
+    def stage_of(self, name):
+        for i, (_, prefixes, _) in enumerate(self.plan):
+            for p in prefixes:
+                if name.startswith(p):
+                    return i
+        return 0                    # unknown owner: full forward (always correct)
+
+    def reset(self):
+        self.cache.clear()
+        self.entry = 0
+
+    # ---- the loss closure ----------------------------------------------------------------------
+    def __call__(self, model, samples, cuda_enabled):
+        assert model is self.model
+        key = id(samples)
+        idx, state = self.cache.get(key, (0, samples))
+        if idx > self.entry:        # asked for an earlier stage than cached: start over
+            idx, state = 0, samples
+        if idx < self.entry:
+            with torch.no_grad():
+                for j in range(idx, self.entry):
+                    state = self.plan[j][2](state)
+                    self.stats["advance_calls"] += 1
+            idx = self.entry
+            self.cache[key] = (idx, state)
+        out = state
+        for j in range(idx, len(self.plan)):
+            out = self.plan[j][2](out)
+        self.stats["stage_calls"] += len(self.plan) - idx
+        self.stats["stage_calls_full"] += len(self.plan)
+        if self.batch_len_fn is not None:
+            n = self.batch_len_fn(samples)
+        elif "text_input" in samples:
+            n = len(samples["text_input"])
+        else:
+            n = len(samples["label"])
+        return self.result(out), n

@@ -171,6 +171,12 @@ def _t5_block_mapping(names, granularity, depth=4):
 
 class _StageOneMixin:
     def _layer_sparsity(self, loss_func, original_sparsity, mapping, per_model_group=()):
+        if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
+                and str(self.score_method).startswith("MEZO") and mapping):
+            # same losses, bit for bit, from the owning block onwards only
+            from .prefix_cache import PrefixCachedLoss
+            loss_func = PrefixCachedLoss(
+                self.model, kind="vision" if loss_func is loss_vision else "vision_language")
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

@@ -109,36 +109,63 @@ class Blip2T5(nn.Module):
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=dtype)
 
-    # --- staged forward: the scoring loop may re-enter at any stage boundary ---
-    def encode_vision(self, image):
-        with self.maybe_autocast():
-            return self.ln_vision(self.visual_encoder(image))
+    # --- staged forward: the scoring loop may re-enter at any stage boundary -------------
+    def stage_plan(self):
+        """[(name, owned parameter prefixes, fn(state) -> state)] in execution order =
+        parameter registration order; stage 0 takes the batch dict.  `forward` is the
+        composition of the stages, so a forward re-entered at a cached stage boundary runs
+        exactly the ops a full forward would run from there
+        (ecoflap_amd/pruners/prefix_cache.py)."""
+        vit = self.visual_encoder
+        t5 = self.t5_model
+        plan = []
 
-    def vision_to_t5_inputs(self, image_embeds):
-        q = self.query_tokens.expand(image_embeds.shape[0], -1, -1)
-        q = self.Qformer(q, image_embeds.to(q.dtype))
-        return self.t5_proj(q)
+        def vit_embed(samples):
+            image = samples["image"].to(self.device)
+            with self.maybe_autocast():
+                x = vit.embed(image)
+            return {"x": x, "text_input": samples["text_input"].to(self.device),
+                    "text_output": samples["text_output"].to(self.device)}
 
-    def language_loss(self, inputs_t5, samples):
-        ids = samples["text_input"].to(self.device)
-        out = samples["text_output"].to(self.device)
-        pad = self.t5_model.config.pad_token_id
-        atts_t5 = torch.ones(inputs_t5.shape[:-1], dtype=torch.long, device=self.device)
-        with self.maybe_autocast(dtype=torch.bfloat16):
-            emb = self.t5_model.encoder.embed_tokens(ids)
-            emb = torch.cat([inputs_t5.to(emb.dtype), emb], dim=1)
-            mask = torch.cat([atts_t5, (ids != pad).long()], dim=1)
-            res = self.t5_model(inputs_embeds=emb, attention_mask=mask,
-                                labels=out.masked_fill(out == pad, -100),
-                                decoder_attention_mask=(out != pad).long())
-        return res
+        plan.append(("visual_encoder.embed", ["visual_encoder.patch_embed.",
+                                              "visual_encoder.cls_token", "visual_encoder.pos_embed"],
+                     vit_embed))
+        for i in range(len(vit.blocks)):
+            def vit_block(st, i=i):
+                with self.maybe_autocast():
+                    x = vit.blocks[i](st["x"], None)
+                new = dict(st)
+                new["x"] = x
+                return new
+            plan.append((f"visual_encoder.blocks.{i}", [f"visual_encoder.blocks.{i}."], vit_block))
+
+        def bridge(st):
+            with self.maybe_autocast():
+                image_embeds = self.ln_vision(st["x"])
+            q = self.query_tokens.expand(image_embeds.shape[0], -1, -1)
+            q = self.Qformer(q, image_embeds.to(q.dtype))
+            inputs_t5 = self.t5_proj(q)
+            ids, out = st["text_input"], st["text_output"]
+            pad = t5.config.pad_token_id
+            atts_t5 = torch.ones(inputs_t5.shape[:-1], dtype=torch.long, device=self.device)
+            with self.maybe_autocast(dtype=torch.bfloat16):
+                emb = t5.encoder.embed_tokens(ids)
+                emb = torch.cat([inputs_t5.to(emb.dtype), emb], dim=1)
+            return {"inputs_embeds": emb,
+                    "attention_mask": torch.cat([atts_t5, (ids != pad).long()], dim=1),
+                    "labels": out.masked_fill(out == pad, -100),
+                    "decoder_attention_mask": (out != pad).long()}
+
+        plan.append(("bridge", ["ln_vision.", "Qformer.", "query_tokens", "t5_proj.",
+                                "t5_model.shared."], bridge))
+        plan += t5.stages("t5_model", lambda: self.maybe_autocast(dtype=torch.bfloat16))
+        return plan
 
     def forward(self, samples):
-        image = samples["image"].to(self.device)
-        image_embeds = self.encode_vision(image)
-        inputs_t5 = self.vision_to_t5_inputs(image_embeds)
-        res = self.language_loss(inputs_t5, samples)
-        return {"loss": res.loss, "logits": res.logits}
+        state = samples
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state
 
 
 def blip2_flant5xl():

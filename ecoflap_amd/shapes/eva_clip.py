@@ -52,10 +52,29 @@ class EVACLIP(nn.Module):
     def encode_image(self, image):
         return self.visual(image.to(self.device))
 
+    def stage_plan(self):
+        """Stages of `predict` (see Blip2T5.stage_plan); the last state holds predictions/targets."""
+        vis = self.visual
+        plan = [("visual.embed", ["visual.patch_embed.", "visual.cls_token", "visual.pos_embed"],
+                 lambda s: {"x": vis.embed(s["image"].to(self.device)),
+                            "targets": s["label"].to(self.device)})]
+        for i in range(len(vis.blocks)):
+            def block(st, i=i):
+                return {"x": vis.blocks[i](st["x"], rel_pos_bias=None), "targets": st["targets"]}
+            plan.append((f"visual.blocks.{i}", [f"visual.blocks.{i}."], block))
+
+        def head(st):
+            feats = F.normalize(vis.head(vis.norm(st["x"])[:, 0]), dim=-1)
+            return {"predictions": 100.0 * feats @ self.classifier, "targets": st["targets"]}
+
+        plan.append(("visual.head", ["visual.norm.", "visual.head."], head))
+        return plan
+
     def predict(self, samples):
-        feats = F.normalize(self.encode_image(samples["image"]), dim=-1)
-        logits = 100.0 * feats @ self.classifier
-        return {"predictions": logits, "targets": samples["label"].to(self.device)}
+        state = samples
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state
 
 
 def vit_b16_clip(num_classes=1000):

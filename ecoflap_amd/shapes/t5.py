@@ -185,33 +185,53 @@ class T5Stack(nn.Module):
             m = m * tri[None, None]
         return (1.0 - m) * torch.finfo(dtype).min
 
-    def forward(self, inputs_embeds, attention_mask, encoder_hidden_states=None,
+    # The stack is written as prepare / one-block / finish steps so that a forward can be
+    # re-entered at any block boundary (ecoflap_amd/pruners/prefix_cache.py); `forward` is
+    # their composition, so both routes run the same ops in the same order.
+    def prepare(self, inputs_embeds, attention_mask, encoder_hidden_states=None,
                 encoder_attention_mask=None):
         dtype = inputs_embeds.dtype
         L = inputs_embeds.shape[1]
-        ext = self._extend(attention_mask, dtype, causal_len=L if self.is_decoder else None)
-        enc_ext = None
+        state = {
+            "h": inputs_embeds,
+            "ext": self._extend(attention_mask, dtype, causal_len=L if self.is_decoder else None),
+            "position_bias": None,
+            "encoder_hidden_states": encoder_hidden_states,
+            "enc_ext": None,
+            "encoder_decoder_position_bias": None,
+        }
         if self.is_decoder and encoder_hidden_states is not None:
-            enc_ext = self._extend(encoder_attention_mask, dtype)
-        position_bias = None
-        encoder_decoder_position_bias = None
-        h = inputs_embeds
-        for blk in self.block:
-            out = blk(
-                h,
-                attention_mask=ext,
-                position_bias=position_bias,
-                encoder_hidden_states=encoder_hidden_states,
-                encoder_attention_mask=enc_ext,
-                encoder_decoder_position_bias=encoder_decoder_position_bias,
-                layer_head_mask=None,
-                cross_attn_layer_head_mask=None,
-            )
-            h = out[0]
-            position_bias = out[1]
-            if self.is_decoder and encoder_hidden_states is not None:
-                encoder_decoder_position_bias = out[2]
-        return self.final_layer_norm(h)
+            state["enc_ext"] = self._extend(encoder_attention_mask, dtype)
+        return state
+
+    def run_block(self, i, state):
+        out = self.block[i](
+            state["h"],
+            attention_mask=state["ext"],
+            position_bias=state["position_bias"],
+            encoder_hidden_states=state["encoder_hidden_states"],
+            encoder_attention_mask=state["enc_ext"],
+            encoder_decoder_position_bias=state["encoder_decoder_position_bias"],
+            layer_head_mask=None,
+            cross_attn_layer_head_mask=None,
+        )
+        new = dict(state)
+        new["h"] = out[0]
+        new["position_bias"] = out[1]
+        if self.is_decoder and state["encoder_hidden_states"] is not None:
+            new["encoder_decoder_position_bias"] = out[2]
+        return new
+
+    def finish(self, state):
+        return self.final_layer_norm(state["h"])
+
+    def forward(self, inputs_embeds, attention_mask, encoder_hidden_states=None,
+                encoder_attention_mask=None):
+        state = self.prepare(inputs_embeds, attention_mask, encoder_hidden_states,
+                             encoder_attention_mask)
+        for i in range(len(self.block)):
+            state = self.run_block(i, state)
+        return self.finish(state)
 
 
 def t5_config(d_model=2048, d_kv=64, num_heads=32, d_ff=5120, num_layers=24,
@@ -245,18 +265,72 @@ class T5ForConditionalGeneration(nn.Module):
         dec[:, 0] = self.config.decoder_start_token_id
         return dec.masked_fill(dec == -100, self.config.pad_token_id)
 
-    def forward(self, inputs_embeds, attention_mask, labels, decoder_attention_mask=None):
-        enc = self.encoder(inputs_embeds, attention_mask)
+    def decoder_prepare(self, enc, attention_mask, labels, decoder_attention_mask=None):
         dec_ids = self._shift_right(labels)
         dec_emb = self.shared(dec_ids)
         if decoder_attention_mask is None:
             decoder_attention_mask = torch.ones_like(dec_ids)
-        dec = self.decoder(dec_emb, decoder_attention_mask, encoder_hidden_states=enc,
-                           encoder_attention_mask=attention_mask)
+        return self.decoder.prepare(dec_emb, decoder_attention_mask, encoder_hidden_states=enc,
+                                    encoder_attention_mask=attention_mask)
+
+    def head(self, dec, labels):
         logits = self.lm_head(dec)
         loss = F.cross_entropy(logits.view(-1, logits.size(-1)).float(), labels.view(-1),
                                ignore_index=-100)
         return SimpleNamespace(loss=loss, logits=logits)
+
+    def forward(self, inputs_embeds, attention_mask, labels, decoder_attention_mask=None):
+        enc = self.encoder(inputs_embeds, attention_mask)
+        state = self.decoder_prepare(enc, attention_mask, labels, decoder_attention_mask)
+        for i in range(len(self.decoder.block)):
+            state = self.decoder.run_block(i, state)
+        return self.head(self.decoder.finish(state), labels)
+
+    def stages(self, prefix, autocast):
+        """Stage list of the encoder-decoder: (name, owned parameter prefixes, fn(state)).
+        The state entering the first stage holds inputs_embeds / attention_mask / labels /
+        decoder_attention_mask."""
+        enc, dec = self.encoder, self.decoder
+        out = []
+
+        def enc_prepare(st):
+            with autocast():
+                new = enc.prepare(st["inputs_embeds"], st["attention_mask"])
+            new.update(attention_mask=st["attention_mask"], labels=st["labels"],
+                       decoder_attention_mask=st["decoder_attention_mask"])
+            return new
+
+        out.append((f"{prefix}.encoder.prepare", [], enc_prepare))
+        for i in range(len(enc.block)):
+            def enc_block(st, i=i):
+                with autocast():
+                    return enc.run_block(i, st)
+            out.append((f"{prefix}.encoder.block.{i}", [f"{prefix}.encoder.block.{i}."], enc_block))
+
+        def bridge(st):
+            with autocast():
+                e = enc.finish(st)
+                new = self.decoder_prepare(e, st["attention_mask"], st["labels"],
+                                           st["decoder_attention_mask"])
+            new["labels"] = st["labels"]
+            return new
+
+        out.append((f"{prefix}.encoder.finish", [f"{prefix}.encoder.final_layer_norm.",
+                                                 f"{prefix}.shared."], bridge))
+        for i in range(len(dec.block)):
+            def dec_block(st, i=i):
+                with autocast():
+                    return dec.run_block(i, st)
+            out.append((f"{prefix}.decoder.block.{i}", [f"{prefix}.decoder.block.{i}."], dec_block))
+
+        def head(st):
+            with autocast():
+                res = self.head(dec.finish(st), st["labels"])
+            return {"loss": res.loss, "logits": res.logits}
+
+        out.append((f"{prefix}.head", [f"{prefix}.decoder.final_layer_norm.", f"{prefix}.lm_head."],
+                    head))
+        return out
 
 
 class T5(nn.Module):
@@ -281,13 +355,24 @@ class T5(nn.Module):
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=dtype)
 
-    def forward(self, samples):
+    def _inputs(self, samples):
         ids = samples["text_input"].to(self.device)
         out = samples["text_output"].to(self.device)
         pad = self.t5_model.config.pad_token_id
         with self.maybe_autocast(dtype=torch.bfloat16):
             emb = self.t5_model.encoder.embed_tokens(ids)
-            res = self.t5_model(inputs_embeds=emb, attention_mask=(ids != pad).long(),
-                                labels=out.masked_fill(out == pad, -100),
-                                decoder_attention_mask=(out != pad).long())
-        return {"loss": res.loss, "logits": res.logits}
+        return {"inputs_embeds": emb, "attention_mask": (ids != pad).long(),
+                "labels": out.masked_fill(out == pad, -100),
+                "decoder_attention_mask": (out != pad).long()}
+
+    def stage_plan(self):
+        """[(name, owned parameter prefixes, fn(state) -> state)]; stage 0 takes the batch."""
+        ac = lambda: self.maybe_autocast(dtype=torch.bfloat16)  # noqa: E731
+        return ([("t5_model.embed", ["t5_model.shared."], self._inputs)]
+                + self.t5_model.stages("t5_model", ac))
+
+    def forward(self, samples):
+        state = samples
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state

@@ -91,6 +91,38 @@ def test_stage1_matches_reference(golden_dir, tag, method, num_noise, num_sample
             assert np.array_equal(to_bits(sd[k]).ravel(), g[key + f"_final::{k}"].ravel()), k
 
 
+@pytest.mark.parametrize("tag", ["vit", "blip2"])
+@pytest.mark.parametrize("method,num_noise,num_samples", SCORING[:4])
+def test_prefix_cached_loss_is_exact(golden_dir, tag, method, num_noise, num_samples):
+    """Suffix-only re-forward: the SAME losses (bit for bit vs the full forward, 1e-6 vs the
+    reference), sparsity table and drifted weights as the reference's two full forwards."""
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    g = np.load(os.path.join(golden_dir, "g2_scoring.npz"))
+    names = [str(n) for n in g[f"{tag}_names"]]
+    mapping = dict(zip(names, [str(x) for x in g[f"{tag}_groups"]]))
+    key = f"{tag}_{method}_n{num_noise}_s{num_samples}"
+    tables = []
+    for cached in (False, True):
+        model, batches, loss_fn = _setup(tag)
+        load_state(model, g, f"{tag}_init")
+        np.random.seed(int(g[key + "_cfg"][0]))
+        if cached:
+            loss_fn = PrefixCachedLoss(model, kind="vision" if tag == "vit" else "vision_language")
+        ls = LayerSparsity(model, batches, loss_fn, num_samples, 0.5, 0.6, method, num_noise,
+                           1e-3, mapping, kernels=OracleKernels(), z_source=torch_cpu_normal)
+        sp = ls.return_sparsity()
+        tables.append(ls.loss_table.copy())
+        assert np.array_equal(np.array([sp[k] for k in names]), g[key + "_sparsity"])
+        sd = model.state_dict()
+        for k in names:
+            assert np.array_equal(to_bits(sd[k]).ravel(), g[key + f"_final::{k}"].ravel()), k
+        if cached:
+            st = loss_fn.stats
+            assert st["stage_calls"] < 0.8 * st["stage_calls_full"]
+    assert np.array_equal(tables[0], tables[1])        # full forward == suffix-only, bit for bit
+    np.testing.assert_allclose(tables[1].reshape(-1), g[key + "_losses"], rtol=1e-6)
+
+
 BASE = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
             is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1, num_noise=1,
             noise_eps=1e-3)
