@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--full-forward", action="store_true",
                     help="two full forwards per unit like the reference, instead of the exact "
                          "suffix-only re-forward (pruners/prefix_cache.py)")
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="launch the suffix forwards eagerly instead of replaying HIP graphs")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
     return ap.parse_args()
 
@@ -173,7 +175,9 @@ def main():
     def run(layer_ids, timed):
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
         np.random.seed(42)
-        loss_fn = loss_vision_language if args.full_forward else PrefixCachedLoss(model)
+        loss_fn = (loss_vision_language if args.full_forward
+                   else PrefixCachedLoss(model, use_graphs=not args.no_graphs))
+        run.loss_fns.append(loss_fn)
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
                            z_source="philox", k1_form=args.k1_form)
@@ -182,6 +186,7 @@ def main():
         kern.enabled = False
         return ls, out
 
+    run.loss_fns = []
     # ---- warmup (untimed) ---------------------------------------------------------------
     if args.warmup > 0:
         run(strided(n_total, args.warmup, offset=1), timed=False)
@@ -236,7 +241,8 @@ def main():
             "k1_form": args.k1_form,
             "forward_form": ("2 full forwards per unit" if args.full_forward else
                              "exact suffix-only re-forward from the owning block (activations "
-                             "at the block boundary cached per batch)"),
+                             "at the block boundary cached per batch)"
+                             + ("" if args.no_graphs else ", suffix replayed as a HIP graph")),
             "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
         },
         "breakdown": {
@@ -244,6 +250,8 @@ def main():
             "forwards_total": ls.stats.get("forwards"),
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
+            "suffix_forward": (dict(run.loss_fns[-1].stats)
+                               if hasattr(run.loss_fns[-1], "stats") else None),
         },
     }
     if k1:

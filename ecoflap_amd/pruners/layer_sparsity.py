@@ -228,15 +228,25 @@ class LayerSparsity:
                     self.kernels.zo_perturb_units(
                         home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
                         None if self.z_source == "philox" else zs)
+                static_w = bool(getattr(self.loss_func, "requires_static_weights", False))
+                final = home.clone() if static_w else None   # graphs bake the address of `home`
                 for j, (u, mine) in enumerate(zip(layer_units, owned)):
                     if not mine:
                         continue
                     _, bi, _, _, blen = units[u]
-                    param.data = plus[j]        # theta + eps z
+                    if static_w:
+                        home.copy_(plus[j])
+                    else:
+                        param.data = plus[j]    # theta + eps z
                     self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
-                    param.data = minus[j]       # theta - eps z
+                    if static_w:
+                        home.copy_(minus[j])
+                    else:
+                        param.data = minus[j]   # theta - eps z
                     self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
                     n_forward += 2
+                if static_w:
+                    home.copy_(final)
                 param.data = home               # "recovered" weights, with the reference's drift
                 del scratch, plus, minus, zs
                 continue

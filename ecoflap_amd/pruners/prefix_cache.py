@@ -34,15 +34,48 @@ def _vision_result(state):
     return -probs[idx, targets].log().mean()
 
 
+def _map_tensors(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
+def _copy_tensors(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_tensors(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s_ in zip(dst, src):
+            _copy_tensors(d, s_)
+
+
 class PrefixCachedLoss:
-    def __init__(self, model, kind="vision_language", batch_len_fn=None):
+    """use_graphs=True (GPU only): the suffix from each entry stage is captured once into a
+    HIP graph (torch.cuda.CUDAGraph -> hipGraph) and replayed for every later unit that
+    re-enters there; the scoring loop is launch-bound (thousands of small kernels per
+    forward), so replay removes the host from the critical path.  Graphs bake device
+    addresses in, hence `requires_static_weights`: LayerSparsity then copies theta+/theta-
+    into the parameter's own storage instead of re-pointing `param.data`."""
+
+    def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False):
         self.model = model
+        self.use_graphs = bool(use_graphs)
+        self.requires_static_weights = self.use_graphs
+        self.graphs = {}            # entry stage -> [calls_seen, graph, static_state, static_loss]
+        self.pool = None
         self.plan = model.stage_plan()
         self.result = _vision_result if kind == "vision" else _vision_language_result
         self.batch_len_fn = batch_len_fn
         self.entry = 0              # stage that owns the parameter being perturbed
         self.cache = {}             # id(batch) -> (stage index, state entering that stage)
-        self.stats = {"stage_calls": 0, "stage_calls_full": 0, "advance_calls": 0}
+        self.stats = {"stage_calls": 0, "stage_calls_full": 0, "advance_calls": 0,
+                      "graph_captures": 0, "graph_replays": 0, "capture_seconds": 0.0}
 
     # ---- hook called by LayerSparsity before the units of a layer --------------------------
     def begin_layer(self, name):
@@ -73,9 +106,10 @@ class PrefixCachedLoss:
                     self.stats["advance_calls"] += 1
             idx = self.entry
             self.cache[key] = (idx, state)
-        out = state
-        for j in range(idx, len(self.plan)):
-            out = self.plan[j][2](out)
+        if self.use_graphs and idx > 0 and _on_gpu(state):
+            loss = self._graphed_suffix(idx, state)
+        else:
+            loss = self.result(self._suffix(idx, state))
         self.stats["stage_calls"] += len(self.plan) - idx
         self.stats["stage_calls_full"] += len(self.plan)
         if self.batch_len_fn is not None:
@@ -84,4 +118,39 @@ class PrefixCachedLoss:
             n = len(samples["text_input"])
         else:
             n = len(samples["label"])
-        return self.result(out), n
+        return loss, n
+
+    def _suffix(self, idx, state):
+        out = state
+        for j in range(idx, len(self.plan)):
+            out = self.plan[j][2](out)
+        return out
+
+    def _graphed_suffix(self, idx, state):
+        import time
+        rec = self.graphs.get(idx)
+        if rec is None:
+            # first visit: eager (also the warm-up torch asks for before a capture)
+            self.graphs[idx] = [1, None, None, None]
+            return self.result(self._suffix(idx, state))
+        if rec[1] is None:
+            t0 = time.time()
+            static_state = _map_tensors(state, lambda t: t.clone())
+            graph = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()   # graphs never overlap: share memory
+            with torch.cuda.graph(graph, pool=self.pool):
+                static_loss = self.result(self._suffix(idx, static_state))
+            rec[1], rec[2], rec[3] = graph, static_state, static_loss
+            self.stats["graph_captures"] += 1
+            self.stats["capture_seconds"] += time.time() - t0
+        _copy_tensors(rec[2], state)
+        rec[1].replay()
+        self.stats["graph_replays"] += 1
+        return rec[3]
+
+
+def _on_gpu(state):
+    found = []
+    _map_tensors(state, lambda t: found.append(t.device.type) or t)
+    return bool(found) and all(d == "cuda" for d in found)

@@ -1,0 +1,74 @@
+"""N>1 path on CPU: two processes over gloo shard the calibration batches, exchange ONE
+all-reduce (the loss table / the per-layer sums) and must reproduce the single-process
+result — sparsity table, loss table and the drifted weights of every replica bit for bit
+(each table entry is written by exactly one rank, so the SUM re-associates nothing)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _run_case(method, k1_form, rank, world, cached):
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    torch.set_num_threads(1)
+    torch.manual_seed(4)
+    model = blip2_toy().eval()
+    for p in model.parameters():
+        p.requires_grad = True
+    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+               for k, v in model.named_parameters()
+               if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+    np.random.seed(42)
+    loss = PrefixCachedLoss(model) if cached else loss_vision_language
+    ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, method, 1, 1e-3, mapping,
+                       kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form=k1_form)
+    sp = ls.return_sparsity()
+    weights = {k: v.detach().clone() for k, v in model.state_dict().items() if k in mapping}
+    sums = {k: float(v.sum()) for k, v in ls.importance_measure.items()}
+    return sp, ls.loss_table, weights, sums, dict(ls.stats)
+
+
+def _worker(rank, world, port, method, k1_form, cached, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = _run_case(method, k1_form, rank, world, cached)
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method,k1_form,cached", [
+    ("MEZO-GradOnly_sum", "units", False), ("MEZO-GradOnly_sum", "triple", False),
+    ("MEZO-GradMagAbs_sum", "units", True), ("GradMagAbs_sum", "units", False)])
+def test_two_ranks_reproduce_single_process(tmp_path, method, k1_form, cached):
+    single = _run_case(method, k1_form, 0, 1, cached)
+    port = 29500 + (os.getpid() + hash((method, k1_form))) % 2000
+    mp.spawn(_worker, args=(2, port, method, k1_form, cached, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        sp, table, weights, sums, stats = torch.load(tmp_path / f"rank{r}.pt", weights_only=False)
+        assert stats["world_size"] == 2
+        if method.startswith("MEZO"):
+            assert stats["forwards"] * 2 == single[4]["forwards"]      # half the forwards per rank
+            assert np.array_equal(table, single[1])                    # exact: x + 0 == x
+            assert sp == single[0]
+            for k in weights:                                          # every replica carries the
+                assert torch.equal(weights[k], single[2][k]), k        # full drift chain
+        else:
+            for k, v in sums.items():                                  # double sums re-associate
+                assert abs(v - single[3][k]) <= 1e-6 * abs(v)
+            assert sp == single[0]

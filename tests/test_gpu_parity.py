@@ -427,6 +427,41 @@ def test_stage1_philox_mode_hip_equals_oracle(kern, method):
         assert torch.equal(v, out["oracle"][2][k]), k
 
 
+@pytest.mark.parametrize("fp32", [True, False])
+def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
+    """Full forward == suffix-only re-forward == suffix replayed from a HIP graph: identical
+    loss tables, sparsity tables and drifted weights (bit for bit, same GPU kernels)."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    res = []
+    for mode in ("full", "suffix", "graph"):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=fp32).eval().to("cuda")
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        loss = {"full": loss_vision_language,
+                "suffix": PrefixCachedLoss(model),
+                "graph": PrefixCachedLoss(model, use_graphs=True)}[mode]
+        np.random.seed(3)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=kern, z_source="philox")
+        sp = ls.return_sparsity()
+        res.append((ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
+        if mode == "graph":
+            assert loss.stats["graph_replays"] > 100 and loss.stats["graph_captures"] >= 4
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0])
+        assert res[0][1] == other[1]
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
