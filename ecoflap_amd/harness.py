@@ -1,0 +1,143 @@
+"""Pruning harness — the build's counterpart of the reference's `evaluate_{blip,t5,eva_clip}.py`
+for this path only (SURVEY.md §8 a-H): CLI flags with the reference's names and defaults
+(LAVIS/evaluate_blip.py:37-284), the config dict handed to `load_pruner`
+(LAVIS/evaluate_blip.py:399-418), and the three output files
+(`pruned_checkpoint/{job_id}.pth`, `sparsity_dict/{job_id}.yaml`,
+`training_statistics/{job_id}.yaml`, LAVIS/evaluate_blip.py:438-472).
+
+Datasets, tasks, runners and checkpoints are out of scope: the model is a shape-compatible
+random-init module and the calibration loader is synthetic (`--shape`, `--toy`).
+
+    python -m ecoflap_amd.harness --shape blip2 --pruning_method blipt5_wanda_pruner \
+        --score_method MEZO-GradOnly_sum --sparsity_ratio_granularity block \
+        --max_sparsity_per_layer 0.6 --prunining_dataset_batch_size 8 \
+        --t5_prune_spec 24-0.5-1.0-1.0 --vit_prune_spec 39-0.5-1.0-1.0 --save_pruned_model \
+        --job_id demo
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="ECoFLaP pruning on MI355X (hot path only)")
+    p.add_argument("--shape", default="blip2", choices=["blip2", "t5", "vit"],
+                   help="blip2: EVA-ViT-g + Q-Former + FlanT5-XL; t5: FlanT5-XL; vit: ViT-B/16 CLIP shape")
+    p.add_argument("--toy", action="store_true", help="CPU-sized shapes of the same families")
+    p.add_argument("--device", default="cuda")
+    # the reference's flags (names, types, defaults)
+    p.add_argument("--pruning_method", type=str, default=None)
+    p.add_argument("--save_pruned_model", action="store_true")
+    p.add_argument("--job_id", type=str, default="job")
+    p.add_argument("--t5_prune_spec", type=str, default=None)
+    p.add_argument("--vit_prune_spec", type=str, default=None)
+    p.add_argument("--num_data", type=int, default=128)
+    p.add_argument("--prunining_dataset_batch_size", type=int, default=1)
+    p.add_argument("--is_global", action="store_true")
+    p.add_argument("--sparsity_ratio_granularity", type=str, default=None)
+    p.add_argument("--max_sparsity_per_layer", type=float, default=0.8)
+    p.add_argument("--score_method", type=str, default="obd_avg")
+    p.add_argument("--num_data_first_stage", type=int, default=32)
+    p.add_argument("--num_noise", default=1, type=int)
+    p.add_argument("--noise_eps", default=1e-3, type=float)
+    p.add_argument("--sparsity_dict", type=str, default=None)
+    p.add_argument("--prune_per_model", action="store_true")
+    p.add_argument("--iteration", type=int, default=1)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--out_dir", type=str, default=".")
+    return p
+
+
+def build_model_and_loader(args, device):
+    from .shapes import synthetic as S
+    bs = args.prunining_dataset_batch_size
+    if args.shape == "blip2":
+        from .shapes.blip2_t5 import blip2_flant5xl, blip2_toy
+        with torch.device(device):
+            model = blip2_toy(fp32=(device.type == "cpu")) if args.toy else blip2_flant5xl()
+        loader = S.image_text_batches(args.num_data, bs, img_size=28 if args.toy else 224,
+                                      vocab=96 if args.toy else 32128, seed=args.seed,
+                                      device=device)
+    elif args.shape == "t5":
+        from .shapes.t5 import T5, t5_config
+        cfg = (t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, vocab_size=96)
+               if args.toy else t5_config())
+        with torch.device(device):
+            model = T5(cfg, dtype=None if device.type == "cpu" else torch.bfloat16,
+                       init_std=0.2 if args.toy else 0.02)
+        loader = S.text_batches(args.num_data, bs, vocab=96 if args.toy else 32128, seed=args.seed,
+                                device=device)
+    else:
+        from .shapes.eva_clip import vit_b16_clip, vit_toy
+        with torch.device(device):
+            model = vit_toy() if args.toy else vit_b16_clip()
+        loader = S.image_label_batches(args.num_data, bs, img_size=32 if args.toy else 224,
+                                       num_classes=5 if args.toy else 1000, seed=args.seed,
+                                       device=device)
+    return model.eval(), loader
+
+
+def config_dict(args):
+    """Keys and values of LAVIS/evaluate_blip.py:399-418 (t5/eva_clip variants use prune_spec)."""
+    cfg = {
+        "importance_scores_cache": None,
+        "keep_indices_cache": None,
+        "is_strct_pruning": False,
+        "is_global": args.is_global,
+        "num_samples": args.num_data,
+        "sparsity_ratio_granularity": args.sparsity_ratio_granularity,
+        "max_sparsity_per_layer": args.max_sparsity_per_layer,
+        "score_method": args.score_method,
+        "num_data_first_stage": args.num_data_first_stage,
+        "num_noise": args.num_noise,
+        "noise_eps": args.noise_eps,
+        "sparsity_dict": args.sparsity_dict,
+        "prune_per_model": args.prune_per_model,
+        "iteration": args.iteration,
+    }
+    if args.pruning_method == "blipt5_wanda_pruner":
+        cfg.update(t5_prune_spec=args.t5_prune_spec, vit_prune_spec=args.vit_prune_spec,
+                   t5_pruning_method="none", vit_pruning_method="none")
+    elif args.pruning_method == "t5_wanda_pruner":
+        cfg.update(prune_spec=args.t5_prune_spec)
+    else:
+        cfg.update(prune_spec=args.vit_prune_spec)
+    return cfg
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from . import load_pruner
+    device = torch.device(args.device)
+    # setup_seeds(seed + rank), LAVIS/evaluate_blip.py:287-295
+    import random
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    model, loader = build_model_and_loader(args, device)
+    orig_total = sum((p != 0).float().sum() for p in model.parameters())
+    pruner = load_pruner(args.pruning_method, model, loader, cfg=config_dict(args))
+    start = time.time()
+    model, sparsity_dict = pruner.prune()
+    remaining = sum((p != 0).float().sum() for p in model.parameters())
+    print(float(remaining / orig_total * 100))
+    if args.save_pruned_model:
+        for folder in ("pruned_checkpoint", "sparsity_dict", "training_statistics"):
+            os.makedirs(os.path.join(args.out_dir, folder), exist_ok=True)
+        torch.save(model.state_dict(),
+                   os.path.join(args.out_dir, "pruned_checkpoint", args.job_id + ".pth"))
+        if sparsity_dict is not None and isinstance(sparsity_dict, dict):
+            with open(os.path.join(args.out_dir, "sparsity_dict", args.job_id + ".yaml"), "w") as f:
+                yaml.dump(sparsity_dict, f)
+        peak = (torch.cuda.max_memory_allocated() / 1024 ** 2) / 1000 if device.type == "cuda" else 0.0
+        with open(os.path.join(args.out_dir, "training_statistics", args.job_id + ".yaml"), "w") as f:
+            yaml.dump({"memory": peak, "time": time.time() - start}, f)
+    return model, sparsity_dict
+
+
+if __name__ == "__main__":
+    main()
