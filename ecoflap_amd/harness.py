@@ -136,6 +136,7 @@ def main(argv=None):
         peak = (torch.cuda.max_memory_allocated() / 1024 ** 2) / 1000 if device.type == "cuda" else 0.0
         with open(os.path.join(args.out_dir, "training_statistics", args.job_id + ".yaml"), "w") as f:
             yaml.dump({"memory": peak, "time": time.time() - start}, f)
+    main.last_stage_stats = dict(getattr(pruner, "stage_stats", {}))
     return model, sparsity_dict
 
 

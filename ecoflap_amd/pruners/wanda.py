@@ -119,6 +119,18 @@ class _BlockwiseWanda:
 
     def run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
             cache_keys, autocast, take_first, mode):
+        import time
+        t0 = time.time()
+        try:
+            return self._run(model, dataloader, module_to_process, n_samples, sparsity_ratio,
+                             forward_fn, cache_keys, autocast, take_first, mode)
+        finally:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.owner.stage_stats.setdefault("stage2", {})[module_to_process] = time.time() - t0
+
+    def _run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
+             cache_keys, autocast, take_first, mode):
         with torch.no_grad():
             blocks = get_module_recursive(model, module_to_process)
             inps, outs, caches = self.capture(model, dataloader, blocks, forward_fn, cache_keys,
@@ -175,8 +187,10 @@ class _StageOneMixin:
                 and str(self.score_method).startswith("MEZO") and mapping):
             # same losses, bit for bit, from the owning block onwards only
             from .prefix_cache import PrefixCachedLoss
+            on_gpu = next(iter(self.model.parameters())).device.type == "cuda"
             loss_func = PrefixCachedLoss(
-                self.model, kind="vision" if loss_func is loss_vision else "vision_language")
+                self.model, kind="vision" if loss_func is loss_vision else "vision_language",
+                use_graphs=bool(getattr(self, "use_graphs", True)) and on_gpu)
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

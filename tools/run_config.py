@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Run one BASELINE.json config end to end through the harness on the GPU and print a JSON
+summary (wall time per stage, table statistics, pruned fraction).  Parity-test cases at full
+size, not bench lines.
+
+    python3 tools/run_config.py 2     # FlanT5-XL first-order GradMagAbs_sum, 128 seqs bs 1
+    python3 tools/run_config.py 3     # BLIP-2 zeroth-order MEZO-GradOnly_sum, 128 pairs bs 8
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecoflap_amd import harness  # noqa: E402
+
+CONFIGS = {
+    "1": ["--shape", "vit", "--pruning_method", "vit_wanda_pruner", "--score_method", "MEZO-GradOnly_sum",
+          "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.6",
+          "--prunining_dataset_batch_size", "8", "--num_data", "8", "--num_data_first_stage", "8",
+          "--vit_prune_spec", "12-0.5-1.0-1.0"],
+    "2": ["--shape", "t5", "--pruning_method", "t5_wanda_pruner", "--score_method", "GradMagAbs_sum",
+          "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.6",
+          "--prunining_dataset_batch_size", "1", "--num_data", "128", "--num_data_first_stage", "128",
+          "--t5_prune_spec", "24-0.5-1.0-1.0"],
+    "3": ["--shape", "blip2", "--pruning_method", "blipt5_wanda_pruner", "--score_method", "MEZO-GradOnly_sum",
+          "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.6",
+          "--prunining_dataset_batch_size", "8", "--num_data", "128", "--num_data_first_stage", "128",
+          "--t5_prune_spec", "24-0.5-1.0-1.0", "--vit_prune_spec", "39-0.5-1.0-1.0"],
+}
+
+
+def main():
+    which = sys.argv[1]
+    extra = sys.argv[2:]
+    t0 = time.time()
+    model, table = harness.main(CONFIGS[which] + extra)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    blocks = {k: v for k, v in model.state_dict().items() if v.dim() == 2 and ".block" in k
+              and "relative_attention_bias" not in k}
+    zeros = sum(int((v == 0).sum()) for v in blocks.values())
+    total = sum(v.numel() for v in blocks.values())
+    vals = sorted(set(round(v, 6) for v in table.values())) if isinstance(table, dict) else []
+    print(json.dumps({
+        "config": which, "wall_seconds": wall, "prunable_matrices": len(blocks),
+        "prunable_elements": total, "pruned_fraction": zeros / total,
+        "table_entries": len(table) if isinstance(table, dict) else 0,
+        "distinct_sparsities": len(vals), "min_sparsity": vals[0] if vals else None,
+        "max_sparsity": vals[-1] if vals else None,
+        "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
+        "stage_stats": getattr(harness.main, "last_stage_stats", None)}, default=str))
+
+
+if __name__ == "__main__":
+    main()
