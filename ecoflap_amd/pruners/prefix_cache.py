@@ -30,7 +30,7 @@ def _vision_result(state):
     logits = state["predictions"] / 100
     targets = state["targets"]
     probs = torch.nn.functional.softmax(logits, -1)
-    idx = torch.arange(len(targets)).to(targets.device)
+    idx = torch.arange(len(targets), device=targets.device)   # (no H2D copy: graph-capturable)
     return -probs[idx, targets].log().mean()
 
 
