@@ -6,8 +6,8 @@ SURVEY.md §8d).
 A "step" = one prunable weight matrix taken through the whole of the reference's inner
 loops (layer_single_base_pruner.py:512-549): for each of its calibration batches one
 +eps/-2eps/+eps perturbation triple (K1), two full forward losses, and its row of the loss
-table.  The K timed steps are K matrices strided evenly over the model's 588 (ViT, T5
-encoder, T5 decoder alike); the closing all-reduce of the loss table, the single host sync,
+table.  The K timed steps are K matrices — runs of 4 consecutive ones at evenly strided
+positions over the model's 588 (ViT, T5 encoder, T5 decoder alike); the closing all-reduce of the loss table, the single host sync,
 the score reduction and the allocator are inside the timed region.
 
     python bench.py --gpus 1 --steps 12 --warmup 2
@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--num-data", type=int, default=128, help="calibration pairs per rank")
     ap.add_argument("--batch-size", type=int, default=8)
@@ -56,8 +56,20 @@ def parse():
     return ap.parse_args()
 
 
-def strided(n_total, k, offset=0):
-    return [min(n_total - 1, int((i + 0.5) * n_total / k) + offset) for i in range(k)]
+def strided(n_total, k, offset=0, run=4):
+    """k layer indices as runs of `run` consecutive matrices at evenly strided positions.
+    A real pass visits the 588 matrices in order, ~6.6 per block, so per-block costs
+    (prefix-cache advance, graph capture) amortise over consecutive matrices; runs of 4
+    (one ViT block) keep that structure in a k-matrix sample."""
+    n_runs = max(1, (k + run - 1) // run)
+    out = []
+    for i in range(n_runs):
+        start = int((i + 0.5) * n_total / n_runs) + offset
+        start -= start % run
+        for j in range(run):
+            if len(out) < k:
+                out.append(min(n_total - 1, start + j))
+    return out
 
 
 class TimedKernels:

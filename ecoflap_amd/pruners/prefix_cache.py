@@ -69,6 +69,7 @@ class PrefixCachedLoss:
         self.requires_static_weights = self.use_graphs
         self.graphs = {}            # entry stage -> [calls_seen, graph, static_state, static_loss]
         self.pool = None
+        self._warmed = False
         self.plan = model.stage_plan()
         self.result = _vision_result if kind == "vision" else _vision_language_result
         self.batch_len_fn = batch_len_fn
@@ -130,9 +131,12 @@ class PrefixCachedLoss:
         import time
         rec = self.graphs.get(idx)
         if rec is None:
-            # first visit: eager (also the warm-up torch asks for before a capture)
-            self.graphs[idx] = [1, None, None, None]
-            return self.result(self._suffix(idx, state))
+            rec = self.graphs[idx] = [1, None, None, None]
+            if not self._warmed:
+                # the very first suffix runs eagerly: the warm-up torch asks for before any
+                # capture (library handles, workspaces); later entry stages capture at once
+                self._warmed = True
+                return self.result(self._suffix(idx, state))
         if rec[1] is None:
             t0 = time.time()
             static_state = _map_tensors(state, lambda t: t.clone())

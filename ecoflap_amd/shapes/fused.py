@@ -1,0 +1,62 @@
+"""Fused forward ops for the shape modules (include/ecoflap_shape_ops.h): used on the GPU,
+for 16-bit tensors, when autograd is off (the zeroth-order loop); everything else takes the
+plain torch op chain — this is model plumbing, not the pruner's compute path."""
+import ctypes
+
+import torch
+
+from .. import hip as _hip
+
+_lib = None
+
+
+def _get():
+    global _lib
+    if _lib is None:
+        lib = _hip.load_library()
+        vp, i64, f32, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+        lib.ecoflap_t5_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, ci, vp]
+        lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
+        _lib = lib
+    return _lib
+
+
+def _usable(*tensors):
+    if torch.is_grad_enabled():
+        return False
+    t0 = tensors[0]
+    if t0.device.type != "cuda" or t0.dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return all(t.dtype == t0.dtype and t.device == t0.device for t in tensors)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def t5_rmsnorm(x, weight, eps):
+    """-> y or None (None: caller runs the torch op chain)."""
+    if not _usable(x, weight) or x.shape[-1] % 8 != 0:
+        return None
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(xc)
+    d = xc.shape[-1]
+    rc = _get().ecoflap_t5_rmsnorm(xc.data_ptr(), weight.data_ptr(), y.data_ptr(),
+                                   xc.numel() // d, d, float(eps), _hip.DTYPE_CODE[xc.dtype],
+                                   _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_t5_rmsnorm failed ({rc})")
+    return y
+
+
+def gelu_mul(a, b):
+    if not _usable(a, b) or a.numel() % 8 != 0 or a.shape != b.shape:
+        return None
+    ac = a if a.is_contiguous() else a.contiguous()
+    bc = b if b.is_contiguous() else b.contiguous()
+    y = torch.empty_like(ac)
+    rc = _get().ecoflap_gelu_mul(ac.data_ptr(), bc.data_ptr(), y.data_ptr(), ac.numel(),
+                                 _hip.DTYPE_CODE[ac.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_gelu_mul failed ({rc})")
+    return y

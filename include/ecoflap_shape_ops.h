@@ -1,0 +1,29 @@
+/*
+ * ecoflap_shape_ops.h — fused forward ops of the synthetic shape modules (plumbing).
+ *
+ * NOT part of the pruner drop-in boundary (that is ecoflap_hip.h).  The scoring loop is
+ * forward-bound, and a third of a BLIP-2-shaped forward's GPU time was eight-kernel
+ * RMSNorm chains and other element-wise glue; these entry points fuse them for the
+ * build's own shape modules (ecoflap_amd/shapes/).  Same conventions as ecoflap_hip.h.
+ */
+#ifndef ECOFLAP_SHAPE_OPS_H
+#define ECOFLAP_SHAPE_OPS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* T5LayerNorm (LAVIS/lavis/models/blip2_models/modeling_t5.py:239-262):
+ *   var = mean(float(x)^2); h = bf16/f16(x * rsqrt(var + eps)); y = w * h
+ * x, y: [rows, d] of `dtype` (F16/BF16), w: [d] of `dtype`; d % 8 == 0. */
+int ecoflap_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t d,
+                       float eps, int dtype, void* stream);
+
+/* gated GELU of T5DenseGatedActDense (modeling_t5.py:296-330): y = gelu(a) * b
+ * (erf GELU in fp32, rounded to dtype, then the product rounded to dtype). n % 8 == 0. */
+int ecoflap_gelu_mul(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

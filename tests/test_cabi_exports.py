@@ -24,6 +24,10 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(hip.EXPORTS) == names
+    shape_ops = re.findall(r"\b(ecoflap_[a-z0-9_]+)\s*\(", re.sub(
+        r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ecoflap_shape_ops.h")).read(), flags=re.S))
+    for n in shape_ops:          # plumbing ops of the shape modules live in the same library
+        assert hasattr(lib, n), n
     lib.ecoflap_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.ecoflap_version()
 

@@ -462,6 +462,31 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
             assert torch.equal(res[0][2][k], other[2][k]), k
 
 
+def test_fused_shape_ops_match_torch_chain():
+    """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
+    from ecoflap_amd.shapes import fused
+    from ecoflap_amd.shapes.t5 import T5LayerNorm
+    torch.manual_seed(0)
+    for dt in (torch.bfloat16, torch.float16):
+        x = (torch.randn(3, 48, 2048, device="cuda") * 1.5).to(dt)
+        ln = T5LayerNorm(2048).to("cuda")
+        ln.weight.data = (1 + 0.1 * torch.randn(2048, device="cuda")).to(dt)
+        with torch.no_grad():
+            got = ln(x)
+        with torch.enable_grad():
+            want = ln(x).detach()
+        err = (got.float() - want.float()).abs().max().item()
+        assert err <= 2 * torch.finfo(dt).eps * want.float().abs().max().item(), err
+        a = (torch.randn(384, 5120, device="cuda")).to(dt)
+        b = (torch.randn(384, 5120, device="cuda")).to(dt)
+        with torch.no_grad():
+            got = fused.gelu_mul(a, b)
+        want = torch.nn.functional.gelu(a) * b
+        assert got is not None
+        assert (got.float() - want.float()).abs().max().item() <= \
+            torch.finfo(dt).eps * want.float().abs().max().item()
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
