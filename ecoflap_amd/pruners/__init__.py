@@ -5,3 +5,6 @@ from .wanda import (  # noqa: F401
     get_module_recursive,
 )
 from .losses import loss_language, loss_vision, loss_vision_language  # noqa: F401
+from .upop import (  # noqa: F401,E402
+    BLIPBertLayerWandaPruner, apply_masks_to_grads, pruning_masks, task_forward,
+)

@@ -1,0 +1,196 @@
+"""UPop-side pruners of the reference (BASELINE configs[4]):
+  BertLayerWandaPruner        UPop/pruners/wanda_pruner.py:81-348 (rows-mode Wanda on BERT layers)
+  BLIPBertLayerWandaPruner    UPop/pruners/wanda_pruner.py:600-834 (ViT blocks + BERT encoder(s))
+and the masked fine-tune step of UPop/ecoflap_compression_vqa.py:124-129 (K8).
+
+`stage1_mode`:
+  "compat"   (default) what the shipped code does: `get_sparsity` passes `self.task`
+             positionally into LayerSparsity (UPop/pruners/wanda_pruner.py:707-717), the group
+             mapping never arrives, `return_sparsity()` takes its early-out (:327-331) and every
+             layer gets the uniform ratio — ECoFLaP on UPop == Wanda at `p`.
+  "intended" the evident intent: task loss -> zeroth/first-order scores -> allocator, through
+             the same LayerSparsity engine the LAVIS pruners use.
+"""
+import torch
+
+from ..registry import registry
+from .base_pruner import LayerWiseBasePruner, print_time
+from .layer_sparsity import LayerSparsity, _UniformSparsity
+from .wanda import _BlockwiseWanda
+
+BERT_LAYER_KWARGS = ["attention_mask", "head_mask", "encoder_hidden_states",
+                     "encoder_attention_mask", "output_attentions", "mode", "labels"]
+
+
+def task_forward(task, model, batch, device="cuda"):
+    """`forward_to_cache` of the reference (UPop/pruners/wanda_pruner.py:721-748):
+    -> (loss, batch_len) for nlvr / coco / retrieval / vqa batches."""
+    if task == "nlvr":
+        image0, image1, text, targets = batch
+        images = torch.cat([image0, image1], dim=0).to(device)
+        return model(images, text, targets=targets.to(device), train=True), image0.shape[0]
+    if task == "coco":
+        image, caption, _ = batch
+        return model(image.to(device), caption), image.shape[0]
+    if task == "retrieval":
+        image, caption, idx = batch
+        return model.forward_itm(image.to(device), caption, alpha=0.4, idx=idx.to(device)), image.shape[0]
+    if task == "vqa":
+        image, question, answer, weights, n = batch
+        loss = model(image.to(device), question, answer, train=True, n=n, weights=weights.to(device))
+        return loss, image.shape[0]
+    return model(batch), 1
+
+
+class _NoAutocast:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _BertWandaMixin:
+    def _bert_prune(self, model, dataloader, device, model_prefix, module_to_process, n_samples,
+                    sparsity_ratio):
+        cfg = getattr(model, model_prefix).config
+        use_cache, cfg.use_cache = cfg.use_cache, False
+        try:
+            _BlockwiseWanda(self).run(
+                model, dataloader, module_to_process, n_samples, sparsity_ratio,
+                forward_fn=lambda m, b: self.forward_to_cache(m, b, device),
+                cache_keys=BERT_LAYER_KWARGS, autocast=_NoAutocast, take_first=True, mode="rows",
+                optional_keys=True, batch_len=lambda b: b[0].shape[0])
+        finally:
+            cfg.use_cache = use_cache
+        return model
+
+    def _vit_prune(self, model, dataloader, device, model_prefix, module_to_process, n_samples,
+                   sparsity_ratio):
+        return _BlockwiseWanda(self).run(
+            model, dataloader, module_to_process, n_samples, sparsity_ratio,
+            forward_fn=lambda m, b: self.forward_to_cache(m, b, device),
+            cache_keys=["register_hook"], autocast=_NoAutocast, take_first=False, mode="matrix",
+            batch_len=lambda b: b[0].shape[0])
+
+
+@registry.register_pruner("blipbert_wanda_pruner")
+class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
+    pruner_name = "blipbert_wanda_pruner"
+
+    def __init__(self, model, data_loader, bert_prune_spec=None, vit_prune_spec=None,
+                 bert_model_prefix="text_encoder", vit_model_prefix="visual_encoder", task="nlvr",
+                 stage1_mode="compat", **kwargs):
+        kwargs.pop("prune_spec", None)
+        kwargs.pop("model_prefix", None)
+        super().__init__(model=model, data_loader=data_loader, prune_spec=None,
+                         model_prefix="tmp", **kwargs)
+        assert stage1_mode in ("compat", "intended")
+        self.task = task
+        self.stage1_mode = stage1_mode
+        self.bert_prune_spec = bert_prune_spec
+        self.vit_prune_spec = vit_prune_spec
+        self.bert_model_prefix = bert_model_prefix
+        self.vit_model_prefix = vit_model_prefix
+
+    def forward_to_cache(self, model, batch, device="cuda"):
+        return task_forward(self.task, model, batch, device)
+
+    def _mapping(self, granularity):
+        b, v = self.bert_model_prefix, self.vit_model_prefix
+        names = [k for k, p in self.model.named_parameters()
+                 if len(p.shape) == 2 and (".block" in k or ".layer" in k)
+                 and "relative_attention_bias.weight" not in k
+                 and (k.startswith(b + ".") or k.startswith(v + ".") or k.startswith("text_encoder."))]
+
+        def group(name):
+            if granularity == "layer":
+                return name
+            is_b, is_v = name.startswith(b + "."), name.startswith(v + ".")
+            if granularity == "model":
+                return b if name.startswith(b) else (v if name.startswith(v) else "other")
+            if granularity == "block":
+                if is_b:
+                    deep = self.task in ("coco", "vqa")
+                    return ".".join(name.split(".")[:5 if deep else 4])
+                if is_v:
+                    return ".".join(name.split(".")[:3])
+                if name.startswith("text_encoder."):
+                    return ".".join(name.split(".")[:4])
+                return "other"
+            raise NotImplementedError
+
+        return {k: group(k) for k in names}
+
+    def get_sparsity(self, original_sparsity, sparsity_ratio_granularity=None):
+        if sparsity_ratio_granularity is None or self.stage1_mode == "compat":
+            return _UniformSparsity(original_sparsity)          # as shipped
+        device = next(iter(self.model.parameters())).device
+        loss_func = lambda m, batch, cuda_enabled: task_forward(self.task, m, batch, device)  # noqa: E731
+        ls = LayerSparsity(
+            self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
+            self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,
+            self._mapping(sparsity_ratio_granularity), kernels=self.kernels,
+            z_source=self.z_source, process_group=self.process_group,
+            batch_len_fn=lambda b: b[0].shape[0])
+        self.kernels = ls.kernels
+        out = ls.return_sparsity()
+        self.stage_stats["stage1"] = dict(ls.stats)
+        return out
+
+    @print_time
+    def prune(self, importance_scores=None, keep_indices_or_masks=None):
+        print("In: ", self.pruner_name)
+        dtype_record, requires_grad_record, device = self.model_setup_and_record_attributes(self.model)
+        global_sparsity_dict = None
+        if self.sparsity_ratio_granularity is not None:
+            _, vit_keep, _, _ = self.convert_spec_to_list(self.vit_prune_spec)
+            _, bert_keep, _, _ = self.convert_spec_to_list(self.bert_prune_spec)
+            assert vit_keep == bert_keep
+            global_sparsity_dict = self.get_sparsity(
+                1 - vit_keep, sparsity_ratio_granularity=self.sparsity_ratio_granularity)
+
+        def table_for(spec):
+            if global_sparsity_dict is not None:
+                return global_sparsity_dict
+            _, keep, _, _ = self.convert_spec_to_list(spec)
+            return self.get_sparsity(1 - keep, sparsity_ratio_granularity=None)
+
+        if self.vit_prune_spec is not None:
+            self.model = self._vit_prune(
+                self.model, self.data_loader, device, model_prefix=self.vit_model_prefix,
+                module_to_process=f"{self.vit_model_prefix}.blocks", n_samples=self.num_samples,
+                sparsity_ratio=table_for(self.vit_prune_spec))
+        if self.bert_prune_spec is not None and \
+                getattr(self.model, self.bert_model_prefix, None) is not None:
+            table = table_for(self.bert_prune_spec)
+            if self.task == "vqa":                       # the question encoder first (:801-807)
+                self.model = self._bert_prune(
+                    self.model, self.data_loader, device, model_prefix="text_encoder",
+                    module_to_process="text_encoder.encoder.layer", n_samples=self.num_samples,
+                    sparsity_ratio=table)
+            deep = self.task in ("coco", "vqa")
+            module = f"{self.bert_model_prefix}.bert.encoder.layer" if deep \
+                else f"{self.bert_model_prefix}.encoder.layer"
+            self.model = self._bert_prune(
+                self.model, self.data_loader, device, model_prefix=self.bert_model_prefix,
+                module_to_process=module, n_samples=self.num_samples, sparsity_ratio=table)
+        self.model_reset(self.model, dtype_record, requires_grad_record, device)
+        table = global_sparsity_dict if isinstance(global_sparsity_dict, dict) else None
+        return self.model, table
+
+
+def pruning_masks(model):
+    """uint8 keep-masks (1 = non-zero) of EVERY parameter, as the reference's fine-tune loop
+    builds them: `masks[n] = (p != 0).float()` (UPop/ecoflap_compression_vqa.py:312-315)."""
+    return {k: (p.data != 0).to(torch.uint8).contiguous() for k, p in model.named_parameters()}
+
+
+def apply_masks_to_grads(model, masks, kernels=None):
+    """`params.grad *= mask` for every masked parameter (UPop/ecoflap_compression_vqa.py:124-129),
+    one K8 launch each, in place on the gradient's storage."""
+    from .. import hip as _hip
+    kernels = kernels if kernels is not None else _hip.HipKernels()
+    for name, p in model.named_parameters():
+        if name in masks and p.grad is not None:
+            kernels.mask_mul(p.grad.data, masks[name])

@@ -82,7 +82,8 @@ class _BlockwiseWanda:
         self.kernels = owner.kernels if owner.kernels is not None else _hip.HipKernels()
         owner.kernels = self.kernels
 
-    def capture(self, model, dataloader, blocks, forward_fn, cache_keys, n_samples):
+    def capture(self, model, dataloader, blocks, forward_fn, cache_keys, n_samples,
+                optional_keys=False, batch_len=None):
         """Record the inputs of block 0 for the first n_samples calibration samples
         (the reference swaps block 0 for a `Catcher`, :184-209 / :469-493; a pre-hook
         leaves the ModuleList untouched)."""
@@ -97,6 +98,8 @@ class _BlockwiseWanda:
                     cache[key] = kwargs[key]
                 elif len(cache_keys) == 1 and len(args) > 1:
                     cache[key] = args[1]          # ViT: blk(x, rel_pos_bias) positional
+                elif optional_keys:
+                    continue                      # UPop's BERT Catcher keeps the keys present
                 else:
                     raise KeyError(key)           # as the reference's Catcher would
             caches.append(cache)
@@ -108,7 +111,11 @@ class _BlockwiseWanda:
             for batch in dataloader:
                 if total >= n_samples:
                     break
-                total += _default_batch_len(batch) if "image" not in batch else batch["image"].shape[0]
+                if batch_len is not None:
+                    total += batch_len(batch)
+                else:
+                    total += (_default_batch_len(batch) if "image" not in batch
+                              else batch["image"].shape[0])
                 try:
                     forward_fn(model, batch)
                 except _StopForward:
@@ -118,23 +125,24 @@ class _BlockwiseWanda:
         return inps, [None] * len(inps), caches
 
     def run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
-            cache_keys, autocast, take_first, mode):
+            cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None):
         import time
         t0 = time.time()
         try:
             return self._run(model, dataloader, module_to_process, n_samples, sparsity_ratio,
-                             forward_fn, cache_keys, autocast, take_first, mode)
+                             forward_fn, cache_keys, autocast, take_first, mode, optional_keys,
+                             batch_len)
         finally:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             self.owner.stage_stats.setdefault("stage2", {})[module_to_process] = time.time() - t0
 
     def _run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
-             cache_keys, autocast, take_first, mode):
+             cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None):
         with torch.no_grad():
             blocks = get_module_recursive(model, module_to_process)
             inps, outs, caches = self.capture(model, dataloader, blocks, forward_fn, cache_keys,
-                                              n_samples)
+                                              n_samples, optional_keys, batch_len)
         n_batches = min(n_samples, len(inps))     # (:226/:505: compared against the batch count)
 
         def call(block, j):
@@ -156,7 +164,7 @@ class _BlockwiseWanda:
             for h in handles:
                 h.remove()
             for name in subset:
-                assert wrapped[name].nsamples == len(inps) * inps[0].shape[0]
+                assert wrapped[name].nsamples == sum(x.shape[0] for x in inps)
                 weight = subset[name].weight.data
                 ratio = sparsity_ratio[f"{module_to_process}.{i}.{name}.weight"]
                 if mode == "rows":      # per output row, k smallest by stable order (:272-279)

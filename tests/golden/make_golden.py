@@ -371,6 +371,31 @@ def golden_end_to_end(registry):
     save("g7_end_to_end.npz", **out)
 
 
+# --------------------------------------------------------------------------- G9: UPop BLIP-BERT
+def golden_upop():
+    """The reference's UPop pruner AS SHIPPED on the toy BLIP-VQA shape: stage 1 degenerates to
+    the uniform ratio, stage 2 = ViT matrix-mode + BERT rows-mode Wanda."""
+    sys.path.insert(0, os.path.join(REF, "UPop"))
+    from pruners.wanda_pruner import BLIPBertLayerWandaPruner  # type: ignore
+    from ecoflap_amd.shapes.blip_bert import blip_vqa_toy, vqa_batches
+    out = {}
+    torch.manual_seed(31)
+    model = blip_vqa_toy().eval()
+    batches = vqa_batches(8, 2, img_size=32, vocab=64, seed=9)
+    for k, v in model.state_dict().items():
+        out[f"vqa_init::{k}"] = bits(v)
+    np.random.seed(42)
+    pruner = BLIPBertLayerWandaPruner(
+        model, batches, bert_prune_spec="0-0.5-1.0-1.0", vit_prune_spec="0-0.5-1.0-1.0",
+        num_samples=8, bert_model_prefix="text_decoder", vit_model_prefix="visual_encoder",
+        sparsity_ratio_granularity="block", max_sparsity_per_layer=0.6,
+        score_method="MEZO-GradOnly_sum", num_data_first_stage=8, task="vqa")
+    model2, _ = pruner.prune()
+    for k, v in model2.state_dict().items():
+        out[f"vqa_final::{k}"] = bits(v)
+    save("g9_upop_vqa.npz", **out)
+
+
 def golden_names():
     d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
                    map_location="cpu", weights_only=False)
@@ -383,7 +408,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # fixed reduction order for the committed vectors
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
-    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names"]
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop"]
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:
@@ -396,3 +421,5 @@ if __name__ == "__main__":
         golden_end_to_end(registry)
     if "names" in only:
         golden_names()
+    if "upop" in only:
+        golden_upop()

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Time the Wanda kernels (K6 column statistic, K7 rows / matrix selection) on BLIP-2's
+shapes with cold inputs (rotating buffer sets > 256 MiB) and print GB/s against the
+algorithmic bytes of DESIGN.md §4.  Also the workload for rocprofv3 summaries."""
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecoflap_amd import hip  # noqa: E402
+
+
+def timed(fn, n_sets, reps=3):
+    blocker = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    for i in range(n_sets):
+        fn(i)
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        for _ in range(4):
+            blocker @ blocker
+        evs = []
+        for i in range(n_sets):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); fn(i); e.record(); evs.append((s, e))
+        torch.cuda.synchronize()
+        out += [s.elapsed_time(e) * 1e3 for s, e in evs]
+    return statistics.median(out), min(out)
+
+
+def main():
+    kern = hip.HipKernels()
+    res = []
+    # K6: hooked Linear inputs of one calibration batch (bs 8)
+    for name, tokens, cols, dt in [("vit qkv/fc1 input", 8 * 257, 1408, torch.float32),
+                                   ("vit fc2 input", 8 * 257, 6144, torch.float16),
+                                   ("t5 enc q/k/v/wi input", 8 * 48, 2048, torch.bfloat16),
+                                   ("t5 enc wo input", 8 * 48, 5120, torch.bfloat16)]:
+        nbytes = tokens * cols * torch.empty(0, dtype=dt).element_size()
+        sets = max(2, int(6e8 // nbytes))
+        xs = [torch.randn(tokens, cols, device="cuda").to(dt) for _ in range(sets)]
+        s = torch.zeros(cols, device="cuda")
+        med, mn = timed(lambda i: kern.colsqnorm_accum(s, xs[i], 8 * i, 8), sets)
+        res.append(("K6 colsqnorm", name, nbytes, med, mn))
+    # K7 rows: T5 matrices (bf16); matrix mode: ViT matrices (fp16)
+    for name, rows, cols, dt, mode in [("t5 wo 2048x5120", 2048, 5120, torch.bfloat16, "rows"),
+                                       ("t5 wi 5120x2048", 5120, 2048, torch.bfloat16, "rows"),
+                                       ("t5 q 2048x2048", 2048, 2048, torch.bfloat16, "rows"),
+                                       ("vit fc1 6144x1408", 6144, 1408, torch.float16, "matrix"),
+                                       ("vit qkv 4224x1408", 4224, 1408, torch.float16, "matrix"),
+                                       ("vit proj 1408x1408", 1408, 1408, torch.float16, "matrix")]:
+        es = torch.empty(0, dtype=dt).element_size()
+        nbytes = 2 * es * rows * cols + 4 * cols
+        sets = max(2, int(6e8 // (rows * cols * es)))
+        ws = [(torch.randn(rows, cols, device="cuda") * 0.02).to(dt) for _ in range(sets)]
+        sr = torch.rand(cols, device="cuda") + 0.05
+        if mode == "rows":
+            fn = lambda i: kern.wanda_prune_rows(ws[i], sr, cols // 2)          # noqa: E731
+        else:
+            fn = lambda i: kern.wanda_prune_matrix(ws[i], sr, rows * cols // 2)  # noqa: E731
+        med, mn = timed(fn, sets, reps=1)   # pruning is idempotent but rewrites zeros: 1 rep on fresh data
+        res.append((f"K7 {mode}", name, nbytes, med, mn))
+    for k, name, nbytes, med, mn in res:
+        print(f"{k:14s} {name:24s} {nbytes/1e6:8.1f} MB  median {med:8.1f} us  min {mn:8.1f} us  "
+              f"{nbytes/med/1e3:7.0f} GB/s ({nbytes/med/1e3/80:5.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()
