@@ -462,6 +462,37 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
             assert torch.equal(res[0][2][k], other[2][k]), k
 
 
+@pytest.mark.parametrize("mode", ["compat", "intended"])
+def test_upop_vqa_hip_equals_oracle(kern, golden_dir, mode):
+    """BASELINE configs[4] shape (toy size): ViT matrix-mode + BERT rows-mode Wanda and, in
+    intended mode, the task-loss zeroth-order stage 1 — HIP == oracle on the same GPU forward;
+    then the K8 masked fine-tune step keeps pruned weights at zero."""
+    from oracle_backend import OracleKernels
+    from test_upop_parity import _model, _pruner
+    from ecoflap_amd.pruners import apply_masks_to_grads, pruning_masks
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model, batches = _model(golden_dir)
+        model.to("cuda")
+        np.random.seed(42)
+        model, table = _pruner(model, batches, mode, backend).prune()
+        res[name] = (table, {k: v.detach().cpu() for k, v in model.state_dict().items()}, model)
+    assert res["hip"][0] == res["oracle"][0]
+    for k, v in res["hip"][1].items():
+        assert torch.equal(v, res["oracle"][1][k]), k
+    model = res["hip"][2]
+    _, _, batches = _model(golden_dir)
+    masks = pruning_masks(model)
+    model.train()
+    image, q, a, w, n = batches[0]
+    loss = model(image, q, a, n=n, weights=w)
+    loss.backward()
+    want = {k: p.grad * masks[k].to(p.grad.dtype) for k, p in model.named_parameters()}
+    apply_masks_to_grads(model, masks, kernels=kern)
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, want[k]), k
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused
