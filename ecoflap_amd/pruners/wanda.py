@@ -82,6 +82,36 @@ class _BlockwiseWanda:
         self.kernels = owner.kernels if owner.kernels is not None else _hip.HipKernels()
         owner.kernels = self.kernels
 
+    def _rank_world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            g = getattr(self.owner, "process_group", None)
+            return dist.get_rank(g), dist.get_world_size(g)
+        return 0, 1
+
+    def _merge_statistics(self, wrapped):
+        """Data-parallel stage 2: ONE all-reduce per block of the concatenated per-channel
+        sums (running mean x local sample count) and the sample counts; every rank then holds
+        bit-identical statistics and computes identical masks."""
+        rank, world = self._rank_world()
+        if world == 1:
+            return
+        import torch.distributed as dist
+        names = list(wrapped)
+        dev = wrapped[names[0]].scaler_row.device
+        parts = [wrapped[n].scaler_row.double() * wrapped[n].nsamples for n in names]
+        counts = torch.tensor([float(wrapped[n].nsamples) for n in names], dtype=torch.float64,
+                              device=dev)
+        flat = torch.cat(parts + [counts])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=getattr(self.owner, "process_group", None))
+        off = 0
+        totals = flat[-len(names):]
+        for i, n in enumerate(names):
+            k = wrapped[n].scaler_row.numel()
+            wrapped[n].scaler_row.copy_((flat[off:off + k] / totals[i]).float())
+            wrapped[n].nsamples_global = int(totals[i].item())
+            off += k
+
     def capture(self, model, dataloader, blocks, forward_fn, cache_keys, n_samples,
                 optional_keys=False, batch_len=None):
         """Record the inputs of block 0 for the first n_samples calibration samples
@@ -107,8 +137,9 @@ class _BlockwiseWanda:
 
         handle = blocks[0].register_forward_pre_hook(grab, with_kwargs=True)
         total = 0
+        rank, world = self._rank_world()
         try:
-            for batch in dataloader:
+            for bi, batch in enumerate(dataloader):
                 if total >= n_samples:
                     break
                 if batch_len is not None:
@@ -116,6 +147,8 @@ class _BlockwiseWanda:
                 else:
                     total += (_default_batch_len(batch) if "image" not in batch
                               else batch["image"].shape[0])
+                if (bi % world) != rank:
+                    continue              # another rank calibrates on this batch
                 try:
                     forward_fn(model, batch)
                 except _StopForward:
@@ -163,6 +196,7 @@ class _BlockwiseWanda:
                 outs[j] = call(block, j)
             for h in handles:
                 h.remove()
+            self._merge_statistics(wrapped)
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps)
                 weight = subset[name].weight.data

@@ -72,3 +72,50 @@ def test_two_ranks_reproduce_single_process(tmp_path, method, k1_form, cached):
             for k, v in sums.items():                                  # double sums re-associate
                 assert abs(v - single[3][k]) <= 1e-6 * abs(v)
             assert sp == single[0]
+
+
+def _run_wanda(rank, world):
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    torch.set_num_threads(1)
+    torch.manual_seed(4)
+    model = blip2_toy().eval()
+    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    np.random.seed(42)
+    cfg = dict(t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+               t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+               max_sparsity_per_layer=0.6, num_data_first_stage=8,
+               sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum",
+               kernels=OracleKernels(), z_source=torch_cpu_normal)
+    model, table = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg).prune()
+    return table, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _wanda_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.save(_run_wanda(rank, world), os.path.join(out_dir, f"w{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
+    """Whole blipt5_wanda_pruner under DP=2: stage 1 bit-identical to one process; stage 2
+    shards the calibration batches and all-reduces the column statistics once per block, so
+    both replicas end with IDENTICAL pruned weights, and the same pruning pattern as one
+    process up to re-association of the fp32 statistics (equal here)."""
+    single_table, single_w = _run_wanda(0, 1)
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_wanda_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0, w0 = torch.load(tmp_path / "w0.pt", weights_only=False)
+    t1, w1 = torch.load(tmp_path / "w1.pt", weights_only=False)
+    assert t0 == t1 == single_table
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k                       # replicas agree bit for bit
+    agree = sum(int(((w0[k] == 0) == (single_w[k] == 0)).sum()) for k in w0)
+    total = sum(v.numel() for v in w0.values())
+    assert agree / total > 0.9999
