@@ -99,7 +99,8 @@ class T5Attention(nn.Module):
         ctx = torch.arange(qlen, dtype=torch.long, device=device)[:, None]
         mem = torch.arange(klen, dtype=torch.long, device=device)[None, :]
         bucket = self._bucket(mem - ctx, not self.is_decoder, self.num_buckets, self.max_distance)
-        return self.relative_attention_bias(bucket).permute(2, 0, 1).unsqueeze(0)
+        # contiguous [1, H, L, K]: the fused attention kernels need stride(-1) == 1 on the bias
+        return self.relative_attention_bias(bucket).permute(2, 0, 1).contiguous().unsqueeze(0)
 
     def forward(self, x, mask=None, key_value_states=None, position_bias=None):
         B, L, _ = x.shape
