@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch the suffix forwards eagerly instead of replaying HIP graphs")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL) in production; 'gloo' + --same-device only to exercise "
+                         "the N>1 code path on a single-GPU box")
+    ap.add_argument("--same-device", action="store_true")
     return ap.parse_args()
 
 
@@ -84,7 +88,7 @@ class TimedKernels:
     def __getattr__(self, name):
         return getattr(self.inner, name)
 
-    def _timed(self, kind, nbytes, fn, *a, **kw):
+    def _timed(self, kind, nbytes, fn, *a, n_launches=1, **kw):
         if not self.enabled:
             return fn(*a, **kw)
         # The loop is host-bound (the GPU drains its queue while Python prepares the next
@@ -99,7 +103,7 @@ class TimedKernels:
         s.record()
         r = fn(*a, **kw)
         e.record()
-        self.records.append((s, e, nbytes, kind))
+        self.records.append((s, e, nbytes, kind, n_launches))
         return r
 
     def zo_perturb_triple(self, w_in, w_plus, w_minus, w_restored, zo_eps, seed, z=None):
@@ -111,10 +115,11 @@ class TimedKernels:
 
     def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
         owned = sum(1 for t in w_plus if t is not None)
-        assert len(seeds) <= self.inner.MAX_UNITS, "one launch per layer expected in the bench"
-        nbytes = (2 * owned + 2) * w.element_size() * w.numel()   # read W; write 2/unit + final
+        chunks = max(1, -(-len(seeds) // self.inner.MAX_UNITS))   # launches of <= 32 units
+        # per launch: read W, write theta+/theta- of its owned units, write the drifted W
+        nbytes = (2 * owned + 2 * chunks) * w.element_size() * w.numel()
         return self._timed("units", nbytes, self.inner.zo_perturb_units, w, zo_eps, seeds, w_plus,
-                           w_minus, z)
+                           w_minus, z, n_launches=chunks)
 
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         nbytes = 2 * w.element_size() * w.numel()          # read W, write W
@@ -122,13 +127,13 @@ class TimedKernels:
                            seed, z)
 
     def summary(self, kind):
-        recs = [(s.elapsed_time(e) * 1e-3, b) for s, e, b, k in self.records if k == kind]
+        recs = [(s.elapsed_time(e) * 1e-3, b, n) for s, e, b, k, n in self.records if k == kind]
         if not recs:
             return None
         t = sum(r[0] for r in recs)
         b = sum(r[1] for r in recs)
-        return {"launches": len(recs), "avg_us": 1e6 * t / len(recs), "bytes_per_launch": b / len(recs),
-                "gbs": b / t / 1e9}
+        n = sum(r[2] for r in recs)
+        return {"launches": n, "avg_us": 1e6 * t / n, "bytes_per_launch": b / n, "gbs": b / t / 1e9}
 
 
 def main():
@@ -138,11 +143,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from ecoflap_amd import hip
     from ecoflap_amd.pruners import LayerSparsity
