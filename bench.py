@@ -6,7 +6,7 @@ SURVEY.md §8d).
 A "step" = one prunable weight matrix taken through the whole of the reference's inner
 loops (layer_single_base_pruner.py:512-549): for each of its calibration batches one
 +eps/-2eps/+eps perturbation triple (K1), two full forward losses, and its row of the loss
-table.  The K timed steps are K matrices — runs of 4 consecutive ones at evenly strided
+table.  The K timed steps are K matrices — runs of 6 consecutive ones at evenly strided
 positions over the model's 588 (ViT, T5 encoder, T5 decoder alike); the closing all-reduce of the loss table, the single host sync,
 the score reduction and the allocator are inside the timed region.
 
@@ -60,11 +60,11 @@ def parse():
     return ap.parse_args()
 
 
-def strided(n_total, k, offset=0, run=4):
+def strided(n_total, k, offset=0, run=6):
     """k layer indices as runs of `run` consecutive matrices at evenly strided positions.
     A real pass visits the 588 matrices in order, ~6.6 per block, so per-block costs
-    (prefix-cache advance, graph capture) amortise over consecutive matrices; runs of 4
-    (one ViT block) keep that structure in a k-matrix sample."""
+    (prefix-cache advance, graph capture) amortise over consecutive matrices; runs of 6
+    keep that structure in a k-matrix sample."""
     n_runs = max(1, (k + run - 1) // run)
     out = []
     for i in range(n_runs):

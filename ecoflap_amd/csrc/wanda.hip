@@ -234,6 +234,269 @@ __global__ __launch_bounds__(256) void wanda_rows_kernel(void* w, const float* _
     }
 }
 
+// -------------------------------------------------------------------------------------
+// K7 rows mode, register form (cols a multiple of the 16-byte vector): the row's metric
+// bits live in registers (NV vectors per lane), W is read with 16-byte loads and written
+// back once; the k-th smallest is found by a bitwise binary search on the bit pattern —
+// per bit one compare-count over the lane's registers, a 64-wide shuffle reduction and one
+// barrier (LDS only carries the four wave sums).  No atomics, no histogram.
+// -------------------------------------------------------------------------------------
+static __device__ __forceinline__ uint32_t block_count_256(uint32_t v, uint32_t* lds8, int phase) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    uint32_t* buf = lds8 + 4 * (phase & 1);     // double-buffered: one barrier per call
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return buf[0] + buf[1] + buf[2] + buf[3];
+}
+
+template <int DT, int NV>
+__global__ __launch_bounds__(256) void wanda_rows_reg_kernel(void* w, const float* __restrict__ sq,
+                                                             int64_t cols, int64_t k,
+                                                             uint8_t* mask_out) {
+    constexpr int N = Vec<DT>::N;
+    __shared__ uint32_t lds8[8];
+    __shared__ uint32_t wave4[4];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t nvec = cols / N;
+    void* wrow = (char*)w + row * cols * Vec<DT>::BYTES;
+    u32x4 wv[NV];
+    uint32_t m[NV][N];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t v = tid + 256 * j;
+        if (v < nvec) {
+            wv[j] = ld16(wrow, v);
+            float f[N];
+            Vec<DT>::unpack(wv[j], f);
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld16(sq, v * (N / 4) + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    m[j][4 * q + i] = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) m[j][i] = 0xffffffffu;   // padding: never among the k smallest
+        }
+    }
+    const bool all = (k >= cols);
+    uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
+    if (!all) {
+        // k-th smallest (1-indexed): largest T with #(m < T) < k
+        uint32_t prefix = 0;
+        int phase = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = prefix | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
+            c = block_count_256(c, lds8, phase++);
+            if (c < (uint32_t)k) prefix = cand;
+        }
+        T = prefix;
+        uint32_t less = 0, eq = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                less += (m[j][i] < T) ? 1u : 0u;
+                eq += (m[j][i] == T) ? 1u : 0u;
+            }
+        less = block_count_256(less, lds8, phase++);
+        total_equal = block_count_256(eq, lds8, phase++);
+        take_equal = (uint32_t)k - less;          // >= 1 of the elements equal to T are pruned
+    }
+    const bool ordered = !all && (take_equal < total_equal);   // ties cut by column order
+    uint32_t running = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t v = tid + 256 * j;
+        uint32_t rank0 = 0;
+        if (ordered) {     // block-uniform: equal-to-T elements in lower columns come first
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
+            uint32_t total;
+            const uint32_t incl = block_scan_256(mine, wave4, total);
+            rank0 = running + incl - mine;
+            running += total;
+        }
+        if (v < nvec) {
+            float f[N];
+            Vec<DT>::unpack(wv[j], f);
+            uint32_t bytes_lo = 0, bytes_hi = 0;
+            uint32_t seen = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool eqT = (m[j][i] == T);
+                bool prune = all || (m[j][i] < T) || (eqT && (!ordered || (rank0 + seen) < take_equal));
+                seen += eqT ? 1u : 0u;
+                if (prune) f[i] = 0.0f;
+                if (i < 4) bytes_lo |= (prune ? 1u : 0u) << (8 * i);
+                else bytes_hi |= (prune ? 1u : 0u) << (8 * (i - 4));
+            }
+            st16(wrow, v, Vec<DT>::pack(f));
+            if (mask_out) {
+                uint8_t* mrow = mask_out + row * cols + v * N;
+                *(uint32_t*)mrow = bytes_lo;
+                if (N == 8) *(uint32_t*)(mrow + 4) = bytes_hi;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// K7 rows mode, wave form (rows of up to 64*12 vectors): ONE 64-lane wave per row, four rows
+// per workgroup.  Counts are ballots: v_cmp writes the lane mask, s_bcnt1 counts it on the
+// scalar unit — the bitwise search needs no shuffle, no LDS and no barrier at all.
+// -------------------------------------------------------------------------------------
+template <int DT, int NV>
+__global__ __launch_bounds__(256) void wanda_rows_wave_kernel(void* w, const float* __restrict__ sq,
+                                                              int64_t rows, int64_t cols, int64_t k,
+                                                              uint8_t* mask_out) {
+    constexpr int N = Vec<DT>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;                   // whole wave leaves together
+    const int64_t nvec = cols / N;
+    void* wrow = (char*)w + row * cols * Vec<DT>::BYTES;
+    u32x4 wv[NV];
+    uint32_t m[NV][N];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t v = lane + 64 * j;
+        if (v < nvec) {
+            wv[j] = ld16(wrow, v);
+            float f[N];
+            Vec<DT>::unpack(wv[j], f);
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld16(sq, v * (N / 4) + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    m[j][4 * q + i] = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) m[j][i] = 0xffffffffu;
+        }
+    }
+    const bool all = (k >= cols);
+    uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
+    if (!all) {
+        uint32_t prefix = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = prefix | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) c += (uint32_t)__popcll(__ballot(m[j][i] < cand));
+            if (c < (uint32_t)k) prefix = cand;
+        }
+        T = prefix;
+        uint32_t less = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                less += (uint32_t)__popcll(__ballot(m[j][i] < T));
+                total_equal += (uint32_t)__popcll(__ballot(m[j][i] == T));
+            }
+        take_equal = (uint32_t)k - less;
+    }
+    const bool ordered = !all && (take_equal < total_equal);
+    uint32_t running = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t v = lane + 64 * j;
+        uint32_t rank0 = 0;
+        if (ordered) {      // wave-uniform
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
+            uint32_t x = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
+            }
+            rank0 = running + x - mine;
+            running += __shfl(x, 63, 64);
+        }
+        if (v < nvec) {
+            float f[N];
+            Vec<DT>::unpack(wv[j], f);
+            uint32_t bytes_lo = 0, bytes_hi = 0, seen = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool eqT = (m[j][i] == T);
+                const bool prune = all || (m[j][i] < T) ||
+                                   (eqT && (!ordered || (rank0 + seen) < take_equal));
+                seen += eqT ? 1u : 0u;
+                if (prune) f[i] = 0.0f;
+                if (i < 4) bytes_lo |= (prune ? 1u : 0u) << (8 * i);
+                else bytes_hi |= (prune ? 1u : 0u) << (8 * (i - 4));
+            }
+            st16(wrow, v, Vec<DT>::pack(f));
+            if (mask_out) {
+                uint8_t* mrow = mask_out + row * cols + v * N;
+                *(uint32_t*)mrow = bytes_lo;
+                if (N == 8) *(uint32_t*)(mrow + 4) = bytes_hi;
+            }
+        }
+    }
+}
+
+template <int DT>
+static int launch_rows_wave(void* w, const float* sq, int64_t rows, int64_t cols, int64_t k,
+                            uint8_t* mask_out, hipStream_t s) {
+    constexpr int N = Vec<DT>::N;
+    const int64_t nvec = cols / N;
+    const int nv = (int)((nvec + 63) / 64);
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define ROWS_WAVE(NV_)                                                                   \
+    hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, NV_>), grid, blk, 0, s, w, sq, rows, cols, k, \
+                       mask_out)
+    if (nv <= 1) ROWS_WAVE(1);
+    else if (nv <= 2) ROWS_WAVE(2);
+    else if (nv <= 4) ROWS_WAVE(4);
+    else if (nv <= 6) ROWS_WAVE(6);
+    else if (nv <= 8) ROWS_WAVE(8);
+    else if (nv <= 10) ROWS_WAVE(10);
+    else if (nv <= 12) ROWS_WAVE(12);
+    else return 1;
+#undef ROWS_WAVE
+    return 0;
+}
+
+template <int DT>
+static int launch_rows_reg(void* w, const float* sq, int64_t rows, int64_t cols, int64_t k,
+                           uint8_t* mask_out, hipStream_t s) {
+    constexpr int N = Vec<DT>::N;
+    const int64_t nvec = cols / N;
+    const int nv = (int)((nvec + 255) / 256);
+    const dim3 grid((unsigned)rows), blk(256);
+#define ROWS_REG(NV_)                                                                          \
+    hipLaunchKernelGGL((wanda_rows_reg_kernel<DT, NV_>), grid, blk, 0, s, w, sq, cols, k, mask_out)
+    if (nv <= 1) ROWS_REG(1);
+    else if (nv <= 2) ROWS_REG(2);
+    else if (nv <= 3) ROWS_REG(3);
+    else if (nv <= 4) ROWS_REG(4);
+    else if (nv <= 6) ROWS_REG(6);
+    else if (nv <= 8) ROWS_REG(8);
+    else if (nv <= 12) ROWS_REG(12);
+    else if (nv <= 16) ROWS_REG(16);
+    else return 1;
+#undef ROWS_REG
+    return 0;
+}
+
 // =====================================================================================
 // K7 matrix mode: global (k+1)-th smallest over rows*cols by 3 histogram passes
 // (11 + 11 + 10 bits), then zero metric <= threshold.
@@ -333,6 +596,30 @@ extern "C" int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_
     hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
                        scaler_row, sq, cols);
     ECO_CHECK_LAUNCH();
+    const int nvec_elems = dtype == ECOFLAP_F32 ? 4 : 8;
+    // mask rows are written with 4/8-byte stores: cols % 8 keeps them aligned for 16-bit dtypes
+    if (cols % nvec_elems == 0 && aligned16(w) && aligned16(sq) &&
+        (!mask_out || (((uintptr_t)mask_out) & 7u) == 0)) {
+        // measured on MI355X: the wave form wins up to 256 vectors per row (2048 bf16 columns),
+        // the workgroup form beyond
+        int miss = 1;
+        if (cols / nvec_elems <= 256) {
+            if (dtype == ECOFLAP_F32) miss = launch_rows_wave<ECOFLAP_F32>(w, sq, rows, cols, k, mask_out, s);
+            else if (dtype == ECOFLAP_F16) miss = launch_rows_wave<ECOFLAP_F16>(w, sq, rows, cols, k, mask_out, s);
+            else miss = launch_rows_wave<ECOFLAP_BF16>(w, sq, rows, cols, k, mask_out, s);
+        }
+        if (!miss) {
+            ECO_CHECK_LAUNCH();
+            return 0;
+        }
+        if (dtype == ECOFLAP_F32) miss = launch_rows_reg<ECOFLAP_F32>(w, sq, rows, cols, k, mask_out, s);
+        else if (dtype == ECOFLAP_F16) miss = launch_rows_reg<ECOFLAP_F16>(w, sq, rows, cols, k, mask_out, s);
+        else miss = launch_rows_reg<ECOFLAP_BF16>(w, sq, rows, cols, k, mask_out, s);
+        if (!miss) {
+            ECO_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const size_t lds = ((size_t)cols + 256 + 4 + 4) * sizeof(uint32_t);
     if (dtype == ECOFLAP_F32)
         hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_F32>), dim3((unsigned)rows), dim3(256), lds, s,
