@@ -52,6 +52,9 @@ def parse():
                          "suffix-only re-forward (pruners/prefix_cache.py)")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch the suffix forwards eagerly instead of replaying HIP graphs")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="2: theta+ and theta- suffixes replay concurrently (second weight "
+                         "replica + second stream); 1: one after the other")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL) in production; 'gloo' + --same-device only to exercise "
@@ -198,7 +201,8 @@ def main():
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
         np.random.seed(42)
         loss_fn = (loss_vision_language if args.full_forward
-                   else PrefixCachedLoss(model, use_graphs=not args.no_graphs))
+                   else PrefixCachedLoss(model, use_graphs=not args.no_graphs,
+                                        two_lanes=(args.lanes == 2)))
         run.loss_fns.append(loss_fn)
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
@@ -264,7 +268,9 @@ def main():
             "forward_form": ("2 full forwards per unit" if args.full_forward else
                              "exact suffix-only re-forward from the owning block (activations "
                              "at the block boundary cached per batch)"
-                             + ("" if args.no_graphs else ", suffix replayed as a HIP graph")),
+                             + ("" if args.no_graphs else ", suffix replayed as a HIP graph")
+                             + (", theta+/theta- on two concurrent lanes"
+                                if (args.lanes == 2 and not args.no_graphs) else "")),
             "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
         },
         "breakdown": {

@@ -229,11 +229,26 @@ class LayerSparsity:
                         home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
                         None if self.z_source == "philox" else zs)
                 static_w = bool(getattr(self.loss_func, "requires_static_weights", False))
+                paired = static_w and bool(getattr(self.loss_func, "supports_pairs", lambda: False)())
                 final = home.clone() if static_w else None   # graphs bake the address of `home`
+                if paired:
+                    self.loss_func.begin_layer_weights(name, home)
                 for j, (u, mine) in enumerate(zip(layer_units, owned)):
                     if not mine:
                         continue
                     _, bi, _, _, blen = units[u]
+                    if paired:
+                        # theta+ on lane A, theta- on lane B, both suffixes in flight together
+                        with torch.no_grad():
+                            l1, l2, batch_len = self.loss_func.pair(
+                                self.model, batches[bi], cuda_enabled, plus[j], minus[j])
+                        if batch_len != blen:
+                            raise RuntimeError("loss_func batch_len differs from the schedule")
+                        self.loss_func.join()
+                        table[u, 0].copy_(l1.detach().float(), non_blocking=True)
+                        table[u, 1].copy_(l2.detach().float(), non_blocking=True)
+                        n_forward += 2
+                        continue
                     if static_w:
                         home.copy_(plus[j])
                     else:
@@ -247,6 +262,8 @@ class LayerSparsity:
                     n_forward += 2
                 if static_w:
                     home.copy_(final)
+                if paired:
+                    self.loss_func.end_layer_weights(final)
                 param.data = home               # "recovered" weights, with the reference's drift
                 del scratch, plus, minus, zs
                 continue

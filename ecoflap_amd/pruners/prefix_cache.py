@@ -63,9 +63,12 @@ class PrefixCachedLoss:
     addresses in, hence `requires_static_weights`: LayerSparsity then copies theta+/theta-
     into the parameter's own storage instead of re-pointing `param.data`."""
 
-    def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False):
+    def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
+                 two_lanes=False):
         self.model = model
         self.use_graphs = bool(use_graphs)
+        self.two_lanes = bool(two_lanes) and self.use_graphs
+        self.lane_b = None          # (replica model, its plan, its graphs, stream) built lazily
         self.requires_static_weights = self.use_graphs
         self.graphs = {}            # entry stage -> [calls_seen, graph, static_state, static_loss]
         self.pool = None
@@ -94,9 +97,7 @@ class PrefixCachedLoss:
         self.entry = 0
 
     # ---- the loss closure ----------------------------------------------------------------------
-    def __call__(self, model, samples, cuda_enabled):
-        assert model is self.model
-        key = id(samples)
+    def _ensure_cached(self, key, samples):
         idx, state = self.cache.get(key, (0, samples))
         if idx > self.entry:        # asked for an earlier stage than cached: start over
             idx, state = 0, samples
@@ -106,20 +107,76 @@ class PrefixCachedLoss:
                     state = self.plan[j][2](state)
                     self.stats["advance_calls"] += 1
             idx = self.entry
-            self.cache[key] = (idx, state)
+        self.cache[key] = (idx, state)
+
+    def _account(self, idx):
+        self.stats["stage_calls"] += len(self.plan) - idx
+        self.stats["stage_calls_full"] += len(self.plan)
+
+    def _batch_len(self, samples):
+        if self.batch_len_fn is not None:
+            return self.batch_len_fn(samples)
+        if "text_input" in samples:
+            return len(samples["text_input"])
+        return len(samples["label"])
+
+    def __call__(self, model, samples, cuda_enabled):
+        assert model is self.model
+        key = id(samples)
+        self._ensure_cached(key, samples)
+        idx, state = self.cache[key]
         if self.use_graphs and idx > 0 and _on_gpu(state):
             loss = self._graphed_suffix(idx, state)
         else:
             loss = self.result(self._suffix(idx, state))
-        self.stats["stage_calls"] += len(self.plan) - idx
-        self.stats["stage_calls_full"] += len(self.plan)
-        if self.batch_len_fn is not None:
-            n = self.batch_len_fn(samples)
-        elif "text_input" in samples:
-            n = len(samples["text_input"])
-        else:
-            n = len(samples["label"])
-        return loss, n
+        self._account(idx)
+        return loss, self._batch_len(samples)
+
+    # ---- both evaluations of one unit at once (LayerSparsity uses it when present) -----------
+    def supports_pairs(self):
+        return self.two_lanes
+
+    def begin_layer_weights(self, name, home):
+        """Called once per layer: `home` is the parameter's own storage (lane A)."""
+        self._pair_name, self._pair_home = name, home
+        if self.two_lanes and self.lane_b is None and home.device.type == "cuda":
+            self.lane_b = _LaneB(self)
+
+    def end_layer_weights(self, final):
+        """Drifted weights of the finished layer go to both replicas."""
+        if self.lane_b is not None:
+            self.lane_b.params[self._pair_name].data.copy_(final)
+
+    def pair(self, model, samples, cuda_enabled, theta_plus, theta_minus):
+        """-> (loss(theta+), loss(theta-), batch_len); lane A on the current stream, lane B
+        concurrently on its own.  The caller must `join()` before reading the losses."""
+        if self.lane_b is None:
+            self._pair_home.copy_(theta_plus)
+            l1, n = self(model, samples, cuda_enabled)
+            l1 = l1.clone()
+            self._pair_home.copy_(theta_minus)
+            l2, _ = self(model, samples, cuda_enabled)
+            return l1, l2, n
+        self._pair_home.copy_(theta_plus)
+        self.lane_b.params[self._pair_name].data.copy_(theta_minus)
+        key = id(samples)
+        self._ensure_cached(key, samples)
+        idx, state = self.cache[key]
+        if idx == 0 or not _on_gpu(state) or not self._warmed:
+            l1, n = self(model, samples, cuda_enabled)
+            l1 = l1.clone()
+            self._pair_home.copy_(theta_minus)
+            l2, _ = self(model, samples, cuda_enabled)
+            return l1, l2, n
+        l2 = self.lane_b.replay(idx, state)                   # lane B first: it runs beside A
+        l1 = self._graphed_suffix(idx, state)
+        self._account(idx)
+        self._account(idx)
+        return l1, l2, self._batch_len(samples)
+
+    def join(self):
+        if self.lane_b is not None:
+            torch.cuda.current_stream().wait_stream(self.lane_b.stream)
 
     def _suffix(self, idx, state):
         out = state
@@ -152,6 +209,57 @@ class PrefixCachedLoss:
         rec[1].replay()
         self.stats["graph_replays"] += 1
         return rec[3]
+
+
+class _LaneB:
+    """Second evaluation lane: a full weight replica (7.4 GB for BLIP-2 — nothing next to
+    288 GB) with its own graphs on its own stream, so the theta- suffix of a unit replays
+    CONCURRENTLY with the theta+ suffix of lane A.  The suffixes are launch- and
+    latency-bound (hundreds of ~5-15 us kernels on 128-384 token activations) and leave most
+    CUs idle; two streams fill them.  Same kernels on the same bits -> same losses."""
+
+    def __init__(self, owner):
+        import copy
+        self.owner = owner
+        self.model = copy.deepcopy(owner.model)
+        self.plan = self.model.stage_plan()
+        self.params = dict(self.model.named_parameters())
+        self.graphs = {}
+        self.stream = torch.cuda.Stream()
+        self.pool = None
+
+    def suffix(self, idx, state):
+        out = state
+        for j in range(idx, len(self.plan)):
+            out = self.plan[j][2](out)
+        return out
+
+    def replay(self, idx, state):
+        """Enqueue lane B's suffix on its stream; returns the static loss tensor."""
+        import time
+        rec = self.graphs.get(idx)
+        if rec is None:
+            t0 = time.time()
+            static_state = _map_tensors(state, lambda t: t.clone())
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                self.owner.result(self.suffix(idx, static_state))       # warm-up on this stream
+            self.stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            with torch.no_grad(), torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+                static_loss = self.owner.result(self.suffix(idx, static_state))
+            rec = self.graphs[idx] = (graph, static_state, static_loss)
+            self.owner.stats["graph_captures"] += 1
+            self.owner.stats["capture_seconds"] += time.time() - t0
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)             # theta- copy and K1 are ordered on `main`
+        with torch.cuda.stream(self.stream):
+            _copy_tensors(rec[1], state)
+            rec[0].replay()
+        self.owner.stats["graph_replays"] += 1
+        return rec[2]
 
 
 def _on_gpu(state):

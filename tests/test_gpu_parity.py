@@ -437,7 +437,7 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_toy
     res = []
-    for mode in ("full", "suffix", "graph"):
+    for mode in ("full", "suffix", "graph", "graph2"):
         torch.manual_seed(0)
         model = blip2_toy(fp32=fp32).eval().to("cuda")
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
@@ -447,13 +447,14 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
                    if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
         loss = {"full": loss_vision_language,
                 "suffix": PrefixCachedLoss(model),
-                "graph": PrefixCachedLoss(model, use_graphs=True)}[mode]
+                "graph": PrefixCachedLoss(model, use_graphs=True),
+                "graph2": PrefixCachedLoss(model, use_graphs=True, two_lanes=True)}[mode]
         np.random.seed(3)
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=kern, z_source="philox")
         sp = ls.return_sparsity()
         res.append((ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
-        if mode == "graph":
+        if mode.startswith("graph"):
             assert loss.stats["graph_replays"] > 100 and loss.stats["graph_captures"] >= 4
     for other in res[1:]:
         assert np.array_equal(res[0][0], other[0])
