@@ -70,8 +70,7 @@ class PrefixCachedLoss:
         self.two_lanes = bool(two_lanes) and self.use_graphs
         self.lane_b = None          # (replica model, its plan, its graphs, stream) built lazily
         self.requires_static_weights = self.use_graphs
-        self.graphs = {}            # entry stage -> [calls_seen, graph, static_state, static_loss]
-        self.pool = None
+        self.chain = None           # per-stage graphs of lane A
         self._warmed = False
         self.plan = model.stage_plan()
         self.result = _vision_result if kind == "vision" else _vision_language_result
@@ -185,30 +184,72 @@ class PrefixCachedLoss:
         return out
 
     def _graphed_suffix(self, idx, state):
+        if not self._warmed:
+            # the very first suffix runs eagerly: the warm-up torch asks for before any
+            # capture (library handles, workspaces)
+            self._warmed = True
+            return self.result(self._suffix(idx, state))
+        if self.chain is None:
+            self.chain = _StageGraphs(self, self.plan, stream=None)
+        return self.chain.replay(idx, state)
+
+
+class _StageGraphs:
+    """One HIP graph per STAGE (ViT block, T5 block, ...), captured once and chained through
+    static buffers: stage j's graph reads the tensors stage j-1's graph wrote.  A suffix from
+    any entry stage is then a sequence of graph launches (~10 us each) and the total capture
+    cost of a whole pass is one forward's worth, instead of one capture per entry stage."""
+
+    def __init__(self, owner, plan, stream):
+        self.owner = owner
+        self.plan = plan
+        self.stream = stream            # None: torch's capture side stream / current stream
+        self.graphs = {}                # stage -> (graph, static_in, static_out)
+        self.pool = None
+        self.bridges = {}               # stage -> tensors to copy into its static input
+
+    def _capture(self, j, static_in):
         import time
-        rec = self.graphs.get(idx)
-        if rec is None:
-            rec = self.graphs[idx] = [1, None, None, None]
-            if not self._warmed:
-                # the very first suffix runs eagerly: the warm-up torch asks for before any
-                # capture (library handles, workspaces); later entry stages capture at once
-                self._warmed = True
-                return self.result(self._suffix(idx, state))
-        if rec[1] is None:
-            t0 = time.time()
-            static_state = _map_tensors(state, lambda t: t.clone())
-            graph = torch.cuda.CUDAGraph()
-            if self.pool is None:
-                self.pool = torch.cuda.graph_pool_handle()   # graphs never overlap: share memory
-            with torch.cuda.graph(graph, pool=self.pool):
-                static_loss = self.result(self._suffix(idx, static_state))
-            rec[1], rec[2], rec[3] = graph, static_state, static_loss
-            self.stats["graph_captures"] += 1
-            self.stats["capture_seconds"] += time.time() - t0
-        _copy_tensors(rec[2], state)
-        rec[1].replay()
-        self.stats["graph_replays"] += 1
-        return rec[3]
+        t0 = time.time()
+        graph = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        kw = {"pool": self.pool}
+        if self.stream is not None:
+            kw["stream"] = self.stream
+        last = (j == len(self.plan) - 1)
+        with torch.no_grad(), torch.cuda.graph(graph, **kw):
+            out = self.plan[j][2](static_in)
+            if last:
+                out = {"__loss__": self.owner.result(out)}
+        self.graphs[j] = (graph, static_in, out)
+        self.owner.stats["graph_captures"] += 1
+        self.owner.stats["capture_seconds"] += time.time() - t0
+        return out
+
+    def ensure(self, idx, state):
+        """Make sure stages idx..end are captured, chained output -> input."""
+        n = len(self.plan)
+        if idx in self.graphs and all(j in self.graphs for j in range(idx, n)):
+            return
+        static_in = _map_tensors(state, lambda t: t.clone())
+        for j in range(idx, n):
+            if j in self.graphs:
+                # joins an existing chain captured from a later entry: bridge by copy at replay
+                self.bridges[j] = static_in
+                break
+            static_in = self._capture(j, static_in)
+
+    def replay(self, idx, state):
+        self.ensure(idx, state)
+        n = len(self.plan)
+        _copy_tensors(self.graphs[idx][1], state)
+        for j in range(idx, n):
+            if j != idx and j in self.bridges:
+                _copy_tensors(self.graphs[j][1], self.bridges[j])
+            self.graphs[j][0].replay()
+        self.owner.stats["graph_replays"] += 1
+        return self.graphs[n - 1][2]["__loss__"]
 
 
 class _LaneB:
@@ -224,42 +265,27 @@ class _LaneB:
         self.model = copy.deepcopy(owner.model)
         self.plan = self.model.stage_plan()
         self.params = dict(self.model.named_parameters())
-        self.graphs = {}
         self.stream = torch.cuda.Stream()
-        self.pool = None
-
-    def suffix(self, idx, state):
-        out = state
-        for j in range(idx, len(self.plan)):
-            out = self.plan[j][2](out)
-        return out
+        self.chain = _StageGraphs(owner, self.plan, stream=self.stream)
+        self.warmed = False
 
     def replay(self, idx, state):
         """Enqueue lane B's suffix on its stream; returns the static loss tensor."""
-        import time
-        rec = self.graphs.get(idx)
-        if rec is None:
-            t0 = time.time()
-            static_state = _map_tensors(state, lambda t: t.clone())
+        if not self.warmed:                        # once: eager pass on this stream
+            self.warmed = True
             torch.cuda.synchronize()
             with torch.cuda.stream(self.stream), torch.no_grad():
-                self.owner.result(self.suffix(idx, static_state))       # warm-up on this stream
+                out = state
+                for j in range(idx, len(self.plan)):
+                    out = self.plan[j][2](out)
+                self.owner.result(out)
             self.stream.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            if self.pool is None:
-                self.pool = torch.cuda.graph_pool_handle()
-            with torch.no_grad(), torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
-                static_loss = self.owner.result(self.suffix(idx, static_state))
-            rec = self.graphs[idx] = (graph, static_state, static_loss)
-            self.owner.stats["graph_captures"] += 1
-            self.owner.stats["capture_seconds"] += time.time() - t0
+        self.chain.ensure(idx, state)              # captures (if any) before the fork
         main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)             # theta- copy and K1 are ordered on `main`
+        self.stream.wait_stream(main)              # theta- copy and K1 are ordered on `main`
         with torch.cuda.stream(self.stream):
-            _copy_tensors(rec[1], state)
-            rec[0].replay()
-        self.owner.stats["graph_replays"] += 1
-        return rec[2]
+            loss = self.chain.replay(idx, state)
+        return loss
 
 
 def _on_gpu(state):
