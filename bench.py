@@ -52,7 +52,7 @@ def parse():
                          "suffix-only re-forward (pruners/prefix_cache.py)")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch the suffix forwards eagerly instead of replaying HIP graphs")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--lanes", type=int, default=4, choices=[1, 2, 4, 6, 8],
                     help="2: theta+ and theta- suffixes replay concurrently (second weight "
                          "replica + second stream); 1: one after the other")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
@@ -202,7 +202,7 @@ def main():
         np.random.seed(42)
         loss_fn = (loss_vision_language if args.full_forward
                    else PrefixCachedLoss(model, use_graphs=not args.no_graphs,
-                                        two_lanes=(args.lanes == 2)))
+                                        n_lanes=args.lanes))
         run.loss_fns.append(loss_fn)
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
@@ -269,8 +269,8 @@ def main():
                              "exact suffix-only re-forward from the owning block (activations "
                              "at the block boundary cached per batch)"
                              + ("" if args.no_graphs else ", suffix replayed as a HIP graph")
-                             + (", theta+/theta- on two concurrent lanes"
-                                if (args.lanes == 2 and not args.no_graphs) else "")),
+                             + (f", {args.lanes} evaluations in flight on concurrent lanes"
+                                if (args.lanes > 1 and not args.no_graphs) else "")),
             "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
         },
         "breakdown": {

@@ -233,22 +233,27 @@ class LayerSparsity:
                 final = home.clone() if static_w else None   # graphs bake the address of `home`
                 if paired:
                     self.loss_func.begin_layer_weights(name, home)
+                if paired:
+                    # theta+/theta- of several units on concurrent lanes (pruners/prefix_cache.py)
+                    mine_js = [j for j, mine in enumerate(owned) if mine]
+                    step = self.loss_func.pairs_in_flight()
+                    for c0 in range(0, len(mine_js), step):
+                        chunk = mine_js[c0:c0 + step]
+                        items = [(batches[units[layer_units[j]][1]], plus[j], minus[j]) for j in chunk]
+                        with torch.no_grad():
+                            res = self.loss_func.multi(self.model, items, cuda_enabled)
+                        self.loss_func.join()
+                        for j, (l1, l2, batch_len) in zip(chunk, res):
+                            u = layer_units[j]
+                            if batch_len != units[u][4]:
+                                raise RuntimeError("loss_func batch_len differs from the schedule")
+                            table[u, 0].copy_(l1.detach().float(), non_blocking=True)
+                            table[u, 1].copy_(l2.detach().float(), non_blocking=True)
+                            n_forward += 2
                 for j, (u, mine) in enumerate(zip(layer_units, owned)):
-                    if not mine:
+                    if not mine or paired:
                         continue
                     _, bi, _, _, blen = units[u]
-                    if paired:
-                        # theta+ on lane A, theta- on lane B, both suffixes in flight together
-                        with torch.no_grad():
-                            l1, l2, batch_len = self.loss_func.pair(
-                                self.model, batches[bi], cuda_enabled, plus[j], minus[j])
-                        if batch_len != blen:
-                            raise RuntimeError("loss_func batch_len differs from the schedule")
-                        self.loss_func.join()
-                        table[u, 0].copy_(l1.detach().float(), non_blocking=True)
-                        table[u, 1].copy_(l2.detach().float(), non_blocking=True)
-                        n_forward += 2
-                        continue
                     if static_w:
                         home.copy_(plus[j])
                     else:

@@ -64,11 +64,15 @@ class PrefixCachedLoss:
     into the parameter's own storage instead of re-pointing `param.data`."""
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
-                 two_lanes=False):
+                 two_lanes=False, n_lanes=None):
         self.model = model
         self.use_graphs = bool(use_graphs)
-        self.two_lanes = bool(two_lanes) and self.use_graphs
-        self.lane_b = None          # (replica model, its plan, its graphs, stream) built lazily
+        if n_lanes is None:
+            n_lanes = 2 if two_lanes else 1
+        assert n_lanes in (1, 2, 4, 6, 8)
+        self.n_lanes = n_lanes if self.use_graphs else 1
+        self.two_lanes = self.n_lanes > 1
+        self.extra_lanes = None     # replicas (model copy + stream + graphs), built lazily
         self.requires_static_weights = self.use_graphs
         self.chain = None           # per-stage graphs of lane A
         self._warmed = False
@@ -133,49 +137,62 @@ class PrefixCachedLoss:
 
     # ---- both evaluations of one unit at once (LayerSparsity uses it when present) -----------
     def supports_pairs(self):
-        return self.two_lanes
+        return self.n_lanes > 1
+
+    def pairs_in_flight(self):
+        return max(1, self.n_lanes // 2)
 
     def begin_layer_weights(self, name, home):
-        """Called once per layer: `home` is the parameter's own storage (lane A)."""
+        """Called once per layer: `home` is the parameter's own storage (lane 0)."""
         self._pair_name, self._pair_home = name, home
-        if self.two_lanes and self.lane_b is None and home.device.type == "cuda":
-            self.lane_b = _LaneB(self)
+        if self.n_lanes > 1 and self.extra_lanes is None and home.device.type == "cuda":
+            self.extra_lanes = [_Lane(self) for _ in range(self.n_lanes - 1)]
 
     def end_layer_weights(self, final):
-        """Drifted weights of the finished layer go to both replicas."""
-        if self.lane_b is not None:
-            self.lane_b.params[self._pair_name].data.copy_(final)
+        """Drifted weights of the finished layer go to every replica."""
+        for lane in self.extra_lanes or []:
+            lane.params[self._pair_name].data.copy_(final)
+
+    def multi(self, model, items, cuda_enabled):
+        """items: [(samples, theta_plus, theta_minus)] for up to pairs_in_flight() units ->
+        [(loss(theta+), loss(theta-), batch_len)].  Evaluation 2i runs on lane 2i, 2i+1 on lane
+        2i+1; lane 0 is the model itself on the current stream, the others are replicas on
+        their own streams, all in flight together.  `join()` before reading the losses."""
+        evals = []
+        for samples, tp, tm in items:
+            evals += [(samples, tp), (samples, tm)]
+        can_fork = self.extra_lanes is not None and self._warmed
+        states = []
+        for samples, _ in evals:
+            key = id(samples)
+            self._ensure_cached(key, samples)
+            states.append(self.cache[key])
+        if can_fork:
+            can_fork = all(idx > 0 and _on_gpu(st) for idx, st in states)
+        losses = [None] * len(evals)
+        if not can_fork:
+            for i, (samples, theta) in enumerate(evals):        # sequential on lane 0
+                self._pair_home.copy_(theta)
+                l, _ = self(model, samples, cuda_enabled)
+                losses[i] = l.clone()
+        else:
+            for i in range(1, len(evals)):                      # replicas first, lane 0 last
+                lane = self.extra_lanes[i - 1]
+                lane.params[self._pair_name].data.copy_(evals[i][1])
+                losses[i] = lane.replay(*states[i])
+                self._account(states[i][0])
+            self._pair_home.copy_(evals[0][1])
+            losses[0] = self._graphed_suffix(*states[0])
+            self._account(states[0][0])
+        return [(losses[2 * i], losses[2 * i + 1], self._batch_len(items[i][0]))
+                for i in range(len(items))]
 
     def pair(self, model, samples, cuda_enabled, theta_plus, theta_minus):
-        """-> (loss(theta+), loss(theta-), batch_len); lane A on the current stream, lane B
-        concurrently on its own.  The caller must `join()` before reading the losses."""
-        if self.lane_b is None:
-            self._pair_home.copy_(theta_plus)
-            l1, n = self(model, samples, cuda_enabled)
-            l1 = l1.clone()
-            self._pair_home.copy_(theta_minus)
-            l2, _ = self(model, samples, cuda_enabled)
-            return l1, l2, n
-        self._pair_home.copy_(theta_plus)
-        self.lane_b.params[self._pair_name].data.copy_(theta_minus)
-        key = id(samples)
-        self._ensure_cached(key, samples)
-        idx, state = self.cache[key]
-        if idx == 0 or not _on_gpu(state) or not self._warmed:
-            l1, n = self(model, samples, cuda_enabled)
-            l1 = l1.clone()
-            self._pair_home.copy_(theta_minus)
-            l2, _ = self(model, samples, cuda_enabled)
-            return l1, l2, n
-        l2 = self.lane_b.replay(idx, state)                   # lane B first: it runs beside A
-        l1 = self._graphed_suffix(idx, state)
-        self._account(idx)
-        self._account(idx)
-        return l1, l2, self._batch_len(samples)
+        return self.multi(model, [(samples, theta_plus, theta_minus)], cuda_enabled)[0]
 
     def join(self):
-        if self.lane_b is not None:
-            torch.cuda.current_stream().wait_stream(self.lane_b.stream)
+        for lane in self.extra_lanes or []:
+            torch.cuda.current_stream().wait_stream(lane.stream)
 
     def _suffix(self, idx, state):
         out = state
@@ -252,7 +269,7 @@ class _StageGraphs:
         return self.graphs[n - 1][2]["__loss__"]
 
 
-class _LaneB:
+class _Lane:
     """Second evaluation lane: a full weight replica (7.4 GB for BLIP-2 — nothing next to
     288 GB) with its own graphs on its own stream, so the theta- suffix of a unit replays
     CONCURRENTLY with the theta+ suffix of lane A.  The suffixes are launch- and
@@ -270,7 +287,7 @@ class _LaneB:
         self.warmed = False
 
     def replay(self, idx, state):
-        """Enqueue lane B's suffix on its stream; returns the static loss tensor."""
+        """Enqueue this lane's suffix on its stream; returns the static loss tensor."""
         if not self.warmed:                        # once: eager pass on this stream
             self.warmed = True
             torch.cuda.synchronize()

@@ -437,7 +437,7 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_toy
     res = []
-    for mode in ("full", "suffix", "graph", "graph2"):
+    for mode in ("full", "suffix", "graph", "graph2", "graph4"):
         torch.manual_seed(0)
         model = blip2_toy(fp32=fp32).eval().to("cuda")
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
@@ -448,7 +448,8 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
         loss = {"full": loss_vision_language,
                 "suffix": PrefixCachedLoss(model),
                 "graph": PrefixCachedLoss(model, use_graphs=True),
-                "graph2": PrefixCachedLoss(model, use_graphs=True, two_lanes=True)}[mode]
+                "graph2": PrefixCachedLoss(model, use_graphs=True, two_lanes=True),
+                "graph4": PrefixCachedLoss(model, use_graphs=True, n_lanes=4)}[mode]
         np.random.seed(3)
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=kern, z_source="philox")
