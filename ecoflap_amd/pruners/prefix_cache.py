@@ -105,10 +105,16 @@ class PrefixCachedLoss:
         if idx > self.entry:        # asked for an earlier stage than cached: start over
             idx, state = 0, samples
         if idx < self.entry:
-            with torch.no_grad():
-                for j in range(idx, self.entry):
-                    state = self.plan[j][2](state)
-                    self.stats["advance_calls"] += 1
+            chain = getattr(self, "chain", None)
+            if (chain is not None and idx > 0 and _on_gpu(state)
+                    and all(j in chain.graphs for j in range(idx, self.entry))):
+                state = chain.advance(idx, self.entry, state)     # already-captured stages
+                self.stats["advance_calls"] += self.entry - idx
+            else:
+                with torch.no_grad():
+                    for j in range(idx, self.entry):
+                        state = self.plan[j][2](state)
+                        self.stats["advance_calls"] += 1
             idx = self.entry
         self.cache[key] = (idx, state)
 
@@ -256,6 +262,16 @@ class _StageGraphs:
                 self.bridges[j] = static_in
                 break
             static_in = self._capture(j, static_in)
+
+    def advance(self, idx, stop, state):
+        """Run captured stages idx..stop-1 on `state`; returns a private copy of the state
+        entering stage `stop` (the static buffers are overwritten by the next replay)."""
+        _copy_tensors(self.graphs[idx][1], state)
+        for j in range(idx, stop):
+            if j != idx and j in self.bridges:
+                _copy_tensors(self.graphs[j][1], self.bridges[j])
+            self.graphs[j][0].replay()
+        return _map_tensors(self.graphs[stop - 1][2], lambda t: t.clone())
 
     def replay(self, idx, state):
         self.ensure(idx, state)
