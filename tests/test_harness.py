@@ -55,3 +55,36 @@ def test_harness_writes_reference_outputs(tmp_path, monkeypatch):
     zeros = sum(int((v == 0).sum()) for k, v in sd.items() if ".blocks." in k and v.dim() == 2)
     total = sum(v.numel() for k, v in sd.items() if ".blocks." in k and v.dim() == 2)
     assert 0.45 < zeros / total < 0.56
+
+
+def test_sparsity_dict_yaml_reingest(tmp_path):
+    """`--sparsity_dict` short-circuits stage 1 (wanda_pruner.py:293-296, :571-585, :722-725):
+    a table written by one run drives stage 2 of the next, incl. the BLIP-2 -> ViT-only key
+    rewrite `visual_encoder.` -> `visual.`."""
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    import numpy as np
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.eva_clip import vit_toy
+    cfg = dict(prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+               max_sparsity_per_layer=0.6, score_method="MEZO-GradOnly_sum", num_data_first_stage=8,
+               kernels=OracleKernels(), z_source=torch_cpu_normal)
+    batches = S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5)
+    torch.manual_seed(1)
+    m1 = vit_toy().eval()
+    init = {k: v.clone() for k, v in m1.state_dict().items()}
+    np.random.seed(42)
+    m1, table = load_pruner("vit_wanda_pruner", m1, batches, cfg=cfg).prune()
+    path = tmp_path / "table.yaml"
+    # as the multi-modal pruner would have written it
+    yaml.dump({k.replace("visual.", "visual_encoder."): v for k, v in table.items()}, open(path, "w"))
+    m2 = vit_toy().eval()
+    m2.load_state_dict(init)
+    m2, table2 = load_pruner("vit_wanda_pruner", m2, batches,
+                             cfg=dict(cfg, sparsity_dict=str(path))).prune()
+    assert {k: v for k, v in table2.items() if "blocks.39" not in k} == table
+    z1 = {k: (v == 0) for k, v in m1.state_dict().items() if ".blocks." in k and v.dim() == 2}
+    z2 = {k: (v == 0) for k, v in m2.state_dict().items() if ".blocks." in k and v.dim() == 2}
+    # stage 2 on un-drifted weights: same per-matrix pruned counts as the table dictates
+    for k in z1:
+        assert int(z1[k].sum()) == int(z2[k].sum()), k
