@@ -6,23 +6,24 @@
 //
 // HBM-bound elementwise read-modify-write: one 16-byte vector per lane per
 // iteration (1 KiB per wave instruction), z produced in registers by
-// Philox4x32-10 + Box-Muller on the hardware log2/sqrt/sin/cos units (v_sin_f32
+// Philox4x32-R (R = ECOFLAP_PHILOX_ROUNDS) + Box-Muller on the hardware log2/sqrt/sin/cos units (v_sin_f32
 // takes revolutions, so 2*pi*u needs no multiply), three roundings to the storage
 // dtype per reference op, no fma contraction (-ffp-contract=off).
 // Algorithmic bytes: single pass 2*s per element; fused triple 4*s per element.
 #include "common.h"
 
-// ---------------------------------------------------------------- Philox4x32-10
+// ---------------------------------------------------------------- Philox4x32
 #define PHILOX_M0 0xD2511F53u
 #define PHILOX_M1 0xCD9E8D57u
 #define PHILOX_W0 0x9E3779B9u
 #define PHILOX_W1 0xBB67AE85u
 
-static __device__ __forceinline__ void philox4x32_10(uint64_t counter, uint32_t k0, uint32_t k1,
+static __device__ __forceinline__ void philox4x32(uint64_t counter, uint32_t k0, uint32_t k1,
                                                      uint32_t out[4]) {
+    // Philox4x32-R with R = ECOFLAP_PHILOX_ROUNDS (include/ecoflap_hip.h)
     uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ECOFLAP_PHILOX_ROUNDS; ++r) {
         // one v_mad_u64_u32 gives hi and lo of each 32x32 product
         const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
         const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
@@ -57,7 +58,7 @@ static __device__ __forceinline__ void gen_z(int64_t vec, uint32_t k0, uint32_t 
 #pragma unroll
     for (int q = 0; q < N / 4; ++q) {
         uint32_t r[4];
-        philox4x32_10((uint64_t)(vec * (N / 4) + q), k0, k1, r);
+        philox4x32((uint64_t)(vec * (N / 4) + q), k0, k1, r);
         box_muller(r[0], r[1], z[4 * q + 0], z[4 * q + 1]);
         box_muller(r[2], r[3], z[4 * q + 2], z[4 * q + 3]);
     }
@@ -75,7 +76,7 @@ static __device__ __forceinline__ void gen_z(int64_t vec, uint32_t k0, uint32_t 
 template <int DT>
 static __device__ __forceinline__ float gen_z1(int64_t e, uint32_t k0, uint32_t k1) {
     uint32_t r[4];
-    philox4x32_10((uint64_t)(e >> 2), k0, k1, r);
+    philox4x32((uint64_t)(e >> 2), k0, k1, r);
     float z[4];
     box_muller(r[0], r[1], z[0], z[1]);
     box_muller(r[2], r[3], z[2], z[3]);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void philox_u32_kernel(uint32_t* __restrict__ 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
         uint32_t r[4];
-        philox4x32_10((uint64_t)q, k0, k1, r);
+        philox4x32((uint64_t)q, k0, k1, r);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (q * 4 + i < n) out[q * 4 + i] = r[i];

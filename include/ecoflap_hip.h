@@ -44,6 +44,16 @@ extern "C" {
 #define ECOFLAP_EALIGN  (-5)
 #define ECOFLAP_EWORKSPACE (-6)
 
+/* Rounds of the in-register Philox4x32 generator (Salmon et al., SC'11).  7 is the
+ * smallest count the authors report as Crush-resistant (passes TestU01 BigCrush); 10 is the
+ * conventional safety margin.  The layer-batched K1 kernel is VALU-bound on the generator for
+ * bf16, so the build ships 7; set 10 here and rebuild for the
+ * conventional stream.  Parity with the reference never depends on this stream: it is taken
+ * with z supplied (z != NULL). */
+#ifndef ECOFLAP_PHILOX_ROUNDS
+#define ECOFLAP_PHILOX_ROUNDS 7
+#endif
+
 /* reduce modes of ecoflap_absprod_reduce* */
 #define ECOFLAP_RED_ABSW_ABSG 0 /* sum |w|*|g|   GradMagAbs     layer_single_base_pruner.py:455,467 */
 #define ECOFLAP_RED_SQW_SQG   1 /* sum w^2*g^2   GradMagSquare  :453,465 */
@@ -64,7 +74,7 @@ const char* ecoflap_error_string(int code);
  *     t = rd(z * scaling_factor);  u = rd(t * zo_eps);  w = rd(w + u)
  * z: if `z` != NULL it is a device array of n elements of `dtype` (parity
  * mode: the caller supplies the reference's own torch.normal draw); if NULL,
- * z is generated in registers: Philox4x32-10, key = seed, counter = e/4,
+ * z is generated in registers: Philox4x32-R (R = ECOFLAP_PHILOX_ROUNDS), key = seed, counter = e/4,
  * Box-Muller, rounded to `dtype` — the stream ecoflap_zo_fill_normal writes.
  * w must be 16-byte aligned (torch allocations are).
  * ------------------------------------------------------------------------- */
@@ -107,8 +117,8 @@ int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_eps,
 int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,
                            void* stream);
 
-/* Raw Philox4x32-10 words (counter = i/4, lane = i%4) — integer, bit-exact
- * against oracle/ecoflap_oracle.c:philox4x32_10. */
+/* Raw Philox4x32-R words (counter = i/4, lane = i%4) — integer, bit-exact
+ * against oracle/ecoflap_oracle.c:oracle_philox4x32. */
 int ecoflap_philox_u32(uint32_t* out, int64_t n, uint64_t seed, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -40,7 +40,8 @@ class Oracle:
                                  ctypes.c_void_p, ctypes.c_int)
         L.oracle_zo_perturb.argtypes = [vp, i64, ci, f32, f32, vp]
         L.oracle_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, vp]
-        L.oracle_philox_u32.argtypes = [vp, i64, u64]
+        L.oracle_philox_u32.argtypes = [vp, i64, u64, ci]
+        L.oracle_philox4x32.argtypes = [vp, vp, vp, ci]
         L.oracle_absprod_reduce.argtypes = [vp, vp, i64, ci, ci, ci]
         L.oracle_absprod_reduce.restype = ctypes.c_double
         L.oracle_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64]
@@ -61,10 +62,18 @@ class Oracle:
                                           DT[w.dtype], zo_eps, _p(z))
         return plus, minus, rest
 
-    def philox_u32(self, n, seed):
+    def philox_u32(self, n, seed, rounds):
         out = torch.empty(n, dtype=torch.int32)
-        self.lib.oracle_philox_u32(_p(out), n, seed)
+        self.lib.oracle_philox_u32(_p(out), n, seed, rounds)
         return out
+
+    def philox4x32(self, ctr, key, rounds):
+        import ctypes
+        c = (ctypes.c_uint32 * 4)(*ctr)
+        k = (ctypes.c_uint32 * 2)(*key)
+        out = (ctypes.c_uint32 * 4)()
+        self.lib.oracle_philox4x32(out, c, k, rounds)
+        return [int(v) for v in out]
 
     def absprod_reduce(self, w, g, mode):
         n = (w if w is not None else g).numel()

@@ -87,7 +87,7 @@ void oracle_round_array(float* x, int64_t n, int dt) {
     for (int64_t i = 0; i < n; ++i) x[i] = round_dt(x[i], dt);
 }
 
-/* ------------------------------------------------------------------ Philox4x32-10
+/* ------------------------------------------------------------------ Philox4x32-R
  * Published algorithm (Salmon et al., "Parallel random numbers: as easy as
  * 1, 2, 3", SC'11; Random123 philox.h).  The reference itself draws z with
  * torch.normal (P:485), whose stream is device specific; the build's
@@ -97,10 +97,10 @@ void oracle_round_array(float* x, int64_t n, int dt) {
 #define PHILOX_M1 0xCD9E8D57u
 #define PHILOX_W0 0x9E3779B9u
 #define PHILOX_W1 0xBB67AE85u
-void oracle_philox4x32_10(uint32_t out[4], uint64_t counter, uint64_t key) {
-    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0, c3 = 0;
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-    for (int r = 0; r < 10; ++r) {
+void oracle_philox4x32(uint32_t out[4], const uint32_t ctr[4], const uint32_t key[2], int rounds) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         uint32_t n1 = (uint32_t)p1;
@@ -111,10 +111,16 @@ void oracle_philox4x32_10(uint32_t out[4], uint64_t counter, uint64_t key) {
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-void oracle_philox_u32(uint32_t* out, int64_t n, uint64_t seed) {
+/* the build's stream: counter = (i/4, 0, 0), key = seed, `rounds` rounds */
+void oracle_philox_u32(uint32_t* out, int64_t n, uint64_t seed, int rounds) {
     uint32_t r[4];
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     for (int64_t i = 0; i < n; ++i) {
-        if ((i & 3) == 0 || i == 0) oracle_philox4x32_10(r, (uint64_t)(i >> 2), seed);
+        if ((i & 3) == 0) {
+            const uint64_t q = (uint64_t)(i >> 2);
+            const uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
+            oracle_philox4x32(r, ctr, key, rounds);
+        }
         out[i] = r[i & 3];
     }
 }

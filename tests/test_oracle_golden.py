@@ -77,10 +77,44 @@ def test_wrapped_gpt_running_mean(oracle, golden_dir):
 
 
 def test_philox_known_answer(oracle):
-    """Random123 known-answer vectors for philox4x32-10 (kat_vectors: counter/key all zero,
-    and all ones)."""
-    import ctypes
-    out = (ctypes.c_uint32 * 4)()
-    oracle.lib.oracle_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
-    oracle.lib.oracle_philox4x32_10(out, 0, 0)
-    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    """Random123 known-answer vectors (kat_vectors) for philox4x32 at 7 and 10 rounds:
+    all-zero, all-ones and the pi-digits counter/key."""
+    kat = [
+        (7, [0] * 4, [0] * 2, [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+        (10, [0] * 4, [0] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        (7, [0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+        (10, [0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        (7, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+        (10, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for rounds, ctr, key, want in kat:
+        assert oracle.philox4x32(ctr, key, rounds) == want, (rounds, ctr)
+
+
+def philox_rounds():
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "ecoflap_hip.h")).read()
+    return int(re.search(r"#define ECOFLAP_PHILOX_ROUNDS (\d+)", text).group(1))
+
+
+def test_philox_stream_bit_statistics(oracle):
+    """The build's word stream (rounds from the header): per-bit frequency, avalanche of a
+    one-bit counter change, and independence across adjacent keys."""
+    rounds = philox_rounds()
+    assert rounds in (7, 10)
+    n = 1 << 16
+    w = oracle.philox_u32(n, 123456789, rounds).numpy().astype(np.uint32)
+    bits = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.float64)
+    assert np.abs(bits.mean(0) - 0.5).max() < 4.5 * 0.5 / np.sqrt(n)           # monobit, each position
+    a = np.array([oracle.philox4x32([i, 0, 0, 0], [5, 6], rounds) for i in range(512)], dtype=np.uint32)
+    b = np.array([oracle.philox4x32([i ^ 1, 0, 0, 0], [5, 6], rounds) for i in range(512)], dtype=np.uint32)
+    flips = np.unpackbits((a ^ b).view(np.uint8)).mean()
+    assert abs(flips - 0.5) < 0.01                                               # avalanche
+    w2 = oracle.philox_u32(n, 123456790, rounds).numpy().astype(np.uint32)       # next key
+    x = w.astype(np.float64) / 2**32 - 0.5
+    y = w2.astype(np.float64) / 2**32 - 0.5
+    assert abs(np.corrcoef(x, y)[0, 1]) < 0.02
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.02
