@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libecoflap_hip.so")
+LIB_PATH = os.environ.get("ECOFLAP_HIP_LIB", os.path.join(_HERE, "libecoflap_hip.so"))
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
