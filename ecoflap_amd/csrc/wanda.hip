@@ -36,7 +36,30 @@ __global__ __launch_bounds__(256) void colsq_partial_kernel(const void* __restri
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.f;
     if (cvec < ncvec) {
-        for (int64_t r = r0 + wave; r < r1; r += 4) {
+        // four independent 16-byte loads in flight per lane before the first use
+        int64_t r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            float f0[N], f1[N], f2[N], f3[N];
+            if (VECTOR) {
+                const u32x4 a = ld16(x, r * ncvec + cvec), b = ld16(x, (r + 4) * ncvec + cvec);
+                const u32x4 c = ld16(x, (r + 8) * ncvec + cvec), d = ld16(x, (r + 12) * ncvec + cvec);
+                Vec<DT>::unpack(a, f0); Vec<DT>::unpack(b, f1);
+                Vec<DT>::unpack(c, f2); Vec<DT>::unpack(d, f3);
+            } else {
+                f0[0] = Vec<DT>::load1(x, r * cols + cvec);
+                f1[0] = Vec<DT>::load1(x, (r + 4) * cols + cvec);
+                f2[0] = Vec<DT>::load1(x, (r + 8) * cols + cvec);
+                f3[0] = Vec<DT>::load1(x, (r + 12) * cols + cvec);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {   // same order as the one-row-at-a-time loop below
+                acc[i] += f0[i] * f0[i];
+                acc[i] += f1[i] * f1[i];
+                acc[i] += f2[i] * f2[i];
+                acc[i] += f3[i] * f3[i];
+            }
+        }
+        for (; r < r1; r += 4) {
             float f[N];
             if (VECTOR) {
                 Vec<DT>::unpack(ld16(x, r * ncvec + cvec), f);
@@ -76,12 +99,13 @@ __global__ __launch_bounds__(256) void colsq_final_kernel(float* __restrict__ sc
 }
 
 static inline int colsq_rows_per_chunk(int64_t tokens, int64_t cols) {
-    // aim for >= ~1024 workgroups over the 256 CUs, at least 8 rows per workgroup
+    // ~512 workgroups over the 256 CUs, at least 64 rows (16 per wave) per workgroup so every
+    // lane keeps several loads in flight and the second stage sums few partials
     const int64_t colblocks = (cols / 4 + 63) / 64 + 1;
-    int64_t want_chunks = 1024 / colblocks;
+    int64_t want_chunks = 512 / colblocks;
     if (want_chunks < 1) want_chunks = 1;
     int64_t rpc = (tokens + want_chunks - 1) / want_chunks;
-    if (rpc < 8) rpc = 8;
+    if (rpc < 64) rpc = 64;
     return (int)rpc;
 }
 static inline int colsq_nchunks(int64_t tokens, int64_t cols) {
@@ -502,76 +526,149 @@ static int launch_rows_reg(void* w, const float* sq, int64_t rows, int64_t cols,
 // (11 + 11 + 10 bits), then zero metric <= threshold.
 // =====================================================================================
 struct MatrixSelState {
-    uint32_t prefix;       // selected high bits so far
-    uint32_t remaining;    // 1-indexed rank still to resolve inside the selected bin
     uint32_t hist[3][2048];
 };
 
-template <int DT, int PASS>
+// Every workgroup resolves the previous passes itself from the global histograms (8 KB each,
+// L2-resident): bin = first bin whose inclusive count reaches `remaining`.  Identical in every
+// workgroup, so no separate "pick" launch and no inter-workgroup hand-off is needed.
+static __device__ __forceinline__ void pick_bin(const uint32_t* __restrict__ hist, int bins,
+                                                uint32_t remaining, uint32_t* wave4,
+                                                uint32_t* out2 /* LDS: bin, new remaining */) {
+    uint32_t carry = 0;
+    for (int base = 0; base < bins; base += 256) {
+        const uint32_t cnt = hist[base + threadIdx.x];
+        uint32_t total;
+        const uint32_t incl = block_scan_256(cnt, wave4, total) + carry;
+        const uint32_t excl = incl - cnt;
+        if (excl < remaining && remaining <= incl) {
+            out2[0] = (uint32_t)(base + threadIdx.x);
+            out2[1] = remaining - excl;
+        }
+        carry += total;
+    }
+    __syncthreads();
+}
+
+// prefix (selected high bits) and remaining rank after `upto` resolved passes
+static __device__ __forceinline__ void resolve(const MatrixSelState* st, int upto, uint32_t rank0,
+                                               uint32_t* wave4, uint32_t* out2, uint32_t& prefix,
+                                               uint32_t& remaining) {
+    prefix = 0;
+    remaining = rank0;
+    if (upto >= 1) {
+        pick_bin(st->hist[0], 2048, remaining, wave4, out2);
+        prefix |= out2[0] << 21; remaining = out2[1];
+        __syncthreads();
+    }
+    if (upto >= 2) {
+        pick_bin(st->hist[1], 2048, remaining, wave4, out2);
+        prefix |= out2[0] << 10; remaining = out2[1];
+        __syncthreads();
+    }
+    if (upto >= 3) {
+        pick_bin(st->hist[2], 1024, remaining, wave4, out2);
+        prefix |= out2[0]; remaining = out2[1];
+        __syncthreads();
+    }
+}
+
+template <int DT, int PASS, bool VECTOR>
 __global__ __launch_bounds__(256) void wanda_matrix_hist_kernel(const void* __restrict__ w,
                                                                 const float* __restrict__ sq,
-                                                                int64_t n, int64_t cols,
-                                                                MatrixSelState* st) {
+                                                                int64_t rows, int64_t cols,
+                                                                uint32_t rank0, MatrixSelState* st) {
     constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
     constexpr int BITS = PASS == 2 ? 10 : 11;
     constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    constexpr int N = Vec<DT>::N;
     __shared__ uint32_t h[2048];
+    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t out2[2];
     for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+    uint32_t prefix, remaining;
+    resolve(st, PASS, rank0, wave4, out2, prefix, remaining);
     __syncthreads();
-    const uint32_t prefix = (PASS == 0) ? 0u : st->prefix;
-    const int64_t rows = n / cols;
-    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        for (int64_t c = threadIdx.x; c < cols; c += 256) {
-            const uint32_t b = metric_bits<DT>(w, r * cols + c, sq[c]);
-            if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+    if (VECTOR) {
+        const int64_t vpr = cols / N;                 // vectors per row
+        const int64_t nvec = rows * vpr;
+        for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+            const int64_t c0 = (v % vpr) * N;
+            float f[N];
+            Vec<DT>::unpack(ld16(w, v), f);
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld16(sq, c0 / 4 + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+                    if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+                }
+            }
         }
+    } else {
+        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+            for (int64_t c = threadIdx.x; c < cols; c += 256) {
+                const uint32_t b = metric_bits<DT>(w, r * cols + c, sq[c]);
+                if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+            }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (1 << BITS); i += 256)
         if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
 }
 
-template <int PASS>
-__global__ __launch_bounds__(256) void wanda_matrix_pick_kernel(MatrixSelState* st, uint32_t rank0) {
-    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
-    constexpr int BINS = PASS == 2 ? 1024 : 2048;
-    __shared__ uint32_t wave4[4];
-    __shared__ uint32_t carry;
-    const uint32_t remaining = (PASS == 0) ? rank0 : st->remaining;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < BINS; base += 256) {
-        const uint32_t cnt = st->hist[PASS][base + threadIdx.x];
-        uint32_t total;
-        const uint32_t incl = block_scan_256(cnt, wave4, total) + carry;
-        const uint32_t excl = incl - cnt;
-        if (excl < remaining && remaining <= incl) {
-            st->prefix = ((PASS == 0) ? 0u : st->prefix) | ((uint32_t)(base + threadIdx.x) << SHIFT);
-            st->remaining = remaining - excl;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
-    }
-}
-
-template <int DT>
+template <int DT, bool VECTOR>
 __global__ __launch_bounds__(256) void wanda_matrix_apply_kernel(void* w,
                                                                  const float* __restrict__ sq,
-                                                                 int64_t n, int64_t cols,
+                                                                 int64_t rows, int64_t cols,
+                                                                 uint32_t rank0,
                                                                  const MatrixSelState* st,
                                                                  uint8_t* mask_out) {
-    const uint32_t thres = st->prefix;
-    const int64_t rows = n / cols;
-    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        for (int64_t c = threadIdx.x; c < cols; c += 256) {
-            const int64_t i = r * cols + c;
-            // W_metric <= thres (W:556): false for NaN metrics, as in torch
-            const float mval = __uint_as_float(metric_bits<DT>(w, i, sq[c]));
-            const bool prune = mval <= __uint_as_float(thres);
-            if (prune) Vec<DT>::store1(w, i, 0.0f);
-            if (mask_out) mask_out[i] = prune ? 1 : 0;
+    constexpr int N = Vec<DT>::N;
+    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t out2[2];
+    uint32_t thres_bits, remaining;
+    resolve(st, 3, rank0, wave4, out2, thres_bits, remaining);
+    const float thres = __uint_as_float(thres_bits);
+    if (VECTOR) {
+        const int64_t vpr = cols / N;
+        const int64_t nvec = rows * vpr;
+        for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+            const int64_t c0 = (v % vpr) * N;
+            float f[N];
+            Vec<DT>::unpack(ld16(w, v), f);
+            uint32_t lo = 0, hi = 0;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld16(sq, c0 / 4 + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * q + i;
+                    // W_metric <= thres (W:556): false for NaN metrics, as in torch
+                    const bool prune = (__builtin_fabsf(f[e]) * __uint_as_float(s4[i])) <= thres;
+                    if (prune) { f[e] = 0.0f; any = true; }
+                    if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
+                    else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
+                }
+            }
+            if (any) st16(w, v, Vec<DT>::pack(f));
+            if (mask_out) {
+                uint8_t* m = mask_out + v * N;
+                *(uint32_t*)m = lo;
+                if (N == 8) *(uint32_t*)(m + 4) = hi;
+            }
         }
+    } else {
+        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+            for (int64_t c = threadIdx.x; c < cols; c += 256) {
+                const int64_t i = r * cols + c;
+                const float mval = __uint_as_float(metric_bits<DT>(w, i, sq[c]));
+                const bool prune = mval <= thres;
+                if (prune) Vec<DT>::store1(w, i, 0.0f);
+                if (mask_out) mask_out[i] = prune ? 1 : 0;
+            }
     }
 }
 
@@ -637,17 +734,21 @@ extern "C" int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_
 template <int DT>
 static int wanda_matrix_launch(void* w, const float* sq, int64_t n, int64_t cols, int64_t k,
                                MatrixSelState* st, uint8_t* mask_out, hipStream_t s) {
-    int64_t b = n / cols;  // one row per workgroup per sweep
-    if (b > 2048) b = 2048;
+    const int64_t rows = n / cols;
+    const bool vector = (cols % Vec<DT>::N == 0) && aligned16(w) && aligned16(sq) &&
+                        (!mask_out || (((uintptr_t)mask_out) & 7u) == 0);
+    int64_t b = vector ? (n / Vec<DT>::N + 255) / 256 : rows;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
     const dim3 grid((unsigned)b), blk(256);
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 0>), grid, blk, 0, s, w, sq, n, cols, st);
-    hipLaunchKernelGGL((wanda_matrix_pick_kernel<0>), dim3(1), blk, 0, s, st, (uint32_t)(k + 1));
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 1>), grid, blk, 0, s, w, sq, n, cols, st);
-    hipLaunchKernelGGL((wanda_matrix_pick_kernel<1>), dim3(1), blk, 0, s, st, 0u);
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 2>), grid, blk, 0, s, w, sq, n, cols, st);
-    hipLaunchKernelGGL((wanda_matrix_pick_kernel<2>), dim3(1), blk, 0, s, st, 0u);
-    hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT>), grid, blk, 0, s, w, sq, n, cols, st,
-                       mask_out);
+    const uint32_t rank0 = (uint32_t)(k + 1);      // sorted[k], 0-indexed -> (k+1)-th smallest
+#define MATRIX_PASSES(V)                                                                        \
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 0, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 1, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
+    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 2, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
+    hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st, mask_out)
+    if (vector) { MATRIX_PASSES(true); } else { MATRIX_PASSES(false); }
+#undef MATRIX_PASSES
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
