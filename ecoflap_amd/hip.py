@@ -25,6 +25,7 @@ EXPORTS = [
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
     "ecoflap_wanda_prune_matrix", "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
+    "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
 ]
 
 
@@ -70,6 +71,8 @@ def load_library():
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_mask_mul.argtypes = [vp, vp, i64, ci, vp]
+    lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
+    lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
     lib.ecoflap_allocate_sparsity.argtypes = [vp, vp, ci, i64, f64, vp, vp]
     _lib = lib
     return lib
@@ -270,6 +273,18 @@ class HipKernels:
     def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
         self._wanda(self.lib.ecoflap_wanda_prune_matrix, "ecoflap_wanda_prune_matrix", w,
                     scaler_row, k, mask_out)
+
+    # ---- SparseGPT ------------------------------------------------------------------------
+    def sparsegpt_block(self, W, Hinv, i1, count, k, err_out, mask_out=None):
+        """One <=128-column block of SparseGPT.fasterprune on the fp32 working copy W."""
+        _gpu(W, "W"), _gpu(Hinv, "Hinv"), _gpu(err_out, "err_out")
+        if W.dtype != torch.float32 or Hinv.dtype != torch.float32:
+            raise EcoflapHipError("SparseGPT works on fp32 copies, as the reference does")
+        ws = self.ws.get(self.lib.ecoflap_sparsegpt_workspace_bytes(), W.device)
+        _check(self.lib.ecoflap_sparsegpt_block(
+            _ptr(W), W.shape[0], W.stride(0), _ptr(Hinv), Hinv.stride(0), int(i1), int(count),
+            int(k), None, _ptr(err_out), _ptr(mask_out), _ptr(ws), ws.numel(), _stream()),
+            "ecoflap_sparsegpt_block")
 
     # ---- K8 ---------------------------------------------------------------------------
     def mask_mul(self, g, keep_mask):

@@ -8,3 +8,6 @@ from .losses import loss_language, loss_vision, loss_vision_language  # noqa: F4
 from .upop import (  # noqa: F401,E402
     BLIPBertLayerWandaPruner, apply_masks_to_grads, pruning_masks, task_forward,
 )
+from .sparsegpt import (  # noqa: F401,E402
+    BLIPT5LayerSparseGPTPruner, SparseGPT, T5LayerSparseGPTPruner, VITLayerSparseGPTPruner,
+)

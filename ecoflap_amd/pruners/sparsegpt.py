@@ -1,0 +1,111 @@
+"""SparseGPT local pruning driven by the ECoFLaP sparsity table.
+
+Host-side mirror of LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:
+  SparseGPT (:56-222): Hessian accumulation, damped Cholesky x2, blockwise OBS sweep
+  T5 / VIT / BLIPT5 LayerSparseGPTPruner (:226-963): same block-sequential loop as the Wanda
+  pruners with SparseGPT in place of WrappedGPT; registered names kept.
+
+The Hessian update and the trailing update are plain GEMMs (torch.addmm -> hipBLASLt) and the
+factorisations are rocSOLVER calls; the per-block threshold + sequential sweep, which torch
+runs as ~1000 small kernels per 128 columns, is one fused HIP step
+(`ecoflap_sparsegpt_block`, csrc/sparsegpt.hip).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import hip as _hip
+from ..registry import registry
+from .wanda import BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPruner
+
+
+class SparseGPT:
+    def __init__(self, layer, kernels=None):
+        self.layer = layer
+        self.dev = self.layer.weight.device
+        W = layer.weight.data
+        assert isinstance(layer, nn.Linear), "the path only prunes nn.Linear"
+        self.rows = W.shape[0]
+        self.columns = W.shape[1]
+        self.H = torch.zeros((self.columns, self.columns), device=self.dev)
+        self.nsamples = 0
+        self.kernels = kernels if kernels is not None else _hip.HipKernels()
+
+    def add_batch(self, inp, out):
+        """H <- H * n/(n+b) + (sqrt(2/(n+b)) x)^T (sqrt(2/(n+b)) x)   (:71-82)"""
+        if len(inp.shape) == 2:
+            inp = inp.unsqueeze(0)
+        tmp = inp.shape[0]
+        x = inp.reshape((-1, inp.shape[-1]))
+        self.H *= self.nsamples / (self.nsamples + tmp)
+        self.nsamples += tmp
+        xs = math.sqrt(2 / self.nsamples) * x.float()
+        self.H.addmm_(xs.t(), xs)
+
+    @staticmethod
+    def _clamp_inf(H):
+        if (torch.isinf(H) * (H > 0)).float().sum() > 0:          # (:104-112, :136-144)
+            H[torch.isinf(H) * (H > 0)] = torch.quantile(H, 0.999)
+        if (torch.isinf(H) * (H < 0)).float().sum() > 0:
+            H[torch.isinf(H) * (H < 0)] = torch.quantile(H, 0.001)
+
+    @staticmethod
+    def _damped_cholesky(H, damp, upper):
+        diag = torch.arange(H.shape[0], device=H.device)
+        for _ in range(10000):                                    # the reference loops forever
+            L, info = torch.linalg.cholesky_ex(H, upper=upper)
+            if int(info) == 0 and not torch.isnan(L).any():
+                return L
+            H[diag, diag] += damp                                 # not positive definite yet
+        raise RuntimeError("Hessian could not be made positive definite")
+
+    def fasterprune(self, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=.01):
+        if prune_n != 0:
+            raise NotImplementedError("N:M sparsity: prune_n is always 0 in the reference "
+                                      "(layer_single_base_pruner.py:62)")
+        W = self.layer.weight.data.clone().float()
+        H = self.H
+        del self.H
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        W[:, dead] = 0
+        self._clamp_inf(H)
+        damp = percdamp * torch.mean(torch.diag(H))
+        H = self._damped_cholesky(H, damp, upper=False)
+        H = torch.cholesky_inverse(H)
+        self._clamp_inf(H)
+        damp = percdamp * torch.mean(torch.diag(H).abs())
+        Hinv = self._damped_cholesky(H, damp, upper=True).contiguous()
+        for i1 in range(0, self.columns, blocksize):
+            i2 = min(i1 + blocksize, self.columns)
+            count = i2 - i1
+            err = torch.empty((self.rows, count), dtype=torch.float32, device=W.device)
+            k = int(self.rows * count * sparsity)                 # int(tmp.numel() * sparsity) (:187)
+            self.kernels.sparsegpt_block(W, Hinv, i1, count, k, err)
+            if i2 < self.columns:
+                W[:, i2:] -= err.matmul(Hinv[i1:i2, i2:])         # (:216)
+        self.layer.weight.data = W.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
+
+    def free(self):
+        self.H = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+
+@registry.register_pruner("t5_sparsegpt_pruner")
+class T5LayerSparseGPTPruner(T5LayerWandaPruner):
+    pruner_name = "t5_sparsegpt_pruner"
+    local_method = "sparsegpt"
+
+
+@registry.register_pruner("vit_sparsegpt_pruner")
+class VITLayerSparseGPTPruner(VITLayerWandaPruner):
+    pruner_name = "vit_sparsegpt_pruner"
+    local_method = "sparsegpt"
+
+
+@registry.register_pruner("blipt5_sparsegpt_pruner")
+class BLIPT5LayerSparseGPTPruner(BLIPT5LayerWandaPruner):
+    pruner_name = "blipt5_sparsegpt_pruner"
+    local_method = "sparsegpt"

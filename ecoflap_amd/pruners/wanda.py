@@ -186,7 +186,12 @@ class _BlockwiseWanda:
         for i in range(len(blocks)):
             block = blocks[i]
             subset = find_layers(block)
-            wrapped = {name: WrappedGPT(subset[name], kernels=self.kernels) for name in subset}
+            sparsegpt = getattr(self.owner, "local_method", "wanda") == "sparsegpt"
+            if sparsegpt:
+                from .sparsegpt import SparseGPT
+                wrapped = {name: SparseGPT(subset[name], kernels=self.kernels) for name in subset}
+            else:
+                wrapped = {name: WrappedGPT(subset[name], kernels=self.kernels) for name in subset}
             handles = [
                 subset[name].register_forward_hook(
                     lambda _m, inp, out, _n=name: wrapped[_n].add_batch(inp[0].data, out.data))
@@ -196,12 +201,20 @@ class _BlockwiseWanda:
                 outs[j] = call(block, j)
             for h in handles:
                 h.remove()
-            self._merge_statistics(wrapped)
+            if not sparsegpt:
+                self._merge_statistics(wrapped)
+            elif self._rank_world()[1] > 1:
+                raise NotImplementedError("data-parallel SparseGPT (all-reduce of the Hessians)")
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps)
                 weight = subset[name].weight.data
                 ratio = sparsity_ratio[f"{module_to_process}.{i}.{name}.weight"]
-                if mode == "rows":      # per output row, k smallest by stable order (:272-279)
+                if sparsegpt:           # sparsegpt_pruner.py:394 / :650
+                    wrapped[name].fasterprune(ratio, prune_n=self.owner.prune_n,
+                                              prune_m=self.owner.prune_m, percdamp=0.01,
+                                              blocksize=128)
+                    wrapped[name].free()
+                elif mode == "rows":      # per output row, k smallest by stable order (:272-279)
                     k = int(weight.shape[1] * ratio)
                     self.kernels.wanda_prune_rows(weight, wrapped[name].scaler_row, k)
                 else:                   # whole matrix, metric <= sorted[k] (:555-558)

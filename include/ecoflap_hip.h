@@ -177,6 +177,23 @@ int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
                                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * SparseGPT block step
+ * replaces the inner block of SparseGPT.fasterprune
+ *   LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:172-216
+ * for columns [i1, i1+count), count <= 128, of the fp32 working copy W[rows, ldw]:
+ *   threshold of W1**2/diag(Hinv1)**2 at rank k = int(rows*count*sparsity) (:186-188),
+ *   the sequential OBS sweep (:192-210), W[:, i1:i1+count] = Q1 (:212) and Err1 into err_out
+ *   (the caller applies W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:], :216, with a library GEMM).
+ * Hinv: float[cols, ldh], the upper Cholesky factor the reference calls Hinv (:162).
+ * mask_in (optional) replaces the threshold by a given uint8[rows*count] mask.
+ * ------------------------------------------------------------------------- */
+size_t ecoflap_sparsegpt_workspace_bytes(void);
+int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hinv,
+                            int64_t ldh, int64_t i1, int count, int64_t k,
+                            const uint8_t* mask_in, float* err_out, uint8_t* mask_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * K8  mask apply in masked fine-tuning:  grad *= mask
  * replaces UPop/ecoflap_compression_vqa.py:124-129
  * keep_mask: uint8[n], 1 = keep (multiply by 1), 0 = pruned (multiply by 0).

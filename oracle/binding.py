@@ -49,6 +49,7 @@ class Oracle:
         L.oracle_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp]
         L.oracle_mask_mul.argtypes = [vp, vp, i64, ci]
         L.oracle_round_array.argtypes = [vp, i64, ci]
+        L.oracle_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp]
 
     def zo_perturb(self, w, scaling_factor, zo_eps, z):
         _cpu(w), _cpu(z)
@@ -108,6 +109,14 @@ class Oracle:
     def mask_mul(self, g, keep):
         _cpu(g), _cpu(keep)
         self.lib.oracle_mask_mul(_p(g), _p(keep), g.numel(), DT[g.dtype])
+
+    def sparsegpt_block(self, W, Hinv, i1, count, k, err_out, mask_out=None):
+        """W, Hinv: fp32 CPU tensors (row strides taken from the tensors), in place on W."""
+        assert W.dtype == torch.float32 and Hinv.dtype == torch.float32
+        assert W.stride(1) == 1 and Hinv.stride(1) == 1
+        self.lib.oracle_sparsegpt_block(_p(W), W.shape[0], W.stride(0), _p(Hinv), Hinv.stride(0),
+                                        i1, count, k, _p(err_out),
+                                        _p(mask_out) if mask_out is not None else None)
 
     def round_array(self, x, dtype):
         _cpu(x)

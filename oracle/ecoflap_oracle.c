@@ -255,3 +255,43 @@ void oracle_mask_mul(void* g, const uint8_t* keep, int64_t n, int dt) {
     for (int64_t i = 0; i < n; ++i)
         store_dt(g, i, dt, load_dt(g, i, dt) * (keep[i] ? 1.0f : 0.0f));
 }
+
+/* ------------------------------------------------------------------ SparseGPT block step
+ * LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:172-216 for columns [i1, i1+count) of the
+ * fp32 working copy W[rows, ldw]; Hinv[cols, ldh] is the upper Cholesky factor (:162).
+ * tmp = W1**2 / diag(Hinv1)**2; thresh = sorted(tmp.flatten())[k]; mask1 = tmp <= thresh;
+ * sequential column sweep with the reference's op order (product, then subtract).  The
+ * trailing GEMM (:216) stays with the caller. */
+void oracle_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hinv, int64_t ldh,
+                            int64_t i1, int count, int64_t k, float* err_out, uint8_t* mask_out) {
+    int64_t n = rows * count;
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
+    float* srt = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int c = 0; c < count; ++c) {
+            float w = W[r * ldw + i1 + c], d = Hinv[(i1 + c) * ldh + i1 + c];
+            float a = w * w, b = d * d;
+            tmp[r * count + c] = a / b;
+        }
+    memcpy(srt, tmp, sizeof(float) * (size_t)n);
+    qsort(srt, (size_t)n, sizeof(float), cmp_f);
+    float thresh = srt[k];
+    float* w1 = (float*)malloc(sizeof(float) * (size_t)count);
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int c = 0; c < count; ++c) w1[c] = W[r * ldw + i1 + c];
+        for (int i = 0; i < count; ++i) {
+            int masked = tmp[r * count + i] <= thresh;
+            float wi = w1[i], d = Hinv[(i1 + i) * ldh + i1 + i];
+            float q = masked ? 0.0f : wi;
+            float err = (wi - q) / d;
+            for (int j = i; j < count; ++j) {
+                float p = err * Hinv[(i1 + i) * ldh + i1 + j];
+                w1[j] = w1[j] - p;
+            }
+            W[r * ldw + i1 + i] = q;
+            err_out[r * count + i] = err;
+            if (mask_out) mask_out[r * count + i] = (uint8_t)masked;
+        }
+    }
+    free(tmp); free(srt); free(w1);
+}

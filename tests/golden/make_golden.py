@@ -396,6 +396,68 @@ def golden_upop():
     save("g9_upop_vqa.npz", **out)
 
 
+# --------------------------------------------------------------------------- G10: SparseGPT
+def golden_sparsegpt(registry):
+    """The reference's SparseGPT object on single Linear layers (Hessian, damped Cholesky,
+    blockwise sweep) and its three pruners end to end on the toy models (batch size 1, as the
+    reference's `nsamples == len(inps)` assertion requires)."""
+    base = os.path.join(REF, "LAVIS/lavis/compression/pruners")
+    name = "lavis.compression.pruners.sparsegpt_pruner"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(base, "sparsegpt_pruner.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    torch.cuda.synchronize = lambda *a, **k: None   # the reference syncs unconditionally (:218); CPU run
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for tag, rows, cols, sparsity, dead in [("a", 40, 300, 0.5, False), ("b", 24, 128, 0.37, False),
+                                            ("c", 16, 200, 0.6, True)]:
+        lin = nn.Linear(cols, rows, bias=False)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(rows, cols, generator=g) * 0.1)
+        sg = mod.SparseGPT(lin)
+        out[f"{tag}_w0"] = bits(lin.weight.data)
+        for bi in range(3):
+            x = torch.randn(2, 9, cols, generator=g)
+            if dead:
+                x[..., 5] = 0
+                x[..., 77] = 0
+            out[f"{tag}_x{bi}"] = bits(x)
+            sg.add_batch(x, None)
+        out[f"{tag}_H"] = bits(sg.H)
+        sg.fasterprune(sparsity, prune_n=0, prune_m=0, percdamp=0.01, blocksize=128)
+        out[f"{tag}_w1"] = bits(lin.weight.data)
+        cases.append(f"{tag}|{rows}|{cols}|{sparsity}")
+    out["cases"] = np.array(cases)
+
+    def run(tag, pname, model, batches, cfg):
+        for k, v in model.state_dict().items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        pruner = registry.get_pruner_class(pname)(model=model, data_loader=batches, **cfg)
+        model2, sp = pruner.prune()
+        for k, v in model2.state_dict().items():
+            out[f"{tag}_final::{k}"] = bits(v)
+
+    cfgbase = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                   is_global=False, sparsity_dict=None, iteration=1, num_noise=1, noise_eps=1e-3,
+                   num_samples=8, max_sparsity_per_layer=0.6, num_data_first_stage=8)
+    torch.manual_seed(41)
+    run("vit", "vit_sparsegpt_pruner", vit_toy().eval(),
+        S.image_label_batches(8, 1, img_size=32, num_classes=5, seed=5),
+        dict(cfgbase, prune_spec="3-0.5-1.0-1.0", sparsity_ratio_granularity=None,
+             score_method="MEZO-GradOnly_sum"))
+    torch.manual_seed(43)
+    run("blip2", "blipt5_sparsegpt_pruner", blip2_toy().eval(),
+        S.image_text_batches(8, 1, img_size=28, vocab=96, in_len=5, out_len=4, seed=6),
+        dict(cfgbase, t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+             t5_pruning_method="none", vit_pruning_method="none",
+             sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum"))
+    save("g10_sparsegpt.npz", **out)
+
+
 def golden_names():
     d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
                    map_location="cpu", weights_only=False)
@@ -408,7 +470,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # fixed reduction order for the committed vectors
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
-    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop"]
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt"]
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:
@@ -423,3 +485,5 @@ if __name__ == "__main__":
         golden_names()
     if "upop" in only:
         golden_upop()
+    if "sparsegpt" in only:
+        golden_sparsegpt(registry)

@@ -77,6 +77,16 @@ class OracleKernels:
         if mask_out is not None:
             mask_out.copy_(m)
 
+    def sparsegpt_block(self, W, Hinv, i1, count, k, err_out, mask_out=None):
+        h = self._host(W)
+        e = torch.empty(err_out.shape, dtype=torch.float32)
+        m = torch.zeros(err_out.shape, dtype=torch.uint8) if mask_out is not None else None
+        self.o.sparsegpt_block(h, self._host(Hinv), i1, count, k, e, m)
+        W.copy_(h)
+        err_out.copy_(e)
+        if mask_out is not None:
+            mask_out.copy_(m)
+
     def mask_mul(self, g, keep_mask):
         h = self._host(g)
         self.o.mask_mul(h, self._host(keep_mask))

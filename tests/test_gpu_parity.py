@@ -497,6 +497,54 @@ def test_upop_vqa_hip_equals_oracle(kern, golden_dir, mode):
         assert torch.equal(p.grad, want[k]), k
 
 
+@pytest.mark.parametrize("rows,cols,i1,count,frac", [(40, 300, 0, 128, 0.5), (40, 300, 256, 44, 0.37),
+                                                     (6144, 1408, 128, 128, 0.5), (7, 128, 0, 128, 0.9),
+                                                     (2048, 5120, 4992, 128, 0.41)])
+def test_sparsegpt_block_vs_oracle(kern, oracle, rows, cols, i1, count, frac):
+    """Threshold + sequential sweep of one SparseGPT block: bit-exact against the oracle
+    (weights, Err1, mask), incl. BASELINE-size matrices."""
+    torch.manual_seed(rows + cols)
+    W = torch.randn(rows, cols) * 0.05
+    A = torch.randn(cols, cols) * 0.1
+    Hinv = torch.linalg.cholesky(A @ A.t() + torch.eye(cols), upper=True).contiguous()
+    k = int(rows * count * frac)
+    Wg, Hg = gpu(W.clone()), gpu(Hinv)
+    err = torch.empty(rows, count, device="cuda")
+    mask = torch.zeros(rows, count, dtype=torch.uint8, device="cuda")
+    kern.lib.ecoflap_sparsegpt_block  # symbol present
+    import ctypes
+    from ecoflap_amd import hip as H
+    ws = kern.ws.get(kern.lib.ecoflap_sparsegpt_workspace_bytes(), Wg.device)
+    rc = kern.lib.ecoflap_sparsegpt_block(
+        ctypes.c_void_p(Wg.data_ptr()), rows, cols, ctypes.c_void_p(Hg.data_ptr()), cols, i1, count, k,
+        None, ctypes.c_void_p(err.data_ptr()), ctypes.c_void_p(mask.data_ptr()),
+        ctypes.c_void_p(ws.data_ptr()), ws.numel(), H._stream())
+    assert rc == 0
+    Wr = W.clone()
+    er = torch.empty(rows, count)
+    mr = torch.zeros(rows, count, dtype=torch.uint8)
+    oracle.sparsegpt_block(Wr, Hinv, i1, count, k, er, mr)
+    assert torch.equal(mask.cpu(), mr)
+    assert torch.equal(Wg.cpu().view(torch.int32), Wr.view(torch.int32))
+    assert torch.equal(err.cpu().view(torch.int32), er.view(torch.int32))
+    assert int(mr.sum()) >= k + 1
+
+
+@pytest.mark.parametrize("tag", ["vit", "blip2"])
+def test_sparsegpt_pruners_hip_equals_oracle(kern, golden_dir, tag):
+    from oracle_backend import OracleKernels
+    from test_sparsegpt_parity import run_sparsegpt_e2e
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model, table = run_sparsegpt_e2e(tag, golden_dir, backend, device="cuda")
+        res[name] = (table, {k: v.cpu() for k, v in model.state_dict().items()})
+    assert res["hip"][0] == res["oracle"][0]
+    for k, v in res["hip"][1].items():
+        assert torch.equal(v, res["oracle"][1][k]), k
+    pruned = sum(int((v == 0).sum()) for k, v in res["hip"][1].items() if v.dim() == 2 and ".block" in k)
+    assert pruned > 0
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused
