@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""BLIP-2 shape: ECoFLaP zeroth-order table + SparseGPT local prune, end to end on the GPU
+(reference: scripts/blip2/ecoflap_sparsegpt_zeroth.py; its committed run took 6801 s)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecoflap_amd import harness  # noqa: E402
+
+args = ["--shape", "blip2", "--pruning_method", "blipt5_sparsegpt_pruner", "--score_method",
+        "MEZO-GradOnly_sum", "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.5",
+        "--prunining_dataset_batch_size", "1", "--num_data", "128", "--num_data_first_stage", "32",
+        "--t5_prune_spec", "24-0.4-1.0-1.0", "--vit_prune_spec", "39-0.4-1.0-1.0"] + sys.argv[1:]
+t0 = time.time()
+model, table = harness.main(args)
+torch.cuda.synchronize()
+blocks = {k: v for k, v in model.state_dict().items() if v.dim() == 2 and ".block" in k
+          and "relative_attention_bias" not in k}
+zeros = sum(int((v == 0).sum()) for v in blocks.values())
+total = sum(v.numel() for v in blocks.values())
+print(json.dumps({"wall_seconds": time.time() - t0, "pruned_fraction": zeros / total,
+                  "stage_stats": getattr(harness.main, "last_stage_stats", None),
+                  "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}, default=str))
