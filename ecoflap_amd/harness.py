@@ -99,10 +99,10 @@ def config_dict(args):
         "prune_per_model": args.prune_per_model,
         "iteration": args.iteration,
     }
-    if args.pruning_method == "blipt5_wanda_pruner":
+    if str(args.pruning_method).startswith("blipt5_"):
         cfg.update(t5_prune_spec=args.t5_prune_spec, vit_prune_spec=args.vit_prune_spec,
                    t5_pruning_method="none", vit_pruning_method="none")
-    elif args.pruning_method == "t5_wanda_pruner":
+    elif str(args.pruning_method).startswith("t5_"):
         cfg.update(prune_spec=args.t5_prune_spec)
     else:
         cfg.update(prune_spec=args.vit_prune_spec)
