@@ -13,7 +13,7 @@ ratio = 0.4
 ratios = f"{ratio}-1.0-1.0"
 job_id = f"cc3m-{method}_{ratios}_olmezo-gradient_sum0.7_block"
 table = f" --sparsity_dict {sys.argv.pop(3)}" if len(sys.argv) > 3 else (
-    " --score_method MEZO-GradOnly_sum --sparsity_ratio_granularity block --max_sparsity_per_layer 0.5")
+    " --score_method MEZO-GradOnly_sum --sparsity_ratio_granularity block --max_sparsity_per_layer 0.7")
 
 sys.exit(launch("blip2", (
     f"--pruning_method '{method}' --save_pruned_model{table}"

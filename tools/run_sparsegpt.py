@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecoflap_amd import harness  # noqa: E402
 
 args = ["--shape", "blip2", "--pruning_method", "blipt5_sparsegpt_pruner", "--score_method",
-        "MEZO-GradOnly_sum", "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.5",
+        "MEZO-GradOnly_sum", "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.7",
         "--prunining_dataset_batch_size", "1", "--num_data", "128", "--num_data_first_stage", "32",
         "--t5_prune_spec", "24-0.4-1.0-1.0", "--vit_prune_spec", "39-0.4-1.0-1.0"] + sys.argv[1:]
 t0 = time.time()
