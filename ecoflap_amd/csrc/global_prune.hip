@@ -1,0 +1,244 @@
+// global_prune.hip — "Real-*" global iterative pruning kernels for gfx950.
+//
+// Replaces, in LayerSparsity.global_iterative_pruning / get_mask
+//   LAVIS/lavis/compression/pruners/layer_single_base_pruner.py:156-245 and the per-element
+//   part of compute_importance_scores (:446-471):
+//     acc[k] += g.float().abs()                       (:455; also for Real-GradMagSquare, whose
+//                                                       name fails the equality test at :452)
+//     acc[k] /= n_batches; score = |W|*|acc|, W^2*acc or |acc|      (:461-469)
+//     score *= mask                                    (:221-224)
+//     threshold = k-th smallest of cat(all scores)     (:170-175, torch.topk over 3.7 G values)
+//     mask = score > threshold ; W *= mask             (:180, :229-231)
+//     sparsity[k] = (W == 0).sum() / numel             (:236-237)
+// The reference concatenates every score tensor on the CPU (14.8 GB for BLIP-2) and runs a
+// top-k; here scores are recomputed on the fly from (W, acc, mask) in three multi-tensor
+// histogram passes (11 + 11 + 10 bits of the fp32 pattern; scores are >= +0 so unsigned order
+// is float order) and one apply pass; nothing of score size is materialised.
+// All passes are HBM-bound streaming reads: (s_W + 4 + 1) bytes per element per pass.
+#include "common.h"
+
+#define GP_SLICES 64
+
+struct GlobalSelState {
+    uint32_t hist[3][2048];
+    unsigned long long zeros[1];
+};
+
+// table row: {w_ptr, acc_ptr, mask_ptr, numel, dtype}; the dtype is per layer (BLIP-2 mixes
+// fp16 ViT and bf16 T5 matrices under ONE global threshold) and uniform within a workgroup
+struct GpRow { const void* w; const float* acc; const uint8_t* mask; int64_t n; int dt; };
+
+static __device__ __forceinline__ GpRow gp_row(const int64_t* table, int layer) {
+    GpRow r;
+    r.w = (const void*)table[5 * layer + 0];
+    r.acc = (const float*)table[5 * layer + 1];
+    r.mask = (const uint8_t*)table[5 * layer + 2];
+    r.n = table[5 * layer + 3];
+    r.dt = (int)table[5 * layer + 4];
+    return r;
+}
+
+static __device__ __forceinline__ float load_any(const void* p, int64_t i, int dt) {
+    if (dt == ECOFLAP_F32) return Vec<ECOFLAP_F32>::load1(p, i);
+    if (dt == ECOFLAP_F16) return Vec<ECOFLAP_F16>::load1(p, i);
+    return Vec<ECOFLAP_BF16>::load1(p, i);
+}
+static __device__ __forceinline__ void store_any(void* p, int64_t i, int dt, float v) {
+    if (dt == ECOFLAP_F32) Vec<ECOFLAP_F32>::store1(p, i, v);
+    else if (dt == ECOFLAP_F16) Vec<ECOFLAP_F16>::store1(p, i, v);
+    else Vec<ECOFLAP_BF16>::store1(p, i, v);
+}
+
+// importance of one element, with the reference's roundings; MODE 0 |W|*|acc|, 1 W^2*acc, 2 |acc|
+template <int MODE>
+static __device__ __forceinline__ float gp_score(float w, float acc, float n_batches, uint8_t keep) {
+    const float a = acc / n_batches;                    // gradients_dict[k] /= current_batch_index
+    float s;
+    if (MODE == 0) s = __builtin_fabsf(w) * __builtin_fabsf(a);
+    else if (MODE == 1) s = (w * w) * a;
+    else s = __builtin_fabsf(a);
+    return s * (keep ? 1.0f : 0.0f);                    // importance_measure[k] *= masks[k]
+}
+
+// ---- acc += |g| --------------------------------------------------------------------------
+// rows {acc_ptr(float), g_ptr, numel, dtype_g}
+__global__ __launch_bounds__(256) void grad_accum_multi_kernel(const int64_t* __restrict__ table) {
+    const int layer = blockIdx.y;
+    float* acc = (float*)table[4 * layer + 0];
+    const void* g = (const void*)table[4 * layer + 1];
+    const int64_t n = table[4 * layer + 2];
+    const int dt = (int)table[4 * layer + 3];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        acc[i] = acc[i] + __builtin_fabsf(load_any(g, i, dt));
+}
+
+extern "C" int ecoflap_grad_accum_multi(const int64_t* table, int n_layers, void* stream) {
+    if (n_layers < 0) return ECOFLAP_ESIZE;
+    if (n_layers == 0) return 0;
+    if (!table) return ECOFLAP_ENULL;
+    const dim3 grid(GP_SLICES * 4, (unsigned)n_layers), blk(256);
+    hipLaunchKernelGGL(grad_accum_multi_kernel, grid, blk, 0, (hipStream_t)stream, table);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- selection -----------------------------------------------------------------------------
+static __device__ __forceinline__ uint32_t gp_scan_256(uint32_t v, uint32_t* wave4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wave4[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < wave) base += wave4[k];
+    total = wave4[0] + wave4[1] + wave4[2] + wave4[3];
+    return x + base;
+}
+
+// ranks here can exceed 2^32 (3.7 G scores): 64-bit remaining, 32-bit per-bin counts are summed
+// in 64 bits across bins
+static __device__ __forceinline__ void gp_pick(const uint32_t* __restrict__ hist, int bins,
+                                               unsigned long long remaining, uint32_t* wave4,
+                                               unsigned long long* out2) {
+    unsigned long long carry = 0;
+    for (int base = 0; base < bins; base += 256) {
+        const uint32_t cnt = hist[base + threadIdx.x];
+        uint32_t total;
+        const uint32_t incl32 = gp_scan_256(cnt, wave4, total);
+        const unsigned long long incl = carry + incl32, excl = incl - cnt;
+        if (excl < remaining && remaining <= incl) {
+            out2[0] = (unsigned long long)(base + threadIdx.x);
+            out2[1] = remaining - excl;
+        }
+        carry += total;
+    }
+    __syncthreads();
+}
+
+static __device__ __forceinline__ void gp_resolve(const GlobalSelState* st, int upto,
+                                                  unsigned long long rank0, uint32_t* wave4,
+                                                  unsigned long long* out2, uint32_t& prefix) {
+    prefix = 0;
+    unsigned long long remaining = rank0;
+    if (upto >= 1) { gp_pick(st->hist[0], 2048, remaining, wave4, out2); prefix |= (uint32_t)out2[0] << 21; remaining = out2[1]; __syncthreads(); }
+    if (upto >= 2) { gp_pick(st->hist[1], 2048, remaining, wave4, out2); prefix |= (uint32_t)out2[0] << 10; remaining = out2[1]; __syncthreads(); }
+    if (upto >= 3) { gp_pick(st->hist[2], 1024, remaining, wave4, out2); prefix |= (uint32_t)out2[0]; remaining = out2[1]; __syncthreads(); }
+}
+
+// NOTE: a histogram bin can receive more than 2^32 hits only if > 4 G scores share 11 leading
+// bits; the host rejects totals >= 2^32 per launch group instead (see below).
+template <int MODE, int PASS>
+__global__ __launch_bounds__(256) void gp_hist_kernel(const int64_t* __restrict__ table,
+                                                      float n_batches, unsigned long long rank0,
+                                                      GlobalSelState* st) {
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr int BITS = PASS == 2 ? 10 : 11;
+    constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    __shared__ uint32_t h[2048];
+    __shared__ uint32_t wave4[4];
+    __shared__ unsigned long long out2[2];
+    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+    uint32_t prefix;
+    gp_resolve(st, PASS, rank0, wave4, out2, prefix);
+    __syncthreads();
+    const GpRow r = gp_row(table, blockIdx.y);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(gp_score<MODE>(load_any(r.w, i, r.dt), r.acc[i], n_batches, r.mask[i]));
+        if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << BITS); i += 256)
+        if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict__ table,
+                                                       float n_batches, unsigned long long rank0,
+                                                       const GlobalSelState* st) {
+    __shared__ uint32_t wave4[4];
+    __shared__ unsigned long long out2[2];
+    uint32_t thres_bits;
+    gp_resolve(st, 3, rank0, wave4, out2, thres_bits);
+    const float thres = __uint_as_float(thres_bits);
+    const GpRow r = gp_row(table, blockIdx.y);
+    void* w = (void*)r.w;
+    uint8_t* mask = (uint8_t*)r.mask;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
+        const float wv = load_any(w, i, r.dt);
+        const float s = gp_score<MODE>(wv, r.acc[i], n_batches, mask[i]);
+        const bool keep = s > thres;                      // masks[k] = (v > threshold)   (:180)
+        mask[i] = keep ? 1 : 0;
+        // v.data *= masks[k]  (:231): a product, so a pruned negative weight becomes -0
+        store_any(w, i, r.dt, wv * (keep ? 1.0f : 0.0f));
+    }
+}
+
+extern "C" size_t ecoflap_global_prune_workspace_bytes(void) { return sizeof(GlobalSelState); }
+
+// table: device int64[n_layers][5] rows {w_ptr, acc_ptr(float), mask_ptr(uint8), numel, dtype};
+// k: rank (1-indexed) of the threshold among all scores = num_to_zero_out (:173).
+extern "C" int ecoflap_global_threshold_prune(const int64_t* table, int n_layers, int mode,
+                                              float n_batches, int64_t k, int64_t total_numel,
+                                              void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+    if (mode < 0 || mode > 2) return ECOFLAP_EMODE;
+    if (n_layers <= 0 || k < 1 || k > total_numel) return ECOFLAP_ESIZE;
+    if (total_numel >= (int64_t)0xffffffffLL) return ECOFLAP_ESIZE;   // 32-bit histogram bins
+    if (!table || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < sizeof(GlobalSelState)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    GlobalSelState* st = (GlobalSelState*)workspace;
+    hipError_t e = hipMemsetAsync(st, 0, sizeof(GlobalSelState), s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(GP_SLICES, (unsigned)n_layers), blk(256);
+    const unsigned long long rank0 = (unsigned long long)k;
+#define GP_RUN(MODE)                                                                        \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 0>), grid, blk, 0, s, table, n_batches, rank0, st); \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 1>), grid, blk, 0, s, table, n_batches, rank0, st); \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 2>), grid, blk, 0, s, table, n_batches, rank0, st); \
+    hipLaunchKernelGGL((gp_apply_kernel<MODE>), grid, blk, 0, s, table, n_batches, rank0, st)
+    if (mode == 0) { GP_RUN(0); }
+    else if (mode == 1) { GP_RUN(1); }
+    else { GP_RUN(2); }
+#undef GP_RUN
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- zeros per layer -------------------------------------------------------------------------
+// rows {w_ptr, numel, dtype}
+__global__ __launch_bounds__(256) void count_zeros_multi_kernel(const int64_t* __restrict__ table,
+                                                                unsigned long long* __restrict__ out) {
+    const int layer = blockIdx.y;
+    const void* w = (const void*)table[3 * layer + 0];
+    const int64_t n = table[3 * layer + 1];
+    const int dt = (int)table[3 * layer + 2];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        c += (load_any(w, i, dt) == 0.0f) ? 1ull : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&out[layer], c);   // integer: order-independent
+}
+
+extern "C" int ecoflap_count_zeros_multi(const int64_t* table, int n_layers,
+                                         int64_t* out_counts, void* stream) {
+    if (n_layers < 0) return ECOFLAP_ESIZE;
+    if (n_layers == 0) return 0;
+    if (!table || !out_counts) return ECOFLAP_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out_counts, 0, sizeof(int64_t) * (size_t)n_layers, s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(GP_SLICES, (unsigned)n_layers), blk(256);
+    unsigned long long* out = (unsigned long long*)out_counts;
+    hipLaunchKernelGGL(count_zeros_multi_kernel, grid, blk, 0, s, table, out);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}

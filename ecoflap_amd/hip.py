@@ -26,6 +26,8 @@ EXPORTS = [
     "ecoflap_colsqnorm_accum", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
     "ecoflap_wanda_prune_matrix", "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
+    "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
+    "ecoflap_global_threshold_prune", "ecoflap_count_zeros_multi",
 ]
 
 
@@ -71,6 +73,10 @@ def load_library():
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_mask_mul.argtypes = [vp, vp, i64, ci, vp]
+    lib.ecoflap_grad_accum_multi.argtypes = [vp, ci, vp]
+    lib.ecoflap_global_prune_workspace_bytes.restype = sz
+    lib.ecoflap_global_threshold_prune.argtypes = [vp, ci, ci, f32, i64, i64, vp, sz, vp]
+    lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
     lib.ecoflap_allocate_sparsity.argtypes = [vp, vp, ci, i64, f64, vp, vp]
@@ -273,6 +279,42 @@ class HipKernels:
     def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
         self._wanda(self.lib.ecoflap_wanda_prune_matrix, "ecoflap_wanda_prune_matrix", w,
                     scaler_row, k, mask_out)
+
+    # ---- Real-* global iterative pruning ---------------------------------------------------------
+    def grad_accum_multi(self, accs, grads):
+        """accs[l] (fp32) += |grads[l]| for every layer, one launch."""
+        rows, keep = [], []
+        for a, g in zip(accs, grads):
+            _gpu(a, "acc")
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep.append(g)
+            rows.append([a.data_ptr(), _gpu(g, "grad").data_ptr(), a.numel(), DTYPE_CODE[g.dtype]])
+        table = torch.tensor(rows, dtype=torch.int64, device=accs[0].device)
+        _check(self.lib.ecoflap_grad_accum_multi(_ptr(table), len(rows), _stream()),
+               "ecoflap_grad_accum_multi")
+
+    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
+        """One round of get_mask + `W *= mask` over all layers: masks (uint8) and weights are
+        updated in place; k = num_to_zero_out."""
+        rows = [[_gpu(w, "w").data_ptr(), _gpu(a, "acc").data_ptr(), _gpu(m, "mask").data_ptr(),
+                 w.numel(), DTYPE_CODE[w.dtype]] for w, a, m in zip(weights, accs, masks)]
+        dev = weights[0].device
+        table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        total = sum(r[3] for r in rows)
+        ws = self.ws.get(self.lib.ecoflap_global_prune_workspace_bytes(), dev)
+        _check(self.lib.ecoflap_global_threshold_prune(
+            _ptr(table), len(rows), int(mode), float(n_batches), int(k), int(total), _ptr(ws),
+            ws.numel(), _stream()), "ecoflap_global_threshold_prune")
+
+    def count_zeros_multi(self, tensors):
+        rows = [[_gpu(t, "w").data_ptr(), t.numel(), DTYPE_CODE[t.dtype]] for t in tensors]
+        dev = tensors[0].device
+        table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        out = torch.zeros(len(rows), dtype=torch.int64, device=dev)
+        _check(self.lib.ecoflap_count_zeros_multi(_ptr(table), len(rows), _ptr(out), _stream()),
+               "ecoflap_count_zeros_multi")
+        return out.cpu().tolist()
 
     # ---- SparseGPT ------------------------------------------------------------------------
     def sparsegpt_block(self, W, Hinv, i1, count, k, err_out, mask_out=None):

@@ -194,6 +194,26 @@ int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hi
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * "Real-*" global iterative pruning
+ * replaces, in layer_single_base_pruner.py:156-245 / :446-471, the per-element accumulator
+ * `acc += |g|` (:455), the score (:461-469) times the previous mask (:221-224), the global
+ * threshold = k-th smallest of ALL scores (torch.topk over the concatenation, :170-175), the
+ * new mask and `W *= mask` (:180, :229-231), and the per-parameter zero fraction (:236-237).
+ * Tables are device int64 arrays; dtype codes are per row (mixed fp16 / bf16 models).
+ *   grad_accum rows:  {acc_ptr(float), g_ptr, numel, dtype_g}
+ *   threshold rows:   {w_ptr, acc_ptr(float), mask_ptr(uint8, 1 = kept), numel, dtype_w}
+ *   count_zeros rows: {w_ptr, numel, dtype_w}
+ * mode: 0 |W|*|acc/n|, 1 W^2*(acc/n), 2 |acc/n|;  k = num_to_zero_out (1-indexed rank).
+ * ------------------------------------------------------------------------- */
+int ecoflap_grad_accum_multi(const int64_t* table, int n_layers, void* stream);
+size_t ecoflap_global_prune_workspace_bytes(void);
+int ecoflap_global_threshold_prune(const int64_t* table, int n_layers, int mode,
+                                   float n_batches, int64_t k, int64_t total_numel,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int ecoflap_count_zeros_multi(const int64_t* table, int n_layers, int64_t* out_counts,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------
  * K8  mask apply in masked fine-tuning:  grad *= mask
  * replaces UPop/ecoflap_compression_vqa.py:124-129
  * keep_mask: uint8[n], 1 = keep (multiply by 1), 0 = pruned (multiply by 0).

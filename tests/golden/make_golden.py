@@ -458,6 +458,67 @@ def golden_sparsegpt(registry):
     save("g10_sparsegpt.npz", **out)
 
 
+# --------------------------------------------------------------------------- G11: Real-* scoring
+def golden_real(LayerSparsity, lavis, registry):
+    """Global iterative pruning (layer_single_base_pruner.py:156-245): per-parameter zero fractions
+    and the untouched weights; plus one pruner run end to end."""
+    utils = lavis["utils"]
+    out = {}
+    torch.manual_seed(3)
+    vit = vit_toy().eval()
+    vit_batches = S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5)
+    torch.manual_seed(4)
+    blip = blip2_toy().eval()
+    blip_batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    for tag, model, batches, loss_fn, prefixes, depth in [
+        ("vit", vit, vit_batches, utils.loss_vision, ["visual"], {"visual": 3}),
+        ("blip2", blip, blip_batches, utils.loss_vision_language,
+         ["t5_model", "visual_encoder"], {"t5_model": 4, "visual_encoder": 3}),
+    ]:
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        for k, v in init.items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        mapping = block_mapping(model, prefixes, depth)
+        out[f"{tag}_names"] = np.array([k for k, _ in model.named_parameters() if k in mapping])
+        all_names = [k for k, _ in model.named_parameters()]
+        out[f"{tag}_all_names"] = np.array(all_names)
+        for method, sparsity, num_samples in [
+            ("Real-GradMagAbs_sum", 0.5, 8), ("Real-GradMagSquare_sum", 0.6, 8),
+            ("Real-GradOnly_sum", 0.4, 6),
+        ]:
+            model.load_state_dict(init)
+            for p in model.parameters():
+                p.requires_grad = True
+            ls = LayerSparsity(model, batches, loss_fn, num_samples, sparsity, 0.9, method, 1,
+                               1e-3, mapping)
+            sp = ls.return_sparsity()
+            key = f"{tag}_{method}_p{sparsity}_s{num_samples}"
+            out[key + "_sparsity"] = np.array([sp[k] for k in all_names], dtype=np.float64)
+            after = model.state_dict()
+            assert all(torch.equal(after[k], init[k]) for k in init)     # weights restored
+    base = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1,
+                num_noise=1, noise_eps=1e-3)
+    torch.manual_seed(27)
+    model = vit_toy().eval()
+    for k, v in model.state_dict().items():
+        out[f"e2e_init::{k}"] = bits(v)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    pruner = registry.get_pruner_class("vit_wanda_pruner")(
+        model=model, data_loader=S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5),
+        **dict(base, prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+               max_sparsity_per_layer=0.6, score_method="Real-GradMagAbs_sum",
+               num_data_first_stage=8))
+    model2, sp = pruner.prune()
+    names = sorted(sp.keys())
+    out["e2e_sparsity_names"] = np.array(names)
+    out["e2e_sparsity"] = np.array([sp[k] for k in names], dtype=np.float64)
+    for k, v in model2.state_dict().items():
+        out[f"e2e_final::{k}"] = bits(v)
+    save("g11_real.npz", **out)
+
+
 def golden_names():
     d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
                    map_location="cpu", weights_only=False)
@@ -470,7 +531,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # fixed reduction order for the committed vectors
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
-    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt"]
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real"]
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:
@@ -487,3 +548,5 @@ if __name__ == "__main__":
         golden_upop()
     if "sparsegpt" in only:
         golden_sparsegpt(registry)
+    if "real" in only:
+        golden_real(lavis["layer_single_base_pruner"].LayerSparsity, lavis, registry)

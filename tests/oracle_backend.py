@@ -77,6 +77,33 @@ class OracleKernels:
         if mask_out is not None:
             mask_out.copy_(m)
 
+    # Real-*: the reference's own torch formulation (layer_single_base_pruner.py:156-245,
+    # :446-471) on host copies — the checker for the multi-tensor HIP kernels
+    def grad_accum_multi(self, accs, grads):
+        for a, g in zip(accs, grads):
+            a += g.detach().float().abs().to(a.device)
+
+    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
+        scores = []
+        for w, a, m in zip(weights, accs, masks):
+            wf, g = self._host(w).float(), self._host(a) / n_batches
+            if mode == 0:
+                sc = wf.abs() * g.abs()
+            elif mode == 1:
+                sc = (wf ** 2) * g
+            else:
+                sc = g.abs()
+            scores.append(sc * self._host(m).float())
+        allv = torch.cat([t.flatten() for t in scores])
+        thr = torch.topk(allv, k, largest=False)[0][-1]
+        for w, m, sc in zip(weights, masks, scores):
+            keep = (sc > thr)
+            m.copy_(keep.to(torch.uint8))
+            w.copy_((self._host(w) * keep.to(w.dtype)))
+
+    def count_zeros_multi(self, tensors):
+        return [int((self._host(t) == 0).sum()) for t in tensors]
+
     def sparsegpt_block(self, W, Hinv, i1, count, k, err_out, mask_out=None):
         h = self._host(W)
         e = torch.empty(err_out.shape, dtype=torch.float32)

@@ -546,6 +546,93 @@ def test_sparsegpt_pruners_hip_equals_oracle(kern, golden_dir, tag):
     assert pruned > 0
 
 
+# ------------------------------------------------------------------------------ Real-* (global)
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_global_prune_kernels_vs_oracle(kern, dt, mode):
+    """grad accumulate -> global threshold -> mask/prune -> zero count, three chained rounds
+    on ragged layers with heavy score ties; masks, weights and counts exact."""
+    from oracle_backend import OracleKernels
+    orc = OracleKernels()
+    gen = torch.Generator().manual_seed(11 + mode)
+    sizes = [(1, 1), (3, 5), (64, 129), (257, 1031), (1024, 1024), (7, 8)]
+    ws = [torch.round(torch.randn(s, generator=gen) * 8).div(8).to(dt) for s in sizes]
+    state = {}
+    for name, backend in (("hip", kern), ("oracle", orc)):
+        w = [gpu(t.clone()) for t in ws]
+        masks = [torch.ones(t.shape, dtype=torch.uint8, device="cuda") for t in w]
+        g2 = torch.Generator().manual_seed(5)
+        total = sum(t.numel() for t in w)
+        for rnd, frac in enumerate([0.125, 0.35, 0.5]):
+            accs = [torch.zeros(t.shape, dtype=torch.float32, device="cuda") for t in w]
+            for _ in range(3):
+                grads = [gpu((torch.round(torch.randn(t.shape, generator=g2) * 4) / 4).to(dt))
+                         for t in w]
+                backend.grad_accum_multi(accs, grads)
+            backend.global_threshold_prune(w, accs, masks, mode, 3, int(frac * total))
+        state[name] = ([t.cpu() for t in w], [m.cpu() for m in masks],
+                       backend.count_zeros_multi(w), [a.cpu() for a in accs])
+    for a, b in zip(state["hip"][3], state["oracle"][3]):
+        assert torch.equal(a, b)
+    for a, b in zip(state["hip"][1], state["oracle"][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(state["hip"][0], state["oracle"][0]):
+        assert torch.equal(a, b)
+    assert state["hip"][2] == state["oracle"][2]
+    assert sum(state["hip"][2]) > 0
+
+
+@pytest.mark.parametrize("tag", ["vit", "blip2"])
+@pytest.mark.parametrize("method,sparsity,num_samples", [
+    ("Real-GradMagAbs_sum", 0.5, 8), ("Real-GradMagSquare_sum", 0.6, 8), ("Real-GradOnly_sum", 0.4, 6)])
+def test_real_global_iterative_hip_equals_oracle(kern, golden_dir, tag, method, sparsity, num_samples):
+    from oracle_backend import OracleKernels
+    from test_host_parity import run_real
+    got_h, want = run_real(golden_dir, tag, method, sparsity, num_samples, kern, device="cuda")
+    got_o, _ = run_real(golden_dir, tag, method, sparsity, num_samples, OracleKernels(), device="cuda")
+    assert np.array_equal(got_h, got_o)
+    # GPU forward/backward differs from the CPU golden in the last bits, which moves a few
+    # elements of these 16..64-wide toy matrices across the threshold: sanity bound only
+    # (exactness is HIP == oracle above, and host logic == golden in test_host_parity)
+    assert np.mean(np.abs(got_h - want)) < 0.01 and np.max(np.abs(got_h - want)) < 0.15
+
+
+def test_real_low_precision_hip_equals_oracle(kern):
+    from oracle_backend import OracleKernels
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    out = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels())):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        for p in model.parameters():
+            p.requires_grad = True
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: "g" for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        ls = LayerSparsity(model, batches, loss_vision_language, 8, 0.5, 0.6,
+                           "Real-GradMagAbs_sum", 1, 1e-3, mapping, kernels=backend)
+        out[name] = ls.return_sparsity()
+    assert out["hip"] == out["oracle"]
+    vals = [v for k, v in out["hip"].items() if k in mapping]
+    assert 0.2 < sum(vals) / len(vals) < 0.8
+
+
+def test_real_end_to_end_hip_equals_oracle(kern, golden_dir):
+    from oracle_backend import OracleKernels
+    from test_host_parity import run_real_e2e
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model, sp = run_real_e2e(golden_dir, backend, device="cuda")
+        res[name] = (sp, {k: v.cpu() for k, v in model.state_dict().items()})
+    assert res["hip"][0] == res["oracle"][0]
+    for k in res["hip"][1]:
+        assert torch.equal(res["hip"][1][k], res["oracle"][1][k]), k
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused

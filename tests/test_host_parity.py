@@ -204,3 +204,59 @@ def test_prunable_key_set_matches_reference_artifact(golden_dir):
     assert got == want
     numel = sum(v.numel() for k, v in model.named_parameters() if k in set(want))
     assert numel == 3701932032
+
+
+# ---------------------------------------------------------------- Real-* (global iterative pruning)
+REAL = [("Real-GradMagAbs_sum", 0.5, 8), ("Real-GradMagSquare_sum", 0.6, 8),
+        ("Real-GradOnly_sum", 0.4, 6)]
+
+
+def run_real(golden_dir, tag, method, sparsity, num_samples, kernels, device="cpu"):
+    g = np.load(os.path.join(golden_dir, "g11_real.npz"))
+    model, batches, loss_fn = _setup(tag)
+    load_state(model, g, f"{tag}_init")
+    model.to(device)
+    for p in model.parameters():
+        p.requires_grad = True
+    mapping = {str(n): "g" for n in g[f"{tag}_names"]}
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ls = LayerSparsity(model, batches, loss_fn, num_samples, sparsity, 0.9, method, 1, 1e-3,
+                       mapping, kernels=kernels)
+    sp = ls.return_sparsity()
+    after = model.state_dict()
+    assert all(torch.equal(after[k], before[k]) for k in before)   # weights restored (:239-243)
+    names = [str(n) for n in g[f"{tag}_all_names"]]
+    assert list(sp.keys()) == names
+    return np.array([sp[k] for k in names]), g[f"{tag}_{method}_p{sparsity}_s{num_samples}_sparsity"]
+
+
+@pytest.mark.parametrize("tag", ["vit", "blip2"])
+@pytest.mark.parametrize("method,sparsity,num_samples", REAL)
+def test_real_global_iterative_matches_reference(golden_dir, tag, method, sparsity, num_samples):
+    got, want = run_real(golden_dir, tag, method, sparsity, num_samples, OracleKernels())
+    assert np.array_equal(got, want)
+
+
+def run_real_e2e(golden_dir, kernels, device="cpu"):
+    g = np.load(os.path.join(golden_dir, "g11_real.npz"))
+    model, batches = build_e2e("vit")
+    load_state(model, g, "e2e_init")
+    model.to(device)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    cfg = dict(BASE, prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+               max_sparsity_per_layer=0.6, score_method="Real-GradMagAbs_sum",
+               num_data_first_stage=8)
+    pruner = load_pruner("vit_wanda_pruner", model, batches,
+                         cfg=dict(cfg, kernels=kernels, z_source=torch_cpu_normal))
+    model2, sp = pruner.prune()
+    return g, model2, sp
+
+
+def test_real_end_to_end_matches_reference(golden_dir):
+    g, model2, sp = run_real_e2e(golden_dir, OracleKernels())
+    names = [str(n) for n in g["e2e_sparsity_names"]]
+    assert sorted(sp.keys()) == names
+    assert np.array_equal(np.array([sp[k] for k in names]), g["e2e_sparsity"])
+    for k, v in model2.state_dict().items():
+        assert np.array_equal(to_bits(v).ravel(), g[f"e2e_final::{k}"].ravel()), k
