@@ -12,8 +12,7 @@
 //     sparsity[k] = (W == 0).sum() / numel             (:236-237)
 // The reference concatenates every score tensor on the CPU (14.8 GB for BLIP-2) and runs a
 // top-k; here scores are recomputed on the fly from (W, acc, mask) in three multi-tensor
-// histogram passes (11 + 11 + 10 bits of the fp32 pattern; scores are >= +0 so unsigned order
-// is float order) and one apply pass; nothing of score size is materialised.
+// histogram passes (11 + 11 + 10 bits of an order-preserving integer key of the fp32 score) and one apply pass; nothing of score size is materialised.
 // All passes are HBM-bound streaming reads: (s_W + 4 + 1) bytes per element per pass.
 #include "common.h"
 
@@ -49,15 +48,33 @@ static __device__ __forceinline__ void store_any(void* p, int64_t i, int dt, flo
     else Vec<ECOFLAP_BF16>::store1(p, i, v);
 }
 
-// importance of one element, with the reference's roundings; MODE 0 |W|*|acc|, 1 W^2*acc, 2 |acc|
+// importance of one element, with the reference's roundings; MODE 0 |W|*|acc|, 1 W^2*acc, 2 |acc|,
+// 3 the SIGNED weight (global_pruner.py:251 — BLIPT5GlobalMagPruner scores `v.data.float()`
+// without an abs, so "magnitude" pruning removes the most negative weights first; kept as shipped)
 template <int MODE>
-static __device__ __forceinline__ float gp_score(float w, float acc, float n_batches, uint8_t keep) {
-    const float a = acc / n_batches;                    // gradients_dict[k] /= current_batch_index
+static __device__ __forceinline__ float gp_score(float w, const float* __restrict__ acc, int64_t i,
+                                                 float n_batches, uint8_t keep) {
     float s;
-    if (MODE == 0) s = __builtin_fabsf(w) * __builtin_fabsf(a);
-    else if (MODE == 1) s = (w * w) * a;
-    else s = __builtin_fabsf(a);
-    return s * (keep ? 1.0f : 0.0f);                    // importance_measure[k] *= masks[k]
+    if (MODE == 3) {
+        s = w;
+    } else {
+        const float a = acc[i] / n_batches;             // gradients_dict[k] /= current_batch_index
+        if (MODE == 0) s = __builtin_fabsf(w) * __builtin_fabsf(a);
+        else if (MODE == 1) s = (w * w) * a;
+        else s = __builtin_fabsf(a);
+    }
+    // importance_measure[k] *= masks[k]; "+ 0" folds -0 into +0 so that the integer order of the
+    // keys below is exactly torch's value order (topk / `>` do not distinguish the two zeros)
+    return s * (keep ? 1.0f : 0.0f) + 0.0f;
+}
+
+// order-preserving map float -> uint32 (negative values exist in MODE 3 only) and its inverse
+static __device__ __forceinline__ uint32_t gp_key(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+static __device__ __forceinline__ float gp_unkey(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
 // ---- acc += |g| --------------------------------------------------------------------------
@@ -150,7 +167,7 @@ __global__ __launch_bounds__(256) void gp_hist_kernel(const int64_t* __restrict_
     __syncthreads();
     const GpRow r = gp_row(table, blockIdx.y);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
-        const uint32_t b = __float_as_uint(gp_score<MODE>(load_any(r.w, i, r.dt), r.acc[i], n_batches, r.mask[i]));
+        const uint32_t b = gp_key(gp_score<MODE>(load_any(r.w, i, r.dt), r.acc, i, n_batches, r.mask[i]));
         if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
     }
     __syncthreads();
@@ -166,13 +183,13 @@ __global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict
     __shared__ unsigned long long out2[2];
     uint32_t thres_bits;
     gp_resolve(st, 3, rank0, wave4, out2, thres_bits);
-    const float thres = __uint_as_float(thres_bits);
+    const float thres = gp_unkey(thres_bits);
     const GpRow r = gp_row(table, blockIdx.y);
     void* w = (void*)r.w;
     uint8_t* mask = (uint8_t*)r.mask;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
         const float wv = load_any(w, i, r.dt);
-        const float s = gp_score<MODE>(wv, r.acc[i], n_batches, mask[i]);
+        const float s = gp_score<MODE>(wv, r.acc, i, n_batches, mask[i]);
         const bool keep = s > thres;                      // masks[k] = (v > threshold)   (:180)
         mask[i] = keep ? 1 : 0;
         // v.data *= masks[k]  (:231): a product, so a pruned negative weight becomes -0
@@ -188,7 +205,7 @@ extern "C" int ecoflap_global_threshold_prune(const int64_t* table, int n_layers
                                               float n_batches, int64_t k, int64_t total_numel,
                                               void* workspace, size_t workspace_bytes,
                                               void* stream) {
-    if (mode < 0 || mode > 2) return ECOFLAP_EMODE;
+    if (mode < 0 || mode > 3) return ECOFLAP_EMODE;
     if (n_layers <= 0 || k < 1 || k > total_numel) return ECOFLAP_ESIZE;
     if (total_numel >= (int64_t)0xffffffffLL) return ECOFLAP_ESIZE;   // 32-bit histogram bins
     if (!table || !workspace) return ECOFLAP_ENULL;
@@ -206,7 +223,8 @@ extern "C" int ecoflap_global_threshold_prune(const int64_t* table, int n_layers
     hipLaunchKernelGGL((gp_apply_kernel<MODE>), grid, blk, 0, s, table, n_batches, rank0, st)
     if (mode == 0) { GP_RUN(0); }
     else if (mode == 1) { GP_RUN(1); }
-    else { GP_RUN(2); }
+    else if (mode == 2) { GP_RUN(2); }
+    else { GP_RUN(3); }
 #undef GP_RUN
     ECO_CHECK_LAUNCH();
     return 0;

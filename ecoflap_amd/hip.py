@@ -297,8 +297,11 @@ class HipKernels:
     def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
         """One round of get_mask + `W *= mask` over all layers: masks (uint8) and weights are
         updated in place; k = num_to_zero_out."""
-        rows = [[_gpu(w, "w").data_ptr(), _gpu(a, "acc").data_ptr(), _gpu(m, "mask").data_ptr(),
-                 w.numel(), DTYPE_CODE[w.dtype]] for w, a, m in zip(weights, accs, masks)]
+        if accs is None:             # mode 3: the score is the signed weight itself
+            accs = [None] * len(weights)
+        rows = [[_gpu(w, "w").data_ptr(), 0 if a is None else _gpu(a, "acc").data_ptr(),
+                 _gpu(m, "mask").data_ptr(), w.numel(), DTYPE_CODE[w.dtype]]
+                for w, a, m in zip(weights, accs, masks)]
         dev = weights[0].device
         table = torch.tensor(rows, dtype=torch.int64, device=dev)
         total = sum(r[3] for r in rows)

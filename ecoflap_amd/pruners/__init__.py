@@ -11,3 +11,6 @@ from .upop import (  # noqa: F401,E402
 from .sparsegpt import (  # noqa: F401,E402
     BLIPT5LayerSparseGPTPruner, SparseGPT, T5LayerSparseGPTPruner, VITLayerSparseGPTPruner,
 )
+from .global_pruner import (  # noqa: F401,E402
+    BLIPT5GlobalGradMagAbsPruner, BLIPT5GlobalMagPruner, BLIPT5GlobalMeZoPruner, BLIPT5GlobalPruner,
+)

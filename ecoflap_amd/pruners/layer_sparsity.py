@@ -415,6 +415,43 @@ class LayerSparsity:
         self.kernels.absprod_reduce_pairs([p.data for p in params], list(grads), mode, sums)
 
     # ------------------------------------------------------------------ Real-* (global iterative)
+    def accumulate_abs_grads(self, params):
+        """Per-element `acc += |g|` over the calibration batches (:433-455) -> (accs, n_batches).
+        One flat fp32 buffer in HBM (14.8 GB for BLIP-2) viewed per layer, one multi-tensor launch
+        per batch.  Data-parallel: batches sharded by global index, ONE all-reduce of the flat
+        buffer per round — the only bandwidth-sized collective of the framework (ring over xGMI;
+        fp32 sums re-associate across ranks, so ties at the threshold may resolve differently
+        from the single-process run; replicas always agree with each other)."""
+        model = self.model
+        device = next(iter(model.parameters())).device
+        cuda_enabled = device.type != "cpu"
+        _, rank, world = self._dist()
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+        accs, o = [], 0
+        for p in params:
+            accs.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        accum_samples, n_batches = 0, 0
+        for bi, d in enumerate(self.data_loader):
+            if accum_samples >= self.num_samples:
+                break
+            if world > 1:
+                blen = self.batch_len_fn(d)
+                accum_samples += blen
+                n_batches += 1
+                if (bi % world) != rank:
+                    continue
+            loss, batch_len = self.loss_func(model, d, cuda_enabled)
+            if world == 1:
+                accum_samples += batch_len
+                n_batches += 1
+            grads = torch.autograd.grad(loss, params)
+            assert len(grads) == len(params)
+            self.kernels.grad_accum_multi(accs, list(grads))
+            del grads, loss
+        self._all_reduce_sum(flat)
+        return accs, n_batches
+
     def global_iterative_pruning(self, target_sparsity, dict_layers_to_prune, iteratation=1,
                                  max_sparsity_per_layer=1.0):
         """Three rounds of: first-order per-element importance -> ONE global threshold over all
@@ -424,14 +461,9 @@ class LayerSparsity:
         if max_sparsity_per_layer != 1.0:
             raise NotImplementedError("the reference only calls this with max_sparsity_per_layer=1.0 "
                                       "(:324), where get_mask's protection step is a no-op")
-        _, _, world = self._dist()
-        if world > 1:
-            raise NotImplementedError("data-parallel Real-* (all-reduce of the accumulators)")
         t0 = time.time()
-        model = self.model
+        _, _, world = self._dist()
         names, params = self._select(dict_layers_to_prune)
-        device = next(iter(model.parameters())).device
-        cuda_enabled = device.type != "cpu"
         sc = self.score_compute
         mode = 1 if "GradMagSquare" in sc else (0 if "GradMagAbs" in sc else 2)     # (:463-469)
         weight_copy = [p.data.clone() for p in params]
@@ -439,21 +471,12 @@ class LayerSparsity:
         total = sum(p.numel() for p in params)
         for i in range(1, iteratation + 1):
             p_i = target_sparsity ** (iteratation / i)                                # (:213)
-            accs = [torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in params]
-            accum_samples, n_batches = 0, 0
-            for d in self.data_loader:
-                if accum_samples >= self.num_samples:
-                    break
-                loss, batch_len = self.loss_func(model, d, cuda_enabled)
-                accum_samples += batch_len
-                n_batches += 1
-                grads = torch.autograd.grad(loss, params)
-                self.kernels.grad_accum_multi(accs, list(grads))   # |g| even for *Square (:452)
-                del grads, loss
+            accs, n_batches = self.accumulate_abs_grads(params)    # |g| even for *Square (:452)
             k = int(p_i * total)                                                       # (:173)
             self.kernels.global_threshold_prune([p.data for p in params], accs, masks, mode,
                                                 n_batches, k)
             del accs
+        model = self.model
         all_names, all_params = [], []
         for k_, v in model.named_parameters():
             all_names.append(k_)

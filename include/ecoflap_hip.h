@@ -203,7 +203,11 @@ int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hi
  *   grad_accum rows:  {acc_ptr(float), g_ptr, numel, dtype_g}
  *   threshold rows:   {w_ptr, acc_ptr(float), mask_ptr(uint8, 1 = kept), numel, dtype_w}
  *   count_zeros rows: {w_ptr, numel, dtype_w}
- * mode: 0 |W|*|acc/n|, 1 W^2*(acc/n), 2 |acc/n|;  k = num_to_zero_out (1-indexed rank).
+ * mode: 0 |W|*|acc/n|, 1 W^2*(acc/n), 2 |acc/n|, 3 the signed weight itself (acc_ptr unused;
+ * BLIPT5GlobalMagPruner, global_pruner.py:116-142 + :251 — the same get_mask over
+ * `v.data.float()`, no abs, as shipped);  k = num_to_zero_out (1-indexed rank).
+ * One call = one threshold over the rows given: all layers (global), one sub-model's layers
+ * (global_pruner.py:183-192) or a single layer (get_layerwise_mask, :144-157).
  * ------------------------------------------------------------------------- */
 int ecoflap_grad_accum_multi(const int64_t* table, int n_layers, void* stream);
 size_t ecoflap_global_prune_workspace_bytes(void);

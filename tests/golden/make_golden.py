@@ -99,6 +99,10 @@ def bits(t):
     return t.numpy().copy()
 
 
+def bits_t(t):
+    return torch.from_numpy(bits(t).astype(np.int64))
+
+
 def state_bits(model):
     return {k: bits(v) for k, v in model.state_dict().items()}
 
@@ -519,6 +523,72 @@ def golden_real(LayerSparsity, lavis, registry):
     save("g11_real.npz", **out)
 
 
+# --------------------------------------------------------------------------- G12: global pruners
+GLOBAL_CASES = {
+    # tag: (pruner, is_global, prune_per_model, iteration, keep ratio)
+    "mag_global": ("blipt5_global_mag_pruner", True, False, 1, 0.5),
+    "mag_permodel_it2": ("blipt5_global_mag_pruner", True, True, 2, 0.6),
+    "mag_layerwise": ("blipt5_global_mag_pruner", False, False, 1, 0.5),
+    "grad_permodel_it3": ("blipt5_global_gradmagabs_pruner", True, True, 3, 0.5),
+    "grad_global": ("blipt5_global_gradmagabs_pruner", True, False, 1, 0.4),
+    "grad_layerwise_it2": ("blipt5_global_gradmagabs_pruner", False, False, 2, 0.5),
+    "mezo_global": ("blipt5_global_mezo_pruner", True, False, 1, 0.5),
+    "mezo_permodel_it2": ("blipt5_global_mezo_pruner", True, True, 2, 0.5),
+}
+
+
+def golden_global(registry):
+    """scripts/blip2/mag.py and iterative_global_gradient.py's pruners (global_pruner.py) on the
+    toy BLIP-2 shape: initial and pruned weights."""
+    out = {}
+    base = os.path.join(REF, "LAVIS/lavis/compression/pruners")
+    name = "lavis.compression.pruners.global_pruner"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(base, "global_pruner.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    torch.manual_seed(31)
+    model0 = blip2_toy().eval()
+    init = {k: v.clone() for k, v in model0.state_dict().items()}
+    for k, v in init.items():
+        out[f"init::{k}"] = bits(v)
+    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    for tag, (name, is_global, per_model, iteration, keep) in GLOBAL_CASES.items():
+        model = blip2_toy().eval()
+        model.load_state_dict(init)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        cfg = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                   is_global=is_global, sparsity_dict=None, prune_per_model=per_model,
+                   iteration=iteration, num_noise=1, noise_eps=1e-3,
+                   t5_prune_spec=f"2-{keep}-1.0-1.0", vit_prune_spec=f"2-{keep}-1.0-1.0",
+                   t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+                   sparsity_ratio_granularity=None, max_sparsity_per_layer=0.6,
+                   score_method="GradMagSquare_avg", num_data_first_stage=8)
+        pruner = registry.get_pruner_class(name)(model=model, data_loader=batches, **cfg)
+        model2, sp = pruner.prune()
+        assert sp is None
+        # a pruned weight is init * 0 (sign kept) — the fixture stores which elements changed
+        changed_keys = []
+        if tag.startswith("mezo"):    # K1's rounding drift touches every weight: full bits
+            for k, v in model2.state_dict().items():
+                if not torch.equal(bits_t(v), bits_t(init[k])):
+                    out[f"{tag}_final::{k}"] = bits(v)
+                    changed_keys.append(k)
+            out[f"{tag}_changed_keys"] = np.array(changed_keys)
+            continue
+        for k, v in model2.state_dict().items():
+            diff = bits(v) != bits(init[k])
+            if diff.any():
+                want = init[k].clone()
+                want[torch.from_numpy(diff.reshape(tuple(v.shape)))] *= 0
+                assert torch.equal(bits_t(want), bits_t(v)), (tag, k)
+                changed_keys.append(k)
+                out[f"{tag}_changed::{k}"] = np.packbits(diff.ravel())
+        out[f"{tag}_changed_keys"] = np.array(changed_keys)
+    save("g12_global_pruners.npz", **out)
+
+
 def golden_names():
     d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
                    map_location="cpu", weights_only=False)
@@ -531,7 +601,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # fixed reduction order for the committed vectors
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
-    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real"]
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global"]
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:
@@ -548,5 +618,7 @@ if __name__ == "__main__":
         golden_upop()
     if "sparsegpt" in only:
         golden_sparsegpt(registry)
+    if "global" in only:
+        golden_global(registry)
     if "real" in only:
         golden_real(lavis["layer_single_base_pruner"].LayerSparsity, lavis, registry)

@@ -85,9 +85,14 @@ class OracleKernels:
 
     def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
         scores = []
+        if accs is None:
+            accs = [None] * len(weights)
         for w, a, m in zip(weights, accs, masks):
-            wf, g = self._host(w).float(), self._host(a) / n_batches
-            if mode == 0:
+            wf = self._host(w).float()
+            g = None if a is None else self._host(a) / n_batches
+            if mode == 3:
+                sc = wf.clone()
+            elif mode == 0:
                 sc = wf.abs() * g.abs()
             elif mode == 1:
                 sc = (wf ** 2) * g

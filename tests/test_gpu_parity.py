@@ -633,6 +633,27 @@ def test_real_end_to_end_hip_equals_oracle(kern, golden_dir):
         assert torch.equal(res["hip"][1][k], res["oracle"][1][k]), k
 
 
+@pytest.mark.parametrize("fp32", [True, False])
+@pytest.mark.parametrize("tag", ["mag_global", "mag_permodel_it2", "mag_layerwise", "grad_permodel_it3",
+                                 "grad_global", "grad_layerwise_it2", "mezo_global",
+                                 "mezo_permodel_it2"])
+def test_global_pruners_hip_equals_oracle(kern, golden_dir, tag, fp32):
+    """scripts/blip2/mag.py / iterative_global_gradient.py pruners: same GPU forward/backward on
+    both sides, HIP kernels vs oracle arithmetic -> identical pruned weights."""
+    from oracle_backend import OracleKernels
+    from test_host_parity import run_global
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model = run_global(golden_dir, tag, backend, device="cuda", fp32=fp32)
+        res[name] = {k: v.cpu() for k, v in model.state_dict().items()}
+    zeros = 0
+    for k, v in res["hip"].items():
+        assert torch.equal(v, res["oracle"][k]), k
+        if v.dim() == 2 and ".block" in k:
+            zeros += int((v == 0).sum())
+    assert zeros > 0
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused

@@ -25,7 +25,9 @@ def test_config_dict_keys_match_reference():
 def test_launcher_names_exist():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for rel in ["LAVIS/scripts/blip2/ecoflap_zeroth.py", "LAVIS/scripts/blip2/ecoflap_first.py",
-                "LAVIS/scripts/t5/ecoflap.py", "LAVIS/scripts/eva_clip/ecoflap.py"]:
+                "LAVIS/scripts/t5/ecoflap.py", "LAVIS/scripts/eva_clip/ecoflap.py",
+                "LAVIS/scripts/blip2/ecoflap_sparsegpt_zeroth.py", "LAVIS/scripts/blip2/mag.py",
+                "LAVIS/scripts/blip2/iterative_global_gradient.py"]:
         assert os.path.exists(os.path.join(root, rel)), rel
 
 

@@ -260,3 +260,58 @@ def test_real_end_to_end_matches_reference(golden_dir):
     assert np.array_equal(np.array([sp[k] for k in names]), g["e2e_sparsity"])
     for k, v in model2.state_dict().items():
         assert np.array_equal(to_bits(v).ravel(), g[f"e2e_final::{k}"].ravel()), k
+
+
+# ---------------------------------------------------------------- global baselines (global_pruner.py)
+GLOBAL_CASES = {
+    "mag_global": ("blipt5_global_mag_pruner", True, False, 1, 0.5),
+    "mag_permodel_it2": ("blipt5_global_mag_pruner", True, True, 2, 0.6),
+    "mag_layerwise": ("blipt5_global_mag_pruner", False, False, 1, 0.5),
+    "grad_permodel_it3": ("blipt5_global_gradmagabs_pruner", True, True, 3, 0.5),
+    "grad_global": ("blipt5_global_gradmagabs_pruner", True, False, 1, 0.4),
+    "grad_layerwise_it2": ("blipt5_global_gradmagabs_pruner", False, False, 2, 0.5),
+    "mezo_global": ("blipt5_global_mezo_pruner", True, False, 1, 0.5),
+    "mezo_permodel_it2": ("blipt5_global_mezo_pruner", True, True, 2, 0.5),
+}
+
+
+def run_global(golden_dir, tag, kernels, device="cpu", fp32=True):
+    g = np.load(os.path.join(golden_dir, "g12_global_pruners.npz"))
+    name, is_global, per_model, iteration, keep = GLOBAL_CASES[tag]
+    torch.manual_seed(5)
+    model = blip2_toy(fp32=fp32).eval()
+    if fp32:
+        load_state(model, g, "init")
+    model.to(device)
+    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                   device=device)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    cfg = dict(BASE, is_global=is_global, prune_per_model=per_model, iteration=iteration,
+               t5_prune_spec=f"2-{keep}-1.0-1.0", vit_prune_spec=f"2-{keep}-1.0-1.0",
+               t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+               sparsity_ratio_granularity=None, max_sparsity_per_layer=0.6,
+               score_method="GradMagSquare_avg", num_data_first_stage=8)
+    pruner = load_pruner(name, model, batches,
+                         cfg=dict(cfg, kernels=kernels, z_source=torch_cpu_normal))
+    model2, sp = pruner.prune()
+    assert sp is None
+    return g, model2
+
+
+@pytest.mark.parametrize("tag", list(GLOBAL_CASES))
+def test_global_pruners_match_reference(golden_dir, tag):
+    g, model2 = run_global(golden_dir, tag, OracleKernels())
+    changed = set(str(k) for k in g[f"{tag}_changed_keys"])
+    assert changed
+    for k, v in model2.state_dict().items():
+        init = from_bits(g[f"init::{k}"], v.dtype).reshape(v.shape)
+        if k not in changed:
+            assert np.array_equal(to_bits(v), to_bits(init)), k
+        elif tag.startswith("mezo"):
+            assert np.array_equal(to_bits(v).ravel(), g[f"{tag}_final::{k}"].ravel()), k
+        else:
+            diff = np.unpackbits(g[f"{tag}_changed::{k}"])[:v.numel()].astype(bool)
+            want = init.clone()
+            want[torch.from_numpy(diff.reshape(tuple(v.shape)))] *= 0     # pruned = w * 0
+            assert np.array_equal(to_bits(v), to_bits(want)), k

@@ -29,6 +29,15 @@ CONFIGS = {
           "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.6",
           "--prunining_dataset_batch_size", "8", "--num_data", "128", "--num_data_first_stage", "128",
           "--t5_prune_spec", "24-0.5-1.0-1.0", "--vit_prune_spec", "39-0.5-1.0-1.0"],
+    # scripts/blip2/iterative_global_gradient.py: 3 rounds, one threshold per sub-model
+    "global_grad": ["--shape", "blip2", "--pruning_method", "blipt5_global_gradmagabs_pruner",
+                    "--is_global", "--prune_per_model", "--iteration", "3",
+                    "--prunining_dataset_batch_size", "8", "--num_data", "128",
+                    "--t5_prune_spec", "24-0.5-1.0-1.0", "--vit_prune_spec", "39-0.5-1.0-1.0"],
+    # scripts/blip2/mag.py
+    "global_mag": ["--shape", "blip2", "--pruning_method", "blipt5_global_mag_pruner", "--is_global",
+                   "--prunining_dataset_batch_size", "8", "--num_data", "128",
+                   "--t5_prune_spec", "24-0.5-1.0-1.0", "--vit_prune_spec", "39-0.5-1.0-1.0"],
 }
 
 
