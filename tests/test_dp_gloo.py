@@ -119,3 +119,49 @@ def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
     agree = sum(int(((w0[k] == 0) == (single_w[k] == 0)).sum()) for k in w0)
     total = sum(v.numel() for v in w0.values())
     assert agree / total > 0.9999
+
+
+# ---------------------------------------------------------------- Real-* / global gradient pruning
+def _run_real(rank, world):
+    from oracle_backend import OracleKernels
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    torch.set_num_threads(1)
+    torch.manual_seed(4)
+    model = blip2_toy().eval()
+    for p in model.parameters():
+        p.requires_grad = True
+    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    mapping = {k: "g" for k, v in model.named_parameters()
+               if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+    ls = LayerSparsity(model, batches, loss_vision_language, 8, 0.5, 0.6, "Real-GradMagAbs_sum", 1,
+                       1e-3, mapping, kernels=OracleKernels())
+    sp = ls.return_sparsity()
+    return sp, dict(ls.stats)
+
+
+def _real_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.save(_run_real(rank, world), os.path.join(out_dir, f"real{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_two_ranks_agree_and_track_single_process(tmp_path):
+    """The per-element accumulators are all-reduced once per round: both replicas hold the same
+    sums -> identical thresholds and tables; vs the single process the fp32 batch sums
+    re-associate, which can move elements that tie at the threshold only."""
+    single, _ = _run_real(0, 1)
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_real_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, st0 = torch.load(tmp_path / "real0.pt", weights_only=False)
+    r1, st1 = torch.load(tmp_path / "real1.pt", weights_only=False)
+    assert st0["world_size"] == st1["world_size"] == 2
+    assert r0 == r1
+    diffs = [abs(r0[k] - single[k]) for k in single]
+    assert max(diffs) < 0.02 and sum(single.values()) > 0
