@@ -47,6 +47,8 @@ def build_parser():
     p.add_argument("--sparsity_dict", type=str, default=None)
     p.add_argument("--prune_per_model", action="store_true")
     p.add_argument("--iteration", type=int, default=1)
+    p.add_argument("--t5_pruned_checkpoint", type=str, default=None)
+    p.add_argument("--vit_pruned_checkpoint", type=str, default=None)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--out_dir", type=str, default=".")
     return p
@@ -79,6 +81,40 @@ def build_model_and_loader(args, device):
                                        num_classes=5 if args.toy else 1000, seed=args.seed,
                                        device=device)
     return model.eval(), loader
+
+
+def load_pruned_checkpoints(model, t5_pruned_checkpoint=None, vit_pruned_checkpoint=None):
+    """Re-ingest `pruned_checkpoint/<job>.pth` files the way the evaluation runs of every
+    launcher do (LAVIS/evaluate_blip.py:345-390): the T5 part by its `t5_model.` prefix, strict;
+    the ViT part from either a BLIP-2 (`visual_encoder.`) or an EVA-CLIP (`visual.`) checkpoint,
+    overriding only the keys the target owns.  (`interpolate_pos_embed` is the model zoo's and
+    is a no-op at equal image size; differing sizes are rejected here.)"""
+    if t5_pruned_checkpoint is not None and getattr(model, "t5_model", None) is not None:
+        print("Load t5 pruned weight")
+        sd = torch.load(t5_pruned_checkpoint, map_location="cpu")
+        sd = {k.replace("t5_model.", ""): v for k, v in sd.items() if k.startswith("t5_model")}
+        model.t5_model.load_state_dict(sd)
+    if vit_pruned_checkpoint is not None:
+        print("Load vit pruned weight")
+        sd = torch.load(vit_pruned_checkpoint, map_location="cpu")
+        model_prefix = None
+        for candidate in ["visual.", "visual_encoder."]:
+            if any(k.startswith(candidate) for k in sd.keys()):
+                model_prefix = candidate
+                break
+        assert model_prefix is not None
+        print(f"VIT checkpoint prefix: {model_prefix}")
+        sd = {k.replace(model_prefix, ""): v for k, v in sd.items() if k.startswith(model_prefix)}
+        target = model.visual_encoder.state_dict()
+        for k, v in sd.items():
+            if k in target:
+                if tuple(v.shape) != tuple(target[k].shape):
+                    raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model "
+                                     f"{tuple(target[k].shape)} (position-embedding interpolation "
+                                     "belongs to the model zoo, not to this path)")
+                target[k] = v
+        model.visual_encoder.load_state_dict(target)
+    return model
 
 
 def config_dict(args):
@@ -119,6 +155,7 @@ def main(argv=None):
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     model, loader = build_model_and_loader(args, device)
+    load_pruned_checkpoints(model, args.t5_pruned_checkpoint, args.vit_pruned_checkpoint)
     orig_total = sum((p != 0).float().sum() for p in model.parameters())
     pruner = load_pruner(args.pruning_method, model, loader, cfg=config_dict(args))
     start = time.time()

@@ -90,3 +90,43 @@ def test_sparsity_dict_yaml_reingest(tmp_path):
     # stage 2 on un-drifted weights: same per-matrix pruned counts as the table dictates
     for k in z1:
         assert int(z1[k].sum()) == int(z2[k].sum()), k
+
+
+def test_pruned_checkpoint_reingest(tmp_path, monkeypatch):
+    """`--t5_pruned_checkpoint` / `--vit_pruned_checkpoint` (LAVIS/evaluate_blip.py:345-390): a
+    BLIP-2 checkpoint written by --save_pruned_model restores the pruned T5 and ViT into a fresh
+    model; an EVA-CLIP (`visual.`) checkpoint restores the ViT blocks of a BLIP-2 shape."""
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    import ecoflap_amd.harness as H
+    import ecoflap_amd
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    real = ecoflap_amd.load_pruner
+    monkeypatch.setattr(ecoflap_amd, "load_pruner", lambda name, model, loader, cfg_path=None, cfg=None:
+                        real(name, model, loader, cfg=dict(cfg, kernels=OracleKernels(),
+                                                           z_source=torch_cpu_normal)))
+    pruned, _ = H.main([
+        "--shape", "blip2", "--toy", "--device", "cpu", "--pruning_method", "blipt5_global_mag_pruner",
+        "--is_global", "--prunining_dataset_batch_size", "2", "--num_data", "4",
+        "--t5_prune_spec", "2-0.5-1.0-1.0", "--vit_prune_spec", "2-0.5-1.0-1.0",
+        "--save_pruned_model", "--job_id", "g", "--out_dir", str(tmp_path)])
+    ckpt = str(tmp_path / "pruned_checkpoint" / "g.pth")
+    torch.manual_seed(123)
+    fresh = blip2_toy().eval()
+    H.load_pruned_checkpoints(fresh, t5_pruned_checkpoint=ckpt, vit_pruned_checkpoint=ckpt)
+    want = pruned.state_dict()
+    for k, v in fresh.state_dict().items():
+        if k.startswith("t5_model.") or k.startswith("visual_encoder."):
+            assert torch.equal(v, want[k]), k
+    assert any(not torch.equal(v, want[k]) for k, v in fresh.state_dict().items()
+               if k.startswith("Qformer"))                      # untouched parts stay fresh
+    # EVA-CLIP style checkpoint: `visual.` prefix, extra keys the BLIP-2 ViT does not own
+    clip_sd = {k.replace("visual_encoder.", "visual."): v for k, v in want.items()
+               if k.startswith("visual_encoder.")}
+    clip_sd["visual.head.weight"] = torch.zeros(3, 3)
+    clip_sd["logit_scale"] = torch.zeros(())
+    torch.save(clip_sd, tmp_path / "clip.pth")
+    fresh2 = blip2_toy().eval()
+    H.load_pruned_checkpoints(fresh2, vit_pruned_checkpoint=str(tmp_path / "clip.pth"))
+    for k, v in fresh2.state_dict().items():
+        if k.startswith("visual_encoder."):
+            assert torch.equal(v, want[k]), k
