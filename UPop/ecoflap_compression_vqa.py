@@ -1,72 +1,18 @@
 """ECoFLaP on BLIP-VQA — the build's counterpart of the reference's
 UPop/ecoflap_compression_vqa.py (pruner construction :256-271, masks :312-315, masked
-fine-tune step :124-129) on a shape-compatible random-init model with synthetic VQA tuples.
+fine-tune step :124-129).
 
     python UPop/ecoflap_compression_vqa.py --p 0.5 [--stage1 intended] [--finetune_steps 2] [--toy]
 """
-import argparse
 import os
 import sys
-import time
 
-import numpy as np
-import torch
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ecoflap_amd.pruners import BLIPBertLayerWandaPruner, apply_masks_to_grads, pruning_masks  # noqa: E402
-from ecoflap_amd.shapes.blip_bert import blip_vqa_base, blip_vqa_toy, vqa_batches  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _entry import run  # noqa: E402
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--p", type=float, default=0.5)
-    ap.add_argument("--sparsity_ratio_granularity", default="block")
-    ap.add_argument("--stage1", default="compat", choices=["compat", "intended"])
-    ap.add_argument("--finetune_steps", type=int, default=0)
-    ap.add_argument("--num_data", type=int, default=128)
-    ap.add_argument("--batch_size", type=int, default=16)
-    ap.add_argument("--toy", action="store_true")
-    ap.add_argument("--device", default="cuda")
-    ap.add_argument("--save", default="")
-    args = ap.parse_args(argv)
-    dev = torch.device(args.device)
-    torch.manual_seed(42)
-    np.random.seed(42)
-    with torch.device(dev):
-        model = (blip_vqa_toy() if args.toy else blip_vqa_base()).eval()
-    loader = vqa_batches(args.num_data, args.batch_size, img_size=32 if args.toy else 480,
-                         vocab=64 if args.toy else 30524, device=dev)
-    t0 = time.time()
-    pruner = BLIPBertLayerWandaPruner(          # ecoflap_compression_vqa.py:256-269
-        model, loader,
-        bert_prune_spec=f"0-{1 - args.p}-1.0-1.0", vit_prune_spec=f"0-{1 - args.p}-1.0-1.0",
-        num_samples=args.num_data, bert_model_prefix="text_decoder",
-        vit_model_prefix="visual_encoder",
-        sparsity_ratio_granularity=args.sparsity_ratio_granularity,
-        max_sparsity_per_layer=args.p + 0.1, score_method="MEZO-GradOnly_sum",
-        num_data_first_stage=32, task="vqa", stage1_mode=args.stage1)
-    model, table = pruner.prune()
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    print(f"pruned in {time.time() - t0:.2f} s; stage stats: {pruner.stage_stats}")
-    if args.save:
-        torch.save(model.state_dict(), args.save)
-    kept = sum(int((p != 0).sum()) for p in model.parameters())
-    total = sum(p.numel() for p in model.parameters())
-    print("remaining parameters", kept / total)
-    if args.finetune_steps > 0:
-        masks = pruning_masks(model)            # :312-315
-        model.train()
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05)
-        for step in range(args.finetune_steps):
-            image, q, a, w, n = loader[step % len(loader)]
-            loss = model(image, q, a, train=True, n=n, weights=w)
-            opt.zero_grad()
-            loss.backward()
-            apply_masks_to_grads(model, masks, kernels=pruner.kernels)   # :124-129 (K8)
-            opt.step()
-            print("finetune step", step, float(loss))
-    return model, table
+    return run("vqa", argv)
 
 
 if __name__ == "__main__":

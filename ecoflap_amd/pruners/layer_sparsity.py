@@ -73,6 +73,7 @@ class LayerSparsity:
         batch_len_fn=None,
         process_group=None,
         k1_form="units",
+        couple_torch_rng=False,
     ):
         """Positional arguments are the reference's (:120-135).  Keyword-only extras:
 
@@ -109,6 +110,10 @@ class LayerSparsity:
         self.kernels = kernels if kernels is not None else _hip.HipKernels()
         self.z_source = z_source
         self.batch_len_fn = batch_len_fn or _default_batch_len
+        # losses that draw from torch's global RNG (BLIP retrieval's hard negatives,
+        # torch.multinomial): the reference reseeds that RNG inside every K1 call (:482), so both
+        # losses of a pair see the same draws; replay that state right before each loss
+        self.couple_torch_rng = couple_torch_rng
         self.process_group = process_group
         assert k1_form in ("units", "triple", "single")
         self.k1_form = k1_form
@@ -258,12 +263,14 @@ class LayerSparsity:
                         home.copy_(plus[j])
                     else:
                         param.data = plus[j]    # theta + eps z
-                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen,
+                                    rng=(units[u][3], param))
                     if static_w:
                         home.copy_(minus[j])
                     else:
                         param.data = minus[j]   # theta - eps z
-                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen,
+                                    rng=(units[u][3], param))
                     n_forward += 2
                 if static_w:
                     home.copy_(final)
@@ -282,10 +289,10 @@ class LayerSparsity:
                     param.data = cur
                     self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
                     if mine:
-                        self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                        self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     self.kernels.zo_perturb(cur, -2, zo_eps, seed, z)
                     if mine:
-                        self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                        self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
                     n_forward += 2 * int(mine)
                     continue
@@ -293,9 +300,9 @@ class LayerSparsity:
                     minus, restored = spare
                     self.kernels.zo_perturb_triple(cur, cur, minus, restored, zo_eps, seed, z)
                     param.data = cur            # theta + eps z
-                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen)
+                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     param.data = minus          # theta - eps z
-                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen)
+                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     param.data = restored       # "recovered" weights, with the reference's drift
                     cur, spare = restored, [minus, cur]
                     n_forward += 2
@@ -352,7 +359,16 @@ class LayerSparsity:
                       "forwards": n_forward, "world_size": world}
         return importance
 
-    def _loss_into(self, table, unit, col, batch, cuda_enabled, expected_len):
+    def _couple_rng(self, seed, param):
+        if not self.couple_torch_rng:
+            return
+        torch.manual_seed(seed)
+        if self.z_source != "philox":
+            self._draw_z(seed, param)     # leaves the generator where the reference's draw does
+
+    def _loss_into(self, table, unit, col, batch, cuda_enabled, expected_len, rng=None):
+        if rng is not None:
+            self._couple_rng(*rng)
         with torch.no_grad():
             loss, batch_len = self.loss_func(self.model, batch, cuda_enabled)
         if batch_len != expected_len:

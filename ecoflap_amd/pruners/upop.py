@@ -71,7 +71,11 @@ class _BertWandaMixin:
             model, dataloader, module_to_process, n_samples, sparsity_ratio,
             forward_fn=lambda m, b: self.forward_to_cache(m, b, device),
             cache_keys=["register_hook"], autocast=_NoAutocast, take_first=False, mode="matrix",
-            batch_len=lambda b: b[0].shape[0])
+            batch_len=lambda b: b[0].shape[0],
+            # as shipped (UPop/pruners/wanda_pruner.py:496-497) the NLVR count check expects twice
+            # the rows the ViT saw although its input already holds both images, so the NLVR
+            # entrypoint stops here unless asserts are off (`python -O`); kept, as an `assert`
+            count_factor=2 if (self.task == "nlvr" and self.stage1_mode == "compat") else 1)
 
 
 @registry.register_pruner("blipbert_wanda_pruner")
@@ -132,7 +136,8 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,
             self._mapping(sparsity_ratio_granularity), kernels=self.kernels,
             z_source=self.z_source, process_group=self.process_group,
-            batch_len_fn=lambda b: b[0].shape[0])
+            batch_len_fn=lambda b: b[0].shape[0],
+            couple_torch_rng=(self.task == "retrieval"))     # forward_itm draws its negatives
         self.kernels = ls.kernels
         out = ls.return_sparsity()
         self.stage_stats["stage1"] = dict(ls.stats)

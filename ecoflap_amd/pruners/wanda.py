@@ -158,20 +158,22 @@ class _BlockwiseWanda:
         return inps, [None] * len(inps), caches
 
     def run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
-            cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None):
+            cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None,
+            count_factor=1):
         import time
         t0 = time.time()
         try:
             return self._run(model, dataloader, module_to_process, n_samples, sparsity_ratio,
                              forward_fn, cache_keys, autocast, take_first, mode, optional_keys,
-                             batch_len)
+                             batch_len, count_factor)
         finally:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             self.owner.stage_stats.setdefault("stage2", {})[module_to_process] = time.time() - t0
 
     def _run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
-             cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None):
+             cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None,
+             count_factor=1):
         with torch.no_grad():
             blocks = get_module_recursive(model, module_to_process)
             inps, outs, caches = self.capture(model, dataloader, blocks, forward_fn, cache_keys,
@@ -206,7 +208,7 @@ class _BlockwiseWanda:
             elif self._rank_world()[1] > 1:
                 raise NotImplementedError("data-parallel SparseGPT (all-reduce of the Hessians)")
             for name in subset:
-                assert wrapped[name].nsamples == sum(x.shape[0] for x in inps)
+                assert wrapped[name].nsamples == sum(x.shape[0] for x in inps) * count_factor
                 weight = subset[name].weight.data
                 ratio = sparsity_ratio[f"{module_to_process}.{i}.{name}.weight"]
                 if sparsegpt:           # sparsegpt_pruner.py:394 / :650

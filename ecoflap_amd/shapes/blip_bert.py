@@ -144,15 +144,17 @@ class BertLMHeadModel(nn.Module):
         self.cls.add_module("decoder", nn.Linear(cfg.hidden_size, cfg.vocab_size))
 
     def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                labels):
+                labels, reduction="none"):
         h = self.bert(input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask)
         t = self.cls.transform
         scores = self.cls.decoder(t.LayerNorm(F.gelu(t.dense(h))))
         shifted = scores[:, :-1, :].contiguous()
         tgt = labels[:, 1:].contiguous()
         loss = F.cross_entropy(shifted.view(-1, shifted.size(-1)).float(), tgt.view(-1),
-                               ignore_index=-100, reduction="none", label_smoothing=0.1)
-        return loss.view(scores.size(0), -1).sum(1)       # reduction='none' -> per answer
+                               ignore_index=-100, reduction=reduction, label_smoothing=0.1)
+        if reduction == "none":                           # per answer (UPop/models/med.py:924-925)
+            loss = loss.view(scores.size(0), -1).sum(1)
+        return loss
 
 
 def med_config(hidden=768, layers=12, heads=12, inter=3072, vocab=30524, encoder_width=768):

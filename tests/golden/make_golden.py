@@ -398,6 +398,69 @@ def golden_upop():
     for k, v in model2.state_dict().items():
         out[f"vqa_final::{k}"] = bits(v)
     save("g9_upop_vqa.npz", **out)
+    # the other three UPop entrypoints (caption / nlvr / retrieval), same pruner as shipped
+    from ecoflap_amd.shapes import blip_tasks as T
+    out = {}
+    for tag, task, prefix, mk, bt, seed in [
+        ("coco", "coco", "text_decoder", T.blip_caption_toy, T.caption_batches, 33),
+        ("nlvr", "nlvr", "text_encoder", lambda: T.blip_nlvr_toy(8), T.nlvr_batches, 34),
+        ("retrieval", "retrieval", "text_encoder", T.blip_retrieval_toy, T.retrieval_batches, 35),
+    ]:
+        torch.manual_seed(seed)
+        model = mk().eval()
+        batches = bt(8, 2, img_size=32, vocab=64, length=6, seed=9)
+        for k, v in model.state_dict().items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        cls = BLIPBertLayerWandaPruner
+        if task == "nlvr":
+            # as shipped the NLVR run dies on `assert nsamples == len(inps) * inps[0].shape[0] * 2`
+            # (UPop/pruners/wanda_pruner.py:496-497: the ViT input already holds both images);
+            # the vector is the reference run the way `python -O` runs it (asserts compiled out)
+            path = os.path.join(REF, "UPop/pruners/wanda_pruner.py")
+            mod = types.ModuleType("pruners.wanda_pruner_O")
+            mod.__file__ = path
+            exec(compile(open(path).read(), path, "exec", optimize=1), mod.__dict__)
+            cls = mod.BLIPBertLayerWandaPruner
+        pruner = cls(
+            model, batches, bert_prune_spec="0-0.5-1.0-1.0", vit_prune_spec="0-0.5-1.0-1.0",
+            num_samples=8, bert_model_prefix=prefix, vit_model_prefix="visual_encoder",
+            sparsity_ratio_granularity="block", max_sparsity_per_layer=0.6,
+            score_method="MEZO-GradOnly_sum", num_data_first_stage=8, task=task)
+        model2, _ = pruner.prune()
+        changed = []
+        for k, v in model2.state_dict().items():
+            if not np.array_equal(bits(v), out[f"{tag}_init::{k}"]):
+                out[f"{tag}_final::{k}"] = bits(v)
+                changed.append(k)
+        out[f"{tag}_changed_keys"] = np.array(changed)
+        print(tag, "pruned tensors:", len(changed))
+        if tag != "retrieval":
+            continue
+        # the evident intent of stage 1 on a loss that draws from torch's RNG (hard negatives by
+        # torch.multinomial): the reference's own LayerSparsity on forward_itm, called with the
+        # arguments in their declared order
+        from pruners.layer_single_base_pruner import LayerSparsity as UPopLayerSparsity  # type: ignore
+        from ecoflap_amd.pruners.upop import BLIPBertLayerWandaPruner as Mine, task_forward
+        model.load_state_dict({k: torch.from_numpy(out[f"{tag}_init::{k}"]).view(v.dtype).reshape(v.shape)
+                               if v.dtype == torch.float32 else v
+                               for k, v in model.state_dict().items()})
+        for p_ in model.parameters():
+            p_.requires_grad = True
+        mapping = Mine(model, batches, bert_prune_spec="0-0.5-1.0-1.0",
+                       vit_prune_spec="0-0.5-1.0-1.0", bert_model_prefix=prefix,
+                       vit_model_prefix="visual_encoder", task=task,
+                       kernels=object())._mapping("block")
+        log = LossLog(lambda m, b, c: task_forward("retrieval", m, b, "cpu"))
+        np.random.seed(42)
+        ls = UPopLayerSparsity(model, batches, log, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping)
+        sp = ls.return_sparsity()
+        names = list(mapping.keys())
+        out["retrieval_intended_names"] = np.array(names)
+        out["retrieval_intended_sparsity"] = np.array([sp[k] for k in names], dtype=np.float64)
+        out["retrieval_intended_losses"] = np.array(log.values, dtype=np.float64)
+    save("g13_upop_tasks.npz", **out)
 
 
 # --------------------------------------------------------------------------- G10: SparseGPT

@@ -654,6 +654,40 @@ def test_global_pruners_hip_equals_oracle(kern, golden_dir, tag, fp32):
     assert zeros > 0
 
 
+@pytest.mark.parametrize("tag", ["coco", "nlvr", "retrieval"])
+def test_upop_task_pruners_hip_equals_oracle(kern, golden_dir, tag):
+    """Caption / NLVR / retrieval entrypoint pruners, intended mode (task loss -> zeroth-order table
+    -> Wanda): HIP kernels vs oracle arithmetic on the same GPU forwards."""
+    from oracle_backend import OracleKernels
+    from test_upop_parity import run_task
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels(z_from=_z_from_hip(kern)))):
+        _, model, table = run_task(golden_dir, tag, "intended", backend, device="cuda")
+        res[name] = (table, {k: v.cpu() for k, v in model.state_dict().items()})
+    assert res["hip"][0] == res["oracle"][0]
+    for k, v in res["hip"][1].items():
+        assert torch.equal(v, res["oracle"][1][k]), k
+
+
+@pytest.mark.parametrize("script,stage1", [
+    ("ecoflap_compression_vqa.py", "compat"), ("ecoflap_compress_caption.py", "compat"),
+    ("ecoflap_compress_nlvr.py", "intended"), ("ecoflap_compression_retrieval_flickr.py", "intended")])
+def test_upop_entrypoints_run(script, stage1):
+    """The four UPop entrypoint names on toy shapes: prune + one masked fine-tune step."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("upop_entry_" + script[:-3],
+                                                  os.path.join(root, "UPop", script))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    model, table = mod.main(["--toy", "--num_data", "8", "--batch_size", "2", "--stage1", stage1,
+                             "--finetune_steps", "1"])
+    blocks = [v for k, v in model.state_dict().items()
+              if v.dim() == 2 and (".blocks." in k or ".layer." in k) and not k.split(".")[0].endswith("_m")]
+    frac = sum(int((v == 0).sum()) for v in blocks) / sum(v.numel() for v in blocks)
+    assert 0.4 < frac < 0.6
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused
