@@ -83,5 +83,5 @@ def run(task, argv=None):
             loss.backward()
             apply_masks_to_grads(model, masks, kernels=pruner.kernels)   # grad *= mask (K8)
             opt.step()
-            print("finetune step", step, float(loss))
+            print("finetune step", step, float(loss.detach()))
     return model, table
