@@ -131,6 +131,14 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
             return _UniformSparsity(original_sparsity)          # as shipped
         device = next(iter(self.model.parameters())).device
         loss_func = lambda m, batch, cuda_enabled: task_forward(self.task, m, batch, device)  # noqa: E731
+        if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
+                and str(self.score_method).startswith("MEZO")):
+            # same losses, bit for bit, re-entering at the block that owns the scored matrix
+            # (the shapes' forward IS the composition of their stages); eager replay: VQA
+            # batches carry a varying number of answers, so shapes differ from batch to batch
+            from .prefix_cache import PrefixCachedLoss
+            loss_func = PrefixCachedLoss(self.model, kind="vision_language",
+                                         batch_len_fn=lambda b: b[0].shape[0], use_graphs=False)
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

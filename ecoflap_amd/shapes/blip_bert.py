@@ -117,8 +117,8 @@ class BertModel(nn.Module):
         self.encoder = _Encoder(cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
                                 cfg.intermediate_size, cfg.encoder_width)
 
-    def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                mode="multimodal"):
+    def prepare(self, input_ids, attention_mask, encoder_attention_mask):
+        """Embeddings and the extended (additive) masks -> (h, ext, enc_ext)."""
         h = self.embeddings(input_ids)
         dtype = h.dtype
         L = input_ids.shape[1]
@@ -127,10 +127,19 @@ class BertModel(nn.Module):
             m = m * torch.tril(torch.ones(L, L, device=h.device, dtype=dtype))[None, None]
         ext = (1.0 - m) * torch.finfo(dtype).min
         enc_ext = (1.0 - encoder_attention_mask[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
-        for layer in self.encoder.layer:
-            h = layer(h, attention_mask=ext, head_mask=None,
-                      encoder_hidden_states=encoder_hidden_states,
-                      encoder_attention_mask=enc_ext, output_attentions=False, mode=mode)[0]
+        return h, ext, enc_ext
+
+    def run_layer(self, i, h, ext, encoder_hidden_states, enc_ext, mode="multimodal"):
+        return self.encoder.layer[i](h, attention_mask=ext, head_mask=None,
+                                     encoder_hidden_states=encoder_hidden_states,
+                                     encoder_attention_mask=enc_ext, output_attentions=False,
+                                     mode=mode)[0]
+
+    def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                mode="multimodal"):
+        h, ext, enc_ext = self.prepare(input_ids, attention_mask, encoder_attention_mask)
+        for i in range(len(self.encoder.layer)):
+            h = self.run_layer(i, h, ext, encoder_hidden_states, enc_ext, mode)
         return h
 
 
@@ -146,6 +155,9 @@ class BertLMHeadModel(nn.Module):
     def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
                 labels, reduction="none"):
         h = self.bert(input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask)
+        return self.lm_loss(h, labels, reduction)
+
+    def lm_loss(self, h, labels, reduction="none"):
         t = self.cls.transform
         scores = self.cls.decoder(t.LayerNorm(F.gelu(t.dense(h))))
         shifted = scores[:, :-1, :].contiguous()
@@ -183,6 +195,38 @@ class _UPopViT(VisionTransformer):
         return self.norm(x)
 
 
+def vit_stages(owner, vit):
+    """Stage entries of a UPop ViT: embed, then one per block (state key "x")."""
+    plan = []
+
+    def embed(batch):
+        st = owner.unpack(batch)
+        st["x"] = vit.embed(st.pop("image"))
+        return st
+
+    plan.append(("visual_encoder.embed", ["visual_encoder.patch_embed.", "visual_encoder.cls_token",
+                                          "visual_encoder.pos_embed"], embed))
+    for i in range(len(vit.blocks)):
+        def block(st, i=i):
+            new = dict(st)
+            new["x"] = vit.blocks[i](st["x"], False)
+            return new
+        plan.append((f"visual_encoder.blocks.{i}", [f"visual_encoder.blocks.{i}."], block))
+    return plan
+
+
+def bert_stages(prefix, bert, key="h", mode="multimodal"):
+    """One stage per BERT layer on state keys (key, "ext", "enc", "enc_ext")."""
+    plan = []
+    for i in range(len(bert.encoder.layer)):
+        def layer(st, i=i):
+            new = dict(st)
+            new[key] = bert.run_layer(i, st[key], st["ext"], st["enc"], st["enc_ext"], mode)
+            return new
+        plan.append((f"{prefix}.encoder.layer.{i}", [f"{prefix}.encoder.layer.{i}."], layer))
+    return plan
+
+
 class BlipVQA(nn.Module):
     def __init__(self, vit_kwargs=None, cfg=None, init_std=0.02):
         super().__init__()
@@ -205,22 +249,60 @@ class BlipVQA(nn.Module):
     def encode_image(self, image):
         return self.visual_encoder(image.to(self.device))
 
-    def forward(self, image, question, answer=None, n=None, weights=None, train=True):
+    # --- staged forward: the scoring loop may re-enter at any stage boundary (the contract of
+    # --- ecoflap_amd/pruners/prefix_cache.py; `forward` is the composition of the stages)
+    def unpack(self, batch):
+        image, question, answer, weights, n = batch
         dev = self.device
-        image, question, answer = image.to(dev), question.to(dev), answer.to(dev)
-        weights = weights.to(dev)
-        pad = self.text_encoder.config.pad_token_id
-        image_embeds = self.visual_encoder(image)
-        image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long, device=dev)
-        q_mask = (question != pad).long()
-        q_out = self.text_encoder(question, q_mask, image_embeds, image_atts)
         rep = torch.repeat_interleave(torch.arange(len(n), device=dev),
                                       torch.as_tensor(list(n), device=dev))
-        q_states, q_atts = q_out[rep], q_mask[rep]
-        a_mask = (answer != pad).long()
-        targets = answer.masked_fill(answer == pad, -100)
-        per_answer = self.text_decoder(answer, a_mask, q_states, q_atts, targets)
-        return (weights * per_answer).sum() / image.size(0)
+        return {"image": image.to(dev), "question": question.to(dev), "answer": answer.to(dev),
+                "weights": weights.to(dev), "rep": rep}
+
+    def stage_plan(self):
+        enc, dec = self.text_encoder, self.text_decoder
+        pad = enc.config.pad_token_id
+        plan = vit_stages(self, self.visual_encoder)
+
+        def question_embed(st):
+            image_embeds = self.visual_encoder.norm(st["x"])
+            image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long,
+                                    device=image_embeds.device)
+            q_mask = (st["question"] != pad).long()
+            h, ext, enc_ext = enc.prepare(st["question"], q_mask, image_atts)
+            return {"h": h, "ext": ext, "enc": image_embeds, "enc_ext": enc_ext, "q_mask": q_mask,
+                    "answer": st["answer"], "weights": st["weights"], "rep": st["rep"],
+                    "batch": st["x"].shape[0]}
+
+        plan.append(("text_encoder.embed", ["visual_encoder.norm.", "text_encoder.embeddings."],
+                     question_embed))
+        plan += bert_stages("text_encoder", enc)
+
+        def answer_embed(st):
+            rep = st["rep"]
+            q_states, q_atts = st["h"][rep], st["q_mask"][rep]
+            answer = st["answer"]
+            a_mask = (answer != pad).long()
+            h, ext, enc_ext = dec.bert.prepare(answer, a_mask, q_atts)
+            return {"a": h, "ext": ext, "enc": q_states, "enc_ext": enc_ext,
+                    "targets": answer.masked_fill(answer == pad, -100), "weights": st["weights"],
+                    "batch": st["batch"]}
+
+        plan.append(("text_decoder.embed", ["text_decoder.bert.embeddings."], answer_embed))
+        plan += bert_stages("text_decoder.bert", dec.bert, key="a")
+
+        def head(st):
+            per_answer = dec.lm_loss(st["a"], st["targets"])
+            return {"loss": (st["weights"] * per_answer).sum() / st["batch"]}
+
+        plan.append(("text_decoder.cls", ["text_decoder.cls."], head))
+        return plan
+
+    def forward(self, image, question, answer=None, n=None, weights=None, train=True):
+        state = (image, question, answer, weights, n)
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state["loss"]
 
 
 def blip_vqa_base():

@@ -20,8 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .blip_bert import (BertLMHeadModel, BertLayer, BertModel, _Dense, _Embeddings, _SelfAttention,
-                        _UPopViT, med_config)
+from .blip_bert import (BertLMHeadModel, BertLayer, BertModel, _Embeddings, _SelfAttention,
+                        _UPopViT, bert_stages, med_config, vit_stages)
 
 
 def _init_text(modules, init_std):
@@ -54,16 +54,38 @@ class BlipCaption(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    # staged forward (contract of ecoflap_amd/pruners/prefix_cache.py)
+    def unpack(self, batch):
+        image, caption = batch[0], batch[1]
+        return {"image": image.to(self.device), "caption": caption.to(self.device)}
+
+    def stage_plan(self):
+        dec = self.text_decoder
+        pad = dec.config.pad_token_id
+        plan = vit_stages(self, self.visual_encoder)
+
+        def caption_embed(st):
+            image_embeds = self.visual_encoder.norm(st["x"])
+            image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long,
+                                    device=image_embeds.device)
+            caption = st["caption"]
+            targets = caption.masked_fill(caption == pad, -100)
+            targets[:, :self.prompt_length] = -100
+            h, ext, enc_ext = dec.bert.prepare(caption, (caption != pad).long(), image_atts)
+            return {"h": h, "ext": ext, "enc": image_embeds, "enc_ext": enc_ext, "targets": targets}
+
+        plan.append(("text_decoder.embed", ["visual_encoder.norm.", "text_decoder.bert.embeddings."],
+                     caption_embed))
+        plan += bert_stages("text_decoder.bert", dec.bert)
+        plan.append(("text_decoder.cls", ["text_decoder.cls."],
+                     lambda st: {"loss": dec.lm_loss(st["h"], st["targets"], reduction="mean")}))
+        return plan
+
     def forward(self, image, caption):
-        dev = self.device
-        image, caption = image.to(dev), caption.to(dev)
-        pad = self.text_decoder.config.pad_token_id
-        image_embeds = self.visual_encoder(image)
-        image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long, device=dev)
-        mask = (caption != pad).long()
-        targets = caption.masked_fill(caption == pad, -100)
-        targets[:, :self.prompt_length] = -100
-        return self.text_decoder(caption, mask, image_embeds, image_atts, targets, reduction="mean")
+        state = (image, caption)
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state["loss"]
 
 
 def blip_caption_base():
@@ -132,17 +154,25 @@ class NLVRBertModel(nn.Module):
             [NLVRBertLayer(cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size,
                            cfg.encoder_width, i) for i in range(cfg.num_hidden_layers)])
 
-    def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                mode="multimodal"):
+    def prepare(self, input_ids, attention_mask, encoder_attention_mask):
         h = self.embeddings(input_ids)
         dtype = h.dtype
         ext = (1.0 - attention_mask[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
         enc_ext = [(1.0 - m[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
                    for m in encoder_attention_mask]
-        for layer in self.encoder.layer:
-            h = layer(h, attention_mask=ext, head_mask=None,
-                      encoder_hidden_states=encoder_hidden_states,
-                      encoder_attention_mask=enc_ext, output_attentions=False, mode=mode)[0]
+        return h, ext, enc_ext
+
+    def run_layer(self, i, h, ext, encoder_hidden_states, enc_ext, mode="multimodal"):
+        return self.encoder.layer[i](h, attention_mask=ext, head_mask=None,
+                                     encoder_hidden_states=encoder_hidden_states,
+                                     encoder_attention_mask=enc_ext, output_attentions=False,
+                                     mode=mode)[0]
+
+    def forward(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                mode="multimodal"):
+        h, ext, enc_ext = self.prepare(input_ids, attention_mask, encoder_attention_mask)
+        for i in range(len(self.encoder.layer)):
+            h = self.run_layer(i, h, ext, encoder_hidden_states, enc_ext, mode)
         return h
 
 
@@ -160,17 +190,50 @@ class BlipNLVR(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def forward(self, image, text, targets, train=True):
+    # staged forward (contract of ecoflap_amd/pruners/prefix_cache.py); a scoring batch is the
+    # reference's tuple (image0, image1, text, targets), a direct call passes the images joined
+    def unpack(self, batch):
         dev = self.device
-        image, text, targets = image.to(dev), text.to(dev), targets.to(dev)
-        pad = self.text_encoder.config.pad_token_id
-        image_embeds = self.visual_encoder(image)
-        image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long, device=dev)
-        image0, image1 = torch.split(image_embeds, targets.size(0))
-        out = self.text_encoder(text, (text != pad).long(), [image0, image1],
-                                [image_atts[:image0.size(0)], image_atts[image0.size(0):]])
-        prediction = self.cls_head(out[:, 0, :])
-        return F.cross_entropy(prediction, targets) if train else prediction
+        if len(batch) == 4:
+            image0, image1, text, targets = batch
+            image = torch.cat([image0, image1], dim=0)
+        else:
+            image, text, targets = batch
+        return {"image": image.to(dev), "text": text.to(dev), "targets": targets.to(dev)}
+
+    def stage_plan(self, train=True):
+        enc = self.text_encoder
+        pad = enc.config.pad_token_id
+        plan = vit_stages(self, self.visual_encoder)
+
+        def text_embed(st):
+            image_embeds = self.visual_encoder.norm(st["x"])
+            image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long,
+                                    device=image_embeds.device)
+            n = st["targets"].size(0)
+            image0, image1 = torch.split(image_embeds, n)
+            text = st["text"]
+            h, ext, enc_ext = enc.prepare(text, (text != pad).long(),
+                                          [image_atts[:image0.size(0)], image_atts[image0.size(0):]])
+            return {"h": h, "ext": ext, "enc": [image0, image1], "enc_ext": enc_ext,
+                    "targets": st["targets"]}
+
+        plan.append(("text_encoder.embed", ["visual_encoder.norm.", "text_encoder.embeddings."],
+                     text_embed))
+        plan += bert_stages("text_encoder", enc)
+
+        def head(st):
+            prediction = self.cls_head(st["h"][:, 0, :])
+            return {"loss": F.cross_entropy(prediction, st["targets"]) if train else prediction}
+
+        plan.append(("cls_head", ["cls_head."], head))
+        return plan
+
+    def forward(self, image, text, targets, train=True):
+        state = (image, text, targets)
+        for _, _, fn in self.stage_plan(train):
+            state = fn(state)
+        return state["loss"]
 
 
 def blip_nlvr_base():

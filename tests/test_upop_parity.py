@@ -204,3 +204,27 @@ def test_retrieval_stage1_replays_torch_rng_coupling(golden_dir, k1_form):
     sp = ls.return_sparsity()
     np.testing.assert_allclose(np.array(losses), g["retrieval_intended_losses"], rtol=1e-6)
     assert np.array_equal(np.array([sp[k] for k in names]), g["retrieval_intended_sparsity"])
+
+
+@pytest.mark.parametrize("tag", ["vqa", "coco", "nlvr"])
+def test_upop_suffix_only_reforward_is_exact(golden_dir, tag):
+    """Intended-mode stage 1 through the prefix cache == the same run with full forwards:
+    loss table, sparsity table and drifted weights identical."""
+    res = {}
+    for cached in (True, False):
+        if tag == "vqa":
+            _, model, batches = _model(golden_dir)
+            prefix, task = "text_decoder", "vqa"
+        else:
+            _, model, batches, prefix, task = _task_setup(golden_dir, tag)
+        np.random.seed(42)
+        pruner = _task_pruner(model, batches, prefix, task, "intended", OracleKernels())
+        pruner.prefix_cache = cached
+        for p in model.parameters():
+            p.requires_grad = True
+        table = pruner.get_sparsity(0.5, "block")
+        res[cached] = (table, {k: v.clone() for k, v in model.state_dict().items()},
+                       dict(pruner.stage_stats["stage1"]))
+    assert res[True][0] == res[False][0]
+    for k, v in res[True][1].items():
+        assert torch.equal(v, res[False][1][k]), k
