@@ -42,6 +42,11 @@ def task_forward(task, model, batch, device="cuda"):
     return model(batch), 1
 
 
+def _shape_signature(batch):
+    return tuple((tuple(t.shape), str(t.dtype)) if torch.is_tensor(t) else
+                 (tuple(t) if isinstance(t, (list, tuple)) else t) for t in batch)
+
+
 class _NoAutocast:
     def __enter__(self):
         return self
@@ -134,11 +139,15 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
         if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO")):
             # same losses, bit for bit, re-entering at the block that owns the scored matrix
-            # (the shapes' forward IS the composition of their stages); eager replay: VQA
-            # batches carry a varying number of answers, so shapes differ from batch to batch
+            # (the shapes' forward IS the composition of their stages).  HIP-graph replay on two
+            # lanes when every batch has the same shapes (caption, NLVR); VQA batches carry a
+            # varying number of answers and replay eagerly
             from .prefix_cache import PrefixCachedLoss
+            uniform = len({_shape_signature(b) for b in self.data_loader}) == 1
+            graphs = (uniform and device.type == "cuda" and bool(getattr(self, "use_graphs", True)))
             loss_func = PrefixCachedLoss(self.model, kind="vision_language",
-                                         batch_len_fn=lambda b: b[0].shape[0], use_graphs=False)
+                                         batch_len_fn=lambda b: b[0].shape[0], use_graphs=graphs,
+                                         n_lanes=int(getattr(self, "n_lanes", 2)) if graphs else 1)
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

@@ -688,6 +688,29 @@ def test_upop_entrypoints_run(script, stage1):
     assert 0.4 < frac < 0.6
 
 
+@pytest.mark.parametrize("tag", ["coco", "nlvr"])
+def test_upop_graph_replay_equals_full_forward(kern, golden_dir, tag):
+    """Intended-mode stage 1 on the GPU: HIP-graph replay of the suffix on two lanes == eager
+    full forwards (sparsity table and drifted weights identical)."""
+    from test_upop_parity import _task_pruner, _task_setup
+    res = {}
+    for cached in (True, False):
+        _, model, batches, prefix, task = _task_setup(golden_dir, tag)
+        model.to("cuda")
+        batches = [tuple(t.to("cuda") if torch.is_tensor(t) else t for t in b) for b in batches]
+        np.random.seed(42)
+        pruner = _task_pruner(model, batches, prefix, task, "intended", kern)
+        pruner.z_source = "philox"
+        pruner.prefix_cache = cached
+        for p in model.parameters():
+            p.requires_grad = True
+        table = pruner.get_sparsity(0.5, "block")
+        res[cached] = (table, {k: v.cpu() for k, v in model.state_dict().items()})
+    assert res[True][0] == res[False][0]
+    for k, v in res[True][1].items():
+        assert torch.equal(v, res[False][1][k]), k
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused
