@@ -165,3 +165,72 @@ def test_real_two_ranks_agree_and_track_single_process(tmp_path):
     assert r0 == r1
     diffs = [abs(r0[k] - single[k]) for k in single]
     assert max(diffs) < 0.02 and sum(single.values()) > 0
+
+
+# ---------------------------------------------------------------- SparseGPT, Hessian all-reduce
+def _run_sparsegpt(rank, world):
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    torch.set_num_threads(1)
+    torch.manual_seed(4)
+    model = blip2_toy().eval()
+    batches = S.image_text_batches(8, 1, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    np.random.seed(42)
+    cfg = dict(t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+               t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+               max_sparsity_per_layer=0.6, num_data_first_stage=8,
+               sparsity_ratio_granularity=None, score_method="MEZO-GradOnly_sum",
+               kernels=OracleKernels(), z_source=torch_cpu_normal)
+    model, _ = load_pruner("blipt5_sparsegpt_pruner", model, batches, cfg=cfg).prune()
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}, _merged_hessian(rank, world)
+
+
+def _merged_hessian(rank, world):
+    """The merge itself on one Linear: 6 ragged batches split over the ranks."""
+    from types import SimpleNamespace
+    from oracle_backend import OracleKernels
+    from ecoflap_amd.pruners.sparsegpt import SparseGPT
+    from ecoflap_amd.pruners.wanda import _BlockwiseWanda
+    g = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(24, 8)
+    xs = [torch.randn(1 + (i % 3), 5, 24, generator=g) for i in range(6)]
+    w = SparseGPT(lin, kernels=OracleKernels())
+    for i, x in enumerate(xs):
+        if i % world == rank:
+            w.add_batch(x, None)
+    owner = SimpleNamespace(kernels=OracleKernels(), process_group=None)
+    _BlockwiseWanda(owner)._merge_hessians({"lin": w})
+    return w.H.clone()
+
+
+def _sparsegpt_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.save(_run_sparsegpt(rank, world), os.path.join(out_dir, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sparsegpt_hessian_allreduce(tmp_path):
+    """blipt5_sparsegpt_pruner under DP=2: calibration batches sharded, one all-reduce of the
+    count-weighted Hessians per block -> both replicas hold identical pruned weights; against one
+    process the Hessian sums re-associate, so the OBS result agrees to rounding."""
+    single, h_single = _run_sparsegpt(0, 1)
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_sparsegpt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, h0 = torch.load(tmp_path / "s0.pt", weights_only=False)
+    w1, h1 = torch.load(tmp_path / "s1.pt", weights_only=False)
+    assert torch.equal(h0, h1)
+    torch.testing.assert_close(h0, h_single, rtol=1e-5, atol=1e-6)   # = (2/N) sum x x^T
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
+    blocks = [k for k, v in w0.items() if v.dim() == 2 and ".block" in k]
+    agree = sum(int(((w0[k] == 0) == (single[k] == 0)).sum()) for k in blocks)
+    total = sum(w0[k].numel() for k in blocks)
+    zeros = sum(int((w0[k] == 0).sum()) for k in blocks)
+    # toy Hessians are rank-deficient (fewer tokens than columns): OBS amplifies the rounding
+    assert agree / total > 0.95 and 0.45 < zeros / total < 0.55
