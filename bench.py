@@ -276,6 +276,7 @@ def main():
         "breakdown": {
             "model_build_s": build_s,
             "forwards_total": ls.stats.get("forwards"),
+            "host_enqueue_ms_per_step": 1e3 * ls.stats.get("host_enqueue_seconds", 0.0) / args.steps,
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
             "suffix_forward": (dict(run.loss_fns[-1].stats)

@@ -317,6 +317,7 @@ class LayerSparsity:
             param.data = home
             del spare
 
+        t_enqueued = time.time() - t0            # host done; the device may still be replaying
         if world > 1:
             self._all_reduce_sum(table)          # each entry is written by exactly one rank
         # (loss1 - loss2) / (2 eps) with torch's own fp32 tensor ops on the loss tensors'
@@ -356,7 +357,8 @@ class LayerSparsity:
         else:
             raise ValueError(f"unknown zeroth-order score_method {self.score_method!r}")
         self.stats = {"seconds": time.time() - t0, "layers": len(names), "units": n_units,
-                      "forwards": n_forward, "world_size": world}
+                      "forwards": n_forward, "world_size": world,
+                      "host_enqueue_seconds": t_enqueued}
         return importance
 
     def _couple_rng(self, seed, param):
