@@ -55,6 +55,50 @@ def _copy_tensors(dst, src):
             _copy_tensors(d, s_)
 
 
+def _is_batched(t, B):
+    return torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == B
+
+
+def _cat_states(states, B):
+    """k per-evaluation states -> one state whose batch-leading tensors are concatenated along
+    dim 0; everything else (position biases, python scalars) is shared by construction."""
+    first = states[0]
+    if torch.is_tensor(first):
+        return torch.cat(states, 0) if _is_batched(first, B) else first.clone()
+    if isinstance(first, dict):
+        return {k: _cat_states([st[k] for st in states], B) for k in first}
+    if isinstance(first, (list, tuple)):
+        return type(first)(_cat_states([st[i] for st in states], B) for i in range(len(first)))
+    return first
+
+
+def _copy_slot(dst, src, i, B):
+    """Write one evaluation's state into slot i of a concatenated static state."""
+    if torch.is_tensor(dst):
+        if _is_batched(src, B) and dst.shape[0] != src.shape[0]:
+            dst[i * B:(i + 1) * B].copy_(src, non_blocking=True)
+        elif i == 0:
+            dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_slot(dst[k], src[k], i, B)
+    elif isinstance(dst, (list, tuple)):
+        for d, s_ in zip(dst, src):
+            _copy_slot(d, s_, i, B)
+
+
+def _slice_state(state, i, B, k):
+    if torch.is_tensor(state):
+        if k > 1 and state.dim() > 0 and state.shape[0] == k * B:
+            return state[i * B:(i + 1) * B]
+        return state
+    if isinstance(state, dict):
+        return {a: _slice_state(b, i, B, k) for a, b in state.items()}
+    if isinstance(state, (list, tuple)):
+        return type(state)(_slice_state(b, i, B, k) for b in state)
+    return state
+
+
 class PrefixCachedLoss:
     """use_graphs=True (GPU only): the suffix from each entry stage is captured once into a
     HIP graph (torch.cuda.CUDAGraph -> hipGraph) and replayed for every later unit that
@@ -64,9 +108,22 @@ class PrefixCachedLoss:
     into the parameter's own storage instead of re-pointing `param.data`."""
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
-                 two_lanes=False, n_lanes=None):
+                 two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries"):
         self.model = model
         self.use_graphs = bool(use_graphs)
+        # eval_batch = k > 1 (graphs only): k evaluations of a layer (theta+/theta- of k/2 units)
+        # share everything downstream of the block that owns the perturbed matrix, so that part
+        # runs ONCE on their states concatenated along the batch dimension (see `_batched`)
+        assert eval_batch >= 1 and (eval_batch == 1 or eval_batch % 2 == 0)
+        self.eval_batch = int(eval_batch) if self.use_graphs else 1
+        # "entries": the first chunk of every (entry stage, first shared stage) pair is also run
+        # sequentially and compared bit for bit; "all": every chunk (tests on toy shapes, where a
+        # whole-tensor comparison of a few hundred values can agree by luck); "first": 4 chunks
+        assert verify_batched in ("first", "entries", "all")
+        self.verify_batched = verify_batched
+        self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
+        self._verified = set()      # (entry, S) whose batched losses were checked bit for bit
+        self.invariant = {}         # stage -> batch invariant on this system (probed)
         if n_lanes is None:
             n_lanes = 2 if two_lanes else 1
         assert n_lanes in (1, 2, 4, 6, 8)
@@ -143,15 +200,18 @@ class PrefixCachedLoss:
 
     # ---- both evaluations of one unit at once (LayerSparsity uses it when present) -----------
     def supports_pairs(self):
-        return self.n_lanes > 1
+        return self.n_lanes > 1 or self.eval_batch > 1
 
     def pairs_in_flight(self):
+        if self.eval_batch > 1:
+            return self.eval_batch // 2
         return max(1, self.n_lanes // 2)
 
     def begin_layer_weights(self, name, home):
         """Called once per layer: `home` is the parameter's own storage (lane 0)."""
         self._pair_name, self._pair_home = name, home
-        if self.n_lanes > 1 and self.extra_lanes is None and home.device.type == "cuda":
+        if (self.n_lanes > 1 and self.eval_batch == 1 and self.extra_lanes is None
+                and home.device.type == "cuda"):
             self.extra_lanes = [_Lane(self) for _ in range(self.n_lanes - 1)]
 
     def end_layer_weights(self, final):
@@ -167,7 +227,13 @@ class PrefixCachedLoss:
         evals = []
         for samples, tp, tm in items:
             evals += [(samples, tp), (samples, tm)]
-        can_fork = self.extra_lanes is not None and self._warmed
+        if self.eval_batch > 1:
+            losses = self._batched(model, evals, cuda_enabled)
+            if losses is not None:
+                return [(losses[2 * i], losses[2 * i + 1], self._batch_len(items[i][0]))
+                        for i in range(len(items))]
+        can_fork = (self.extra_lanes is not None and self._warmed
+                    and len(evals) <= len(self.extra_lanes) + 1)
         states = []
         for samples, _ in evals:
             key = id(samples)
@@ -192,6 +258,149 @@ class PrefixCachedLoss:
             self._account(states[0][0])
         return [(losses[2 * i], losses[2 * i + 1], self._batch_len(items[i][0]))
                 for i in range(len(items))]
+
+    # ---- k evaluations, shared suffix run once --------------------------------------------
+    def _sequential(self, model, evals, cuda_enabled):
+        out = []
+        for samples, theta in evals:
+            self._pair_home.copy_(theta)
+            l, _ = self(model, samples, cuda_enabled)
+            out.append(l.clone())
+        return out
+
+    def _probe_invariance(self, entry, evals, states, B):
+        """Which stages after `entry` give every slot of a batch-concatenated state exactly the
+        bits they give that evaluation alone?  Arithmetic order is data independent, so one
+        bitwise comparison of whole activation tensors per stage decides it for this shape.
+        (Measured on MI355X / hipBLASLt: every FlanT5 stage is; the ViT-g blocks are not beyond
+        4 concatenated evaluations — their fp16 GEMMs are Stream-K kernels, whose split of the
+        K loop depends on the tile position — and the fp32 Q-Former is not in its last slot.)"""
+        k, n = self.eval_batch, len(self.plan)
+        with torch.no_grad():
+            ins = []
+            for (samples, theta), (_, st) in zip(evals, states):
+                self._pair_home.copy_(theta)
+                ins.append(self.plan[entry][2](st))
+            while len(ins) < k:
+                ins.append(ins[-1])
+            for j in range(entry + 1, n - 1):
+                outs = [self.plan[j][2](x) for x in ins]
+                both = self.plan[j][2](_cat_states(ins, B))
+                same = True
+                for i, o in enumerate(outs):
+                    got = _slice_state(both, i, B, k)
+                    flat_a, flat_b = [], []
+                    _map_tensors(o, lambda t: flat_a.append(t) or t)
+                    _map_tensors(got, lambda t: flat_b.append(t) or t)
+                    if len(flat_a) != len(flat_b) or not all(
+                            a.shape == b_.shape and torch.equal(a, b_) for a, b_ in zip(flat_a, flat_b)):
+                        same = False
+                        break
+                self.invariant[j] = same
+                ins = outs
+        self.stats["invariance_probes"] = self.stats.get("invariance_probes", 0) + 1
+        self.stats["stages_not_batch_invariant"] = sorted(
+            self.plan[j][0] for j, ok in self.invariant.items() if not ok)
+
+    def _batch_from(self, entry, evals, states, B):
+        """First stage S > entry such that S..n-2 are all batch invariant (None: nothing to share)."""
+        n = len(self.plan)
+        if any(j not in self.invariant for j in range(entry + 1, n - 1)):
+            self._probe_invariance(entry, evals, states, B)
+        S = n - 1
+        while S - 1 > entry and self.invariant.get(S - 1, False):
+            S -= 1
+        return S if S <= n - 2 else None
+
+    def _batched(self, model, evals, cuda_enabled):
+        """losses of `evals` = [(samples, theta)] (all for the layer announced by begin_layer).
+        Every evaluation of a layer shares all weights downstream of the block that owns the
+        perturbed matrix.  Each evaluation runs alone (batch B graphs) from the owning stage up
+        to stage S-1; its state goes into slot i of ONE state of batch k*B; stages S..n-2 run
+        once on that state; the last stage (loss head) runs per slot, so each loss is reduced
+        over its own batch exactly as alone.  S is the first stage from which everything is
+        batch invariant on this system (`_probe_invariance`), so slot i of the shared part
+        carries exactly the bits of the evaluation run alone; the first chunks are also checked
+        end to end against the sequential losses.  Returns None when this chunk has to run
+        sequentially (warm-up, nothing to share)."""
+        k, n = self.eval_batch, len(self.plan)
+        entry = self.entry
+        if not self._warmed or entry < 1 or len(evals) > k:
+            return None
+        states = []
+        for samples, _ in evals:
+            key = id(samples)
+            self._ensure_cached(key, samples)
+            states.append(self.cache[key])
+        if not all(idx == entry and _on_gpu(st) for idx, st in states):
+            return None
+        B = self._batch_len(evals[0][0])
+        S = self._batch_from(entry, evals, states, B)
+        if S is None:
+            return None
+        if self.chain is None:
+            self.chain = _StageGraphs(self, self.plan, stream=None)
+        bundle = self.bchains.get(k)
+        if bundle is None:
+            bundle = [_StageGraphs(self, self.plan, stream=None), None, None]
+            self.bchains[k] = bundle
+        bchain = bundle[0]
+        captured = S in bchain.graphs
+        # 1. the per-evaluation part: owning stage (its theta in the parameter's storage), then
+        #    the not-shareable stages, into the slots of the batched input
+        outs = []
+        for i, ((samples, theta), (_, st)) in enumerate(zip(evals, states)):
+            self._pair_home.copy_(theta)
+            out = self.chain.run_stage(entry, st)
+            if S > entry + 1:
+                out = self.chain.replay(entry + 1, out, stop=S)
+            if captured:
+                _copy_slot(bchain.graphs[S][1], out, i, B)
+            else:
+                outs.append(_map_tensors(out, lambda t: t.clone()))
+        if not captured:
+            while len(outs) < k:
+                outs.append(outs[-1])
+            cat = _cat_states(outs, B)
+            bchain.ensure(S, cat, stop=n - 1)
+            _copy_tensors(bchain.graphs[S][1], cat)
+        # 2. shared suffix, once, on batch k*B
+        mid = bchain.replay(S, None, stop=n - 1)
+        # 3. loss head per slot (one graph for all slots)
+        if bundle[1] is None:
+            losses = torch.zeros(k, dtype=torch.float32, device=self._pair_home.device)
+            with torch.no_grad():
+                for i in range(k):      # eager once: library handles, workspaces
+                    losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, pool=bchain.pool):
+                    for i in range(k):
+                        losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
+            bundle[1], bundle[2] = graph, losses
+            self.stats["graph_captures"] += 1
+        bundle[1].replay()
+        for _ in evals:
+            self.stats["stage_calls"] += (S - entry) + (n - S) / k
+            self.stats["stage_calls_full"] += n
+        self.stats["batched_evals"] = self.stats.get("batched_evals", 0) + len(evals)
+        losses = [bundle[2][i].clone() for i in range(len(evals))]
+        import os
+        check = (self.verify_batched == "all" or bool(os.environ.get("ECOFLAP_VERIFY_BATCHED"))
+                 or ((entry, S) not in self._verified
+                     and (self.verify_batched == "entries" or len(self._verified) < 4)))
+        if check:
+            self._verified.add((entry, S))
+            want = self._sequential(model, evals, cuda_enabled)
+            same = all(torch.equal(a, b) for a, b in zip(losses, want))   # one sync
+            self.stats["batched_checks"] = self.stats.get("batched_checks", 0) + 1
+            if not same:
+                if os.environ.get("ECOFLAP_DEBUG_BATCHED"):
+                    print("batched mismatch at", self.plan[entry][0], "S", S, [float(x) for x in losses],
+                          [float(x) for x in want], flush=True)
+                self.stats["batched_disabled_at"] = self.plan[entry][0]
+                self.eval_batch = 1
+            return want
+        return losses
 
     def pair(self, model, samples, cuda_enabled, theta_plus, theta_minus):
         return self.multi(model, [(samples, theta_plus, theta_minus)], cuda_enabled)[0]
@@ -228,6 +437,7 @@ class _StageGraphs:
         self.plan = plan
         self.stream = stream            # None: torch's capture side stream / current stream
         self.graphs = {}                # stage -> (graph, static_in, static_out)
+        self.solo = {}                  # stage -> the same, captured standalone (run_stage)
         self.pool = None
         self.bridges = {}               # stage -> tensors to copy into its static input
 
@@ -250,18 +460,32 @@ class _StageGraphs:
         self.owner.stats["capture_seconds"] += time.time() - t0
         return out
 
-    def ensure(self, idx, state):
-        """Make sure stages idx..end are captured, chained output -> input."""
-        n = len(self.plan)
-        if idx in self.graphs and all(j in self.graphs for j in range(idx, n)):
-            return
-        static_in = _map_tensors(state, lambda t: t.clone())
+    def run_stage(self, j, state):
+        """Replay stage j alone on `state`; returns its static output (captured on first use)."""
+        if j in self.graphs and j not in self.solo:      # already part of the chain: replay it alone
+            _copy_tensors(self.graphs[j][1], state)
+            self.graphs[j][0].replay()
+            return self.graphs[j][2]
+        if j not in self.solo:       # kept apart from the chain
+            self._capture(j, _map_tensors(state, lambda t: t.clone()))
+            self.solo[j] = self.graphs.pop(j)
+        _copy_tensors(self.solo[j][1], state)
+        self.solo[j][0].replay()
+        return self.solo[j][2]
+
+    def ensure(self, idx, state, stop=None):
+        """Make sure stages idx..stop-1 are captured, chained output -> input (stages captured
+        earlier from another entry are joined by a copy at replay: `bridges`)."""
+        n = len(self.plan) if stop is None else stop
+        prev_out = None
         for j in range(idx, n):
             if j in self.graphs:
-                # joins an existing chain captured from a later entry: bridge by copy at replay
-                self.bridges[j] = static_in
-                break
-            static_in = self._capture(j, static_in)
+                if prev_out is not None and self.graphs[j][1] is not prev_out:
+                    self.bridges[j] = prev_out
+                prev_out = self.graphs[j][2]
+                continue
+            static_in = prev_out if prev_out is not None else _map_tensors(state, lambda t: t.clone())
+            prev_out = self._capture(j, static_in)
 
     def advance(self, idx, stop, state):
         """Run captured stages idx..stop-1 on `state`; returns a private copy of the state
@@ -273,16 +497,19 @@ class _StageGraphs:
             self.graphs[j][0].replay()
         return _map_tensors(self.graphs[stop - 1][2], lambda t: t.clone())
 
-    def replay(self, idx, state):
-        self.ensure(idx, state)
-        n = len(self.plan)
-        _copy_tensors(self.graphs[idx][1], state)
+    def replay(self, idx, state, stop=None):
+        """state=None: the caller has already written the static input of stage idx."""
+        n = len(self.plan) if stop is None else stop
+        if state is not None:
+            self.ensure(idx, state, stop)
+            _copy_tensors(self.graphs[idx][1], state)
         for j in range(idx, n):
             if j != idx and j in self.bridges:
                 _copy_tensors(self.graphs[j][1], self.bridges[j])
             self.graphs[j][0].replay()
         self.owner.stats["graph_replays"] += 1
-        return self.graphs[n - 1][2]["__loss__"]
+        out = self.graphs[n - 1][2]
+        return out["__loss__"] if stop is None else out
 
 
 class _Lane:

@@ -273,7 +273,8 @@ class _StageOneMixin:
             loss_func = PrefixCachedLoss(
                 self.model, kind="vision" if loss_func is loss_vision else "vision_language",
                 use_graphs=bool(getattr(self, "use_graphs", True)) and on_gpu,
-                n_lanes=int(getattr(self, "n_lanes", 2)))
+                n_lanes=int(getattr(self, "n_lanes", 2)),
+                eval_batch=int(getattr(self, "eval_batch", 1)))
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

@@ -439,7 +439,7 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_toy
     res = []
-    for mode in ("full", "suffix", "graph", "graph2", "graph4"):
+    for mode in ("full", "suffix", "graph", "graph2", "graph4", "batched4", "batched8x2"):
         torch.manual_seed(0)
         model = blip2_toy(fp32=fp32).eval().to("cuda")
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
@@ -451,7 +451,12 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
                 "suffix": PrefixCachedLoss(model),
                 "graph": PrefixCachedLoss(model, use_graphs=True),
                 "graph2": PrefixCachedLoss(model, use_graphs=True, two_lanes=True),
-                "graph4": PrefixCachedLoss(model, use_graphs=True, n_lanes=4)}[mode]
+                "graph4": PrefixCachedLoss(model, use_graphs=True, n_lanes=4),
+                # toy tensors are too small for the invariance probe to be decisive: check all
+                "batched4": PrefixCachedLoss(model, use_graphs=True, eval_batch=4,
+                                             verify_batched="all"),
+                "batched8x2": PrefixCachedLoss(model, use_graphs=True, eval_batch=8, n_lanes=2,
+                                               verify_batched="all")}[mode]
         np.random.seed(3)
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=kern, z_source="philox")
@@ -459,6 +464,9 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
         res.append((ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
         if mode.startswith("graph"):
             assert loss.stats["graph_replays"] > 100 and loss.stats["graph_captures"] >= 4
+        if mode.startswith("batched"):      # the shared suffix ran batched (or the guard fell back)
+            assert loss.stats.get("batched_evals", 0) > 0, loss.stats
+            assert loss.stats.get("invariance_probes", 0) >= 1
     for other in res[1:]:
         assert np.array_equal(res[0][0], other[0])
         assert res[0][1] == other[1]
@@ -709,6 +717,46 @@ def test_upop_graph_replay_equals_full_forward(kern, golden_dir, tag):
     assert res[True][0] == res[False][0]
     for k, v in res[True][1].items():
         assert torch.equal(v, res[False][1][k]), k
+
+
+def test_batched_suffix_is_exact_at_full_size(kern):
+    """BLIP-2 shape at BASELINE size, four matrices (two ViT-g, two FlanT5): evaluating 8
+    perturbations per pass with the batch-invariant part of the suffix shared (FlanT5 stages on
+    this system; the probe decides) gives the same loss table, bit for bit, as one suffix per
+    evaluation; the guard never fires."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_flant5xl
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = blip2_flant5xl().eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    batches = S.image_text_batches(64, 8, img_size=224, vocab=32128, in_len=16, out_len=16, seed=42,
+                                   device=dev)
+    names = [k for k, v in model.named_parameters()
+             if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
+    pick = [names[60], names[61], names[300], names[500]]
+    init = {k: dict(model.named_parameters())[k].data.clone() for k in pick}
+    tables = {}
+    for mode in ("sequential", "batched"):
+        for k in pick:
+            dict(model.named_parameters())[k].data.copy_(init[k])
+        loss = PrefixCachedLoss(model, use_graphs=True, n_lanes=1,
+                                eval_batch=8 if mode == "batched" else 1, verify_batched="all")
+        np.random.seed(11)
+        ls = LayerSparsity(model, batches, loss, 64, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3,
+                           {k: k for k in pick}, kernels=kern, z_source="philox")
+        ls.return_sparsity()
+        tables[mode] = ls.loss_table.copy()
+        if mode == "batched":
+            assert loss.stats.get("batched_evals", 0) >= 48, loss.stats
+            assert "batched_disabled_at" not in loss.stats, loss.stats
+            bad = loss.stats.get("stages_not_batch_invariant", [])
+            assert not any(b.startswith("t5_model") for b in bad), bad
+    assert np.array_equal(tables["sequential"], tables["batched"])
 
 
 def test_fused_shape_ops_match_torch_chain():
