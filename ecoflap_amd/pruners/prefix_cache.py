@@ -210,8 +210,7 @@ class PrefixCachedLoss:
     def begin_layer_weights(self, name, home):
         """Called once per layer: `home` is the parameter's own storage (lane 0)."""
         self._pair_name, self._pair_home = name, home
-        if (self.n_lanes > 1 and self.eval_batch == 1 and self.extra_lanes is None
-                and home.device.type == "cuda"):
+        if self.n_lanes > 1 and self.extra_lanes is None and home.device.type == "cuda":
             self.extra_lanes = [_Lane(self) for _ in range(self.n_lanes - 1)]
 
     def end_layer_weights(self, final):
@@ -348,8 +347,19 @@ class PrefixCachedLoss:
         captured = S in bchain.graphs
         # 1. the per-evaluation part: owning stage (its theta in the parameter's storage), then
         #    the not-shareable stages, into the slots of the batched input
+        #    (odd evaluations on the second lane — weight replica, own stream, own graphs — when
+        #    there is one: this part is latency-bound at batch B, two streams fill the device)
         outs = []
+        lane = self.extra_lanes[0] if (self.extra_lanes and captured) else None
+        main = torch.cuda.current_stream()
+        if lane is not None:
+            lane.stream.wait_stream(main)        # K1's theta and the previous pass are complete
         for i, ((samples, theta), (_, st)) in enumerate(zip(evals, states)):
+            if lane is not None and (i & 1):
+                out = lane.run_prefix(entry, S, st, self._pair_name, theta)
+                with torch.cuda.stream(lane.stream):
+                    _copy_slot(bchain.graphs[S][1], out, i, B)
+                continue
             self._pair_home.copy_(theta)
             out = self.chain.run_stage(entry, st)
             if S > entry + 1:
@@ -358,6 +368,8 @@ class PrefixCachedLoss:
                 _copy_slot(bchain.graphs[S][1], out, i, B)
             else:
                 outs.append(_map_tensors(out, lambda t: t.clone()))
+        if lane is not None:
+            main.wait_stream(lane.stream)
         if not captured:
             while len(outs) < k:
                 outs.append(outs[-1])
@@ -390,16 +402,23 @@ class PrefixCachedLoss:
                      and (self.verify_batched == "entries" or len(self._verified) < 4)))
         if check:
             self._verified.add((entry, S))
-            want = self._sequential(model, evals, cuda_enabled)
-            same = all(torch.equal(a, b) for a, b in zip(losses, want))   # one sync
+            # "entries": one unit (theta+, theta-) per check, its slot rotating from check to
+            # check; "all" / "first": the whole chunk
+            if self.verify_batched == "entries" and not os.environ.get("ECOFLAP_VERIFY_BATCHED"):
+                p0 = 2 * (self.stats.get("batched_checks", 0) % max(1, len(evals) // 2))
+                sel = [i for i in (p0, p0 + 1) if i < len(evals)]
+            else:
+                sel = list(range(len(evals)))
+            want = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
+            same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))   # one sync
             self.stats["batched_checks"] = self.stats.get("batched_checks", 0) + 1
             if not same:
                 if os.environ.get("ECOFLAP_DEBUG_BATCHED"):
-                    print("batched mismatch at", self.plan[entry][0], "S", S, [float(x) for x in losses],
-                          [float(x) for x in want], flush=True)
+                    print("batched mismatch at", self.plan[entry][0], "S", S,
+                          [float(losses[i]) for i in sel], [float(x) for x in want], flush=True)
                 self.stats["batched_disabled_at"] = self.plan[entry][0]
                 self.eval_batch = 1
-            return want
+                return self._sequential(model, evals, cuda_enabled)
         return losses
 
     def pair(self, model, samples, cuda_enabled, theta_plus, theta_minus):
@@ -528,6 +547,34 @@ class _Lane:
         self.stream = torch.cuda.Stream()
         self.chain = _StageGraphs(owner, self.plan, stream=self.stream)
         self.warmed = False
+        self.prepared = set()
+
+    def run_prefix(self, entry, S, state, name, theta):
+        """On this lane's stream: theta into the replica's parameter, then stages entry..S-1 of
+        the replica on `state`; returns the lane's static output state.  The first use of an
+        (entry, S) pair captures its graphs with the device quiescent."""
+        def go():
+            self.params[name].data.copy_(theta)
+            out = self.chain.run_stage(entry, state)
+            if S > entry + 1:
+                out = self.chain.replay(entry + 1, out, stop=S)
+            return out
+        if (entry, S) in self.prepared:
+            with torch.cuda.stream(self.stream):
+                return go()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            if not self.warmed:                    # once: eager pass on this stream
+                self.warmed = True
+                self.params[name].data.copy_(theta)
+                out = state
+                for j in range(entry, S):
+                    out = self.plan[j][2](out)
+                self.stream.synchronize()
+            out = go()
+        torch.cuda.synchronize()
+        self.prepared.add((entry, S))
+        return out
 
     def replay(self, idx, state):
         """Enqueue this lane's suffix on its stream; returns the static loss tensor."""
