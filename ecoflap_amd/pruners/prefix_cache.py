@@ -231,6 +231,20 @@ class PrefixCachedLoss:
             if losses is not None:
                 return [(losses[2 * i], losses[2 * i + 1], self._batch_len(items[i][0]))
                         for i in range(len(items))]
+            per_group = max(1, self.n_lanes // 2)
+            if len(items) > per_group:       # nothing to share here: lane-sized groups instead
+                out = []
+                for g0 in range(0, len(items), per_group):
+                    res = self.multi_lanes(model, items[g0:g0 + per_group], cuda_enabled)
+                    self.join()
+                    out += [(a.clone(), b.clone(), n) for a, b, n in res]
+                return out
+        return self.multi_lanes(model, items, cuda_enabled)
+
+    def multi_lanes(self, model, items, cuda_enabled):
+        evals = []
+        for samples, tp, tm in items:
+            evals += [(samples, tp), (samples, tm)]
         can_fork = (self.extra_lanes is not None and self._warmed
                     and len(evals) <= len(self.extra_lanes) + 1)
         states = []
