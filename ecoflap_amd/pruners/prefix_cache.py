@@ -364,12 +364,13 @@ class PrefixCachedLoss:
         #    (odd evaluations on the second lane — weight replica, own stream, own graphs — when
         #    there is one: this part is latency-bound at batch B, two streams fill the device)
         outs = []
-        lane = self.extra_lanes[0] if (self.extra_lanes and captured) else None
+        lanes = list(self.extra_lanes) if (self.extra_lanes and captured) else []
         main = torch.cuda.current_stream()
-        if lane is not None:
+        for lane in lanes:
             lane.stream.wait_stream(main)        # K1's theta and the previous pass are complete
         for i, ((samples, theta), (_, st)) in enumerate(zip(evals, states)):
-            if lane is not None and (i & 1):
+            lane = lanes[i % (len(lanes) + 1) - 1] if (lanes and i % (len(lanes) + 1)) else None
+            if lane is not None:
                 out = lane.run_prefix(entry, S, st, self._pair_name, theta)
                 with torch.cuda.stream(lane.stream):
                     _copy_slot(bchain.graphs[S][1], out, i, B)
@@ -382,7 +383,7 @@ class PrefixCachedLoss:
                 _copy_slot(bchain.graphs[S][1], out, i, B)
             else:
                 outs.append(_map_tensors(out, lambda t: t.clone()))
-        if lane is not None:
+        for lane in lanes:
             main.wait_stream(lane.stream)
         if not captured:
             while len(outs) < k:
