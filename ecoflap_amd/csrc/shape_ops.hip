@@ -35,6 +35,68 @@ __global__ __launch_bounds__(256) void t5_rmsnorm_kernel(const void* __restrict_
     }
 }
 
+// LayerNorm of a 16-bit activation with fp32 statistics and fp32 affine parameters (what
+// autocast makes of nn.LayerNorm: cast up, normalise in fp32, cast down at the next Linear),
+// optionally preceded by the residual add that produces its input:
+//   s = dtype(x + r)            (written to sum_out)      [if r != nullptr]
+//   y = dtype((float(s) - mean) * rstd * w + b)
+// one wave per row, two passes over registers' worth of row (mean, then centred squares).
+template <int DT>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const void* __restrict__ x,
+                                                            const void* __restrict__ r,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ b,
+                                                            void* __restrict__ sum_out,
+                                                            void* __restrict__ y, int64_t rows,
+                                                            int64_t d, float eps) {
+    constexpr int N = Vec<DT>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t nvec = d / N;
+    const int64_t base = row * nvec;
+    float acc = 0.f;
+    for (int64_t v = lane; v < nvec; v += 64) {
+        float f[N];
+        Vec<DT>::unpack(ld16(x, base + v), f);
+        if (r) {
+            float g[N];
+            Vec<DT>::unpack(ld16(r, base + v), g);
+#pragma unroll
+            for (int i = 0; i < N; ++i) f[i] = Vec<DT>::round(f[i] + g[i]);
+            st16(sum_out, base + v, Vec<DT>::pack(f));
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += f[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const float mean = acc / (float)d;
+    const void* src = r ? (const void*)sum_out : x;     // own writes: same lane re-reads them
+    float var = 0.f;
+    for (int64_t v = lane; v < nvec; v += 64) {
+        float f[N];
+        Vec<DT>::unpack(ld16(src, base + v), f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) var += (f[i] - mean) * (f[i] - mean);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+    const float rstd = rsqrtf(var / (float)d + eps);
+    for (int64_t v = lane; v < nvec; v += 64) {
+        float f[N];
+        Vec<DT>::unpack(ld16(src, base + v), f);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const u32x4 w4 = ld16(w, v * (N / 4) + q), b4 = ld16(b, v * (N / 4) + q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                f[4 * q + i] = ((f[4 * q + i] - mean) * rstd) * __uint_as_float(w4[i]) + __uint_as_float(b4[i]);
+        }
+        st16(y, base + v, Vec<DT>::pack(f));
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void gelu_mul_kernel(const void* __restrict__ a,
                                                        const void* __restrict__ b,
@@ -84,6 +146,25 @@ extern "C" int ecoflap_gelu_mul(const void* a, const void* b, void* y, int64_t n
         hipLaunchKernelGGL((gelu_mul_kernel<ECOFLAP_F16>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, y, nvec);
     else
         hipLaunchKernelGGL((gelu_mul_kernel<ECOFLAP_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, y, nvec);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_add_layernorm(const void* x, const void* residual, const float* w,
+                                     const float* b, void* sum_out, void* y, int64_t rows,
+                                     int64_t d, float eps, int dtype, void* stream) {
+    if (dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) return ECOFLAP_EDTYPE;
+    if (rows < 0 || d <= 0 || (d % 8) != 0) return ECOFLAP_ESIZE;
+    if (rows == 0) return 0;
+    if (!x || !w || !b || !y || (residual && !sum_out)) return ECOFLAP_ENULL;
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ECOFLAP_F16)
+        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_F16>), grid, blk, 0, s, x, residual, w, b,
+                           sum_out, y, rows, d, eps);
+    else
+        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_BF16>), grid, blk, 0, s, x, residual, w, b,
+                           sum_out, y, rows, d, eps);
     ECO_CHECK_LAUNCH();
     return 0;
 }

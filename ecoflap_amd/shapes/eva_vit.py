@@ -60,9 +60,16 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, mlp_hidden)
 
     def forward(self, x, rel_pos_bias=None):
-        x = x + self.attn(self.norm1(x), rel_pos_bias=rel_pos_bias)
-        x = x + self.mlp(self.norm2(x))
-        return x
+        from . import fused          # one kernel per norm (and residual add) on the GPU loop
+        h = fused.add_layernorm(x, None, self.norm1)
+        a = self.attn(self.norm1(x) if h is None else h[1], rel_pos_bias=rel_pos_bias)
+        h = fused.add_layernorm(x, a, self.norm2)
+        if h is None:
+            x = x + a
+            h2 = self.norm2(x)
+        else:
+            x, h2 = h
+        return x + self.mlp(h2)
 
 
 class PatchEmbed(nn.Module):

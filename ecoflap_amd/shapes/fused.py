@@ -17,6 +17,7 @@ def _get():
         vp, i64, f32, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
         lib.ecoflap_t5_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
+        lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         _lib = lib
     return _lib
 
@@ -60,3 +61,28 @@ def gelu_mul(a, b):
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_gelu_mul failed ({rc})")
     return y
+
+
+def add_layernorm(x, residual, norm):
+    """nn.LayerNorm `norm` (fp32 parameters) of the 16-bit activation x — or of x + residual,
+    also returned — as ONE kernel instead of cast / layer_norm / cast (/ add).
+    -> (x_plus_residual or x, normalised) or None (caller runs the torch ops)."""
+    if (torch.is_grad_enabled() or x.device.type != "cuda"
+            or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[-1] % 8 != 0
+            or norm.weight is None or norm.bias is None or norm.weight.dtype != torch.float32
+            or not torch.is_autocast_enabled()):
+        return None
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
+        return None
+    xc = x if x.is_contiguous() else x.contiguous()
+    rc_ = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
+    y = torch.empty_like(xc)
+    s = torch.empty_like(xc) if rc_ is not None else xc
+    d = xc.shape[-1]
+    rc = _get().ecoflap_add_layernorm(
+        xc.data_ptr(), None if rc_ is None else rc_.data_ptr(), norm.weight.data_ptr(),
+        norm.bias.data_ptr(), None if rc_ is None else s.data_ptr(), y.data_ptr(),
+        xc.numel() // d, d, float(norm.eps), _hip.DTYPE_CODE[xc.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_add_layernorm failed ({rc})")
+    return s, y

@@ -23,6 +23,16 @@ int ecoflap_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int6
  * (erf GELU in fp32, rounded to dtype, then the product rounded to dtype). n % 8 == 0. */
 int ecoflap_gelu_mul(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 
+/* nn.LayerNorm on a 16-bit activation under autocast (EVA ViT blocks,
+ * LAVIS/lavis/models/eva_vit.py:160-184): fp32 statistics and fp32 affine parameters, 16-bit
+ * in and out; with `residual` the block's residual add is fused in front:
+ *   s = dtype(x + residual) -> sum_out;  y = dtype((float(s) - mean) * rstd * w + b)
+ * x, residual, sum_out, y: [rows, d] of `dtype` (F16/BF16); w, b: [d] float; d % 8 == 0.
+ * residual == NULL: plain LayerNorm of x (sum_out unused). */
+int ecoflap_add_layernorm(const void* x, const void* residual, const float* w, const float* b,
+                          void* sum_out, void* y, int64_t rows, int64_t d, float eps, int dtype,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

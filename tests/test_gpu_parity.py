@@ -782,6 +782,23 @@ def test_fused_shape_ops_match_torch_chain():
         assert got is not None
         assert (got.float() - want.float()).abs().max().item() <= \
             torch.finfo(dt).eps * want.float().abs().max().item()
+        # residual add + LayerNorm (EVA ViT block) vs autocast's cast / layer_norm / cast chain
+        norm = torch.nn.LayerNorm(1408, eps=1e-6).to("cuda")
+        norm.weight.data = 1 + 0.1 * torch.randn(1408, device="cuda")
+        norm.bias.data = 0.1 * torch.randn(1408, device="cuda")
+        xv = torch.randn(8 * 257, 1408, device="cuda").to(dt)
+        rv = (0.5 * torch.randn(8 * 257, 1408, device="cuda")).to(dt)
+        with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+            s1, y1 = fused.add_layernorm(xv, rv, norm)
+            s0, y0 = fused.add_layernorm(xv, None, norm)
+            want_s = xv + rv
+            want_y1 = norm(want_s).to(dt)
+            want_y0 = norm(xv).to(dt)
+        assert torch.equal(s1, want_s) and s0 is xv
+        for gy, wy in ((y1, want_y1), (y0, want_y0)):
+            assert (gy.float() - wy.float()).abs().max().item() <= \
+                2 * torch.finfo(dt).eps * wy.float().abs().max().item()
+            assert (gy != wy).float().mean().item() < 0.01      # 16-bit roundings of 1-ulp fp32 diffs
 
 
 def test_smoke_entry():
