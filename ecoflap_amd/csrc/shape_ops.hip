@@ -97,6 +97,27 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const void* __restri
     }
 }
 
+// qkv += cat(q_bias, 0, v_bias).to(dtype)   (EVA attention, eva_vit.py:123-128), in place:
+// one kernel instead of zeros_like / cat / cast / add.  qkv: [rows, 3*dim]; biases fp32 [dim].
+template <int DT>
+__global__ __launch_bounds__(256) void qkv_bias_add_kernel(void* __restrict__ qkv,
+                                                           const float* __restrict__ qb,
+                                                           const float* __restrict__ vb,
+                                                           int64_t rows, int64_t dim) {
+    constexpr int N = Vec<DT>::N;
+    const int64_t vpr = 3 * dim / N, nvec = rows * vpr;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int64_t c0 = (v % vpr) * N;
+        if (c0 >= dim && c0 < 2 * dim) continue;          // k: + 0 changes nothing but -0 -> +0
+        const float* b = c0 < dim ? qb + c0 : vb + (c0 - 2 * dim);
+        float f[N];
+        Vec<DT>::unpack(ld16(qkv, v), f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = f[i] + Vec<DT>::round(b[i]);
+        st16(qkv, v, Vec<DT>::pack(f));
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void gelu_mul_kernel(const void* __restrict__ a,
                                                        const void* __restrict__ b,
@@ -165,6 +186,24 @@ extern "C" int ecoflap_add_layernorm(const void* x, const void* residual, const 
     else
         hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_BF16>), grid, blk, 0, s, x, residual, w, b,
                            sum_out, y, rows, d, eps);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias,
+                                    int64_t rows, int64_t dim, int dtype, void* stream) {
+    if (dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) return ECOFLAP_EDTYPE;
+    if (rows < 0 || dim <= 0 || (dim % 8) != 0) return ECOFLAP_ESIZE;
+    if (rows == 0) return 0;
+    if (!qkv || !q_bias || !v_bias) return ECOFLAP_ENULL;
+    int64_t b = (rows * 3 * dim / 8 + 255) / 256;
+    if (b > 4096) b = 4096;
+    const dim3 grid((unsigned)b), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ECOFLAP_F16)
+        hipLaunchKernelGGL((qkv_bias_add_kernel<ECOFLAP_F16>), grid, blk, 0, s, qkv, q_bias, v_bias, rows, dim);
+    else
+        hipLaunchKernelGGL((qkv_bias_add_kernel<ECOFLAP_BF16>), grid, blk, 0, s, qkv, q_bias, v_bias, rows, dim);
     ECO_CHECK_LAUNCH();
     return 0;
 }

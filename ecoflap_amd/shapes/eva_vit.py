@@ -42,8 +42,10 @@ class Attention(nn.Module):
         B, N, C = x.shape
         qkv = self.qkv(x)
         if self.q_bias is not None:
-            qkv = qkv + torch.cat(
-                (self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(qkv.dtype)
+            from . import fused
+            if fused.qkv_bias_add(qkv, self.q_bias, self.v_bias) is None:
+                qkv = qkv + torch.cat(
+                    (self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(qkv.dtype)
         qkv = qkv.reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         x = F.scaled_dot_product_attention(q, k, v, attn_mask=rel_pos_bias, scale=self.scale)

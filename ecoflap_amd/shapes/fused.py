@@ -18,6 +18,7 @@ def _get():
         lib.ecoflap_t5_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
         lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
+        lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         _lib = lib
     return _lib
 
@@ -86,3 +87,20 @@ def add_layernorm(x, residual, norm):
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_add_layernorm failed ({rc})")
     return s, y
+
+
+def qkv_bias_add(qkv, q_bias, v_bias):
+    """qkv (fresh GEMM output, [.., 3*dim]) += cat(q_bias, 0, v_bias).to(dtype), in place.
+    -> qkv or None (caller runs the torch ops)."""
+    if (torch.is_grad_enabled() or qkv.device.type != "cuda"
+            or qkv.dtype not in (torch.float16, torch.bfloat16) or not qkv.is_contiguous()
+            or q_bias.dtype != torch.float32 or v_bias.dtype != torch.float32
+            or q_bias.numel() % 8 != 0 or qkv.shape[-1] != 3 * q_bias.numel()):
+        return None
+    dim = q_bias.numel()
+    rc = _get().ecoflap_qkv_bias_add(qkv.data_ptr(), q_bias.data_ptr(), v_bias.data_ptr(),
+                                     qkv.numel() // (3 * dim), dim, _hip.DTYPE_CODE[qkv.dtype],
+                                     _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_qkv_bias_add failed ({rc})")
+    return qkv

@@ -33,6 +33,11 @@ int ecoflap_add_layernorm(const void* x, const void* residual, const float* w, c
                           void* sum_out, void* y, int64_t rows, int64_t d, float eps, int dtype,
                           void* stream);
 
+/* EVA attention bias (eva_vit.py:123-128): qkv += cat(q_bias, zeros, v_bias).to(dtype), in
+ * place; qkv: [rows, 3*dim] of `dtype` (F16/BF16), q_bias / v_bias: [dim] float; dim % 8 == 0. */
+int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias, int64_t rows,
+                         int64_t dim, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

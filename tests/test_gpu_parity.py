@@ -799,6 +799,12 @@ def test_fused_shape_ops_match_torch_chain():
             assert (gy.float() - wy.float()).abs().max().item() <= \
                 2 * torch.finfo(dt).eps * wy.float().abs().max().item()
             assert (gy != wy).float().mean().item() < 0.01      # 16-bit roundings of 1-ulp fp32 diffs
+        qb, vb = torch.randn(1408, device="cuda"), torch.randn(1408, device="cuda")
+        qkv = torch.randn(8 * 257, 3 * 1408, device="cuda").to(dt)
+        want = qkv + torch.cat((qb, torch.zeros_like(vb), vb)).to(dt)
+        with torch.no_grad():
+            got = fused.qkv_bias_add(qkv.clone(), qb, vb)
+        assert torch.equal(got, want)
 
 
 def test_smoke_entry():
