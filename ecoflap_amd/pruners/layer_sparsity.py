@@ -74,6 +74,7 @@ class LayerSparsity:
         process_group=None,
         k1_form="units",
         couple_torch_rng=False,
+        grad_graphs=True,
     ):
         """Positional arguments are the reference's (:120-135).  Keyword-only extras:
 
@@ -114,6 +115,9 @@ class LayerSparsity:
         # torch.multinomial): the reference reseeds that RNG inside every K1 call (:482), so both
         # losses of a pair see the same draws; replay that state right before each loss
         self.couple_torch_rng = couple_torch_rng
+        # first-order passes: forward + backward of equally shaped batches captured once as a HIP
+        # graph and replayed (the eager loop is launch-bound at batch 1: thousands of tiny kernels)
+        self.grad_graphs = grad_graphs
         self.process_group = process_group
         assert k1_form in ("units", "triple", "single")
         self.k1_form = k1_form
@@ -402,21 +406,17 @@ class LayerSparsity:
         sums = torch.zeros(len(names), dtype=torch.float64, device=device)
         accum_samples = 0
         n_batches = 0
+        todo = []
         for bi, d in enumerate(self.data_loader):
             if accum_samples >= self.num_samples:
                 break
-            blen = self.batch_len_fn(d)
-            accum_samples += blen
+            accum_samples += self.batch_len_fn(d)
             n_batches += 1
-            if (bi % world) != rank:
-                continue
-            loss, batch_len = self.loss_func(model, d, cuda_enabled)
-            if batch_len != blen:
-                raise RuntimeError("loss_func batch_len differs from batch_len_fn")
-            grads = torch.autograd.grad(loss, params)
+            if (bi % world) == rank:
+                todo.append(d)
+        for _, grads in self._grads_per_batch(params, todo, cuda_enabled):
             assert len(grads) == len(names) == len(params)
             self._reduce_pairs(params, grads, mode, sums)
-            del grads, loss
         self._all_reduce_sum(sums)
         host = sums.cpu().numpy()
         importance = {}
@@ -427,6 +427,73 @@ class LayerSparsity:
         self.stats = {"seconds": time.time() - t0, "layers": len(names), "batches": n_batches,
                       "world_size": world}
         return importance
+
+    def _grads_per_batch(self, params, todo, cuda_enabled):
+        """Yields (batch, grads) for every batch of `todo`: `torch.autograd.grad(loss, params)`
+        as the reference calls it (:446), eagerly — or, on the GPU when all batches have the same
+        shapes, by replaying ONE captured HIP graph of forward + backward on static input
+        buffers (same kernels, same order -> same bits; the gradients live in the graph's static
+        buffers and are consumed by the caller's kernel before the next replay)."""
+        model = self.model
+        dev = params[0].device
+
+        def tensors_of(b):
+            return [v for v in (b.values() if isinstance(b, dict) else b) if torch.is_tensor(v)]
+
+        def signature(b):
+            if not isinstance(b, (dict, tuple, list)):
+                return None
+            items = b.items() if isinstance(b, dict) else enumerate(b)
+            sig = []
+            for k, v in items:
+                if torch.is_tensor(v):
+                    if v.device != dev:
+                        return None
+                    sig.append((k, tuple(v.shape), v.dtype))
+                elif isinstance(v, (int, float, str, type(None))):
+                    sig.append((k, v))
+                else:
+                    return None            # lists of per-sample counts etc.: shapes vary
+            return tuple(sig)
+
+        sigs = {signature(b) for b in todo}
+        use_graph = (self.grad_graphs and dev.type == "cuda" and len(todo) >= 4
+                     and len(sigs) == 1 and None not in sigs)
+        if not use_graph:
+            for d in todo:
+                loss, batch_len = self.loss_func(model, d, cuda_enabled)
+                if batch_len != self.batch_len_fn(d):
+                    raise RuntimeError("loss_func batch_len differs from batch_len_fn")
+                grads = torch.autograd.grad(loss, params)
+                assert len(grads) == len(params)
+                yield d, grads
+                del grads, loss
+            return
+        first = todo[0]
+        static = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}
+                  if isinstance(first, dict) else
+                  type(first)(v.clone() if torch.is_tensor(v) else v for v in first))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the capture, as torch asks
+            for _ in range(2):
+                loss, batch_len = self.loss_func(model, static, cuda_enabled)
+                torch.autograd.grad(loss, params)
+        torch.cuda.current_stream().wait_stream(side)
+        if batch_len != self.batch_len_fn(first):
+            raise RuntimeError("loss_func batch_len differs from batch_len_fn")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss, _ = self.loss_func(model, static, cuda_enabled)
+            grads = torch.autograd.grad(loss, params)
+        assert len(grads) == len(params)
+        self.stats_grad_graph = {"captured": 1, "replays": 0}
+        for d in todo:
+            for dst, src in zip(tensors_of(static), tensors_of(d)):
+                dst.copy_(src, non_blocking=True)
+            graph.replay()
+            self.stats_grad_graph["replays"] += 1
+            yield d, grads
 
     def _reduce_pairs(self, params, grads, mode, sums):
         """sums[l] += sum_e f(W_l, g_l): one multi-tensor launch per dtype class."""
@@ -450,23 +517,16 @@ class LayerSparsity:
             accs.append(flat[o:o + p.numel()].view(p.shape))
             o += p.numel()
         accum_samples, n_batches = 0, 0
+        todo = []
         for bi, d in enumerate(self.data_loader):
             if accum_samples >= self.num_samples:
                 break
-            if world > 1:
-                blen = self.batch_len_fn(d)
-                accum_samples += blen
-                n_batches += 1
-                if (bi % world) != rank:
-                    continue
-            loss, batch_len = self.loss_func(model, d, cuda_enabled)
-            if world == 1:
-                accum_samples += batch_len
-                n_batches += 1
-            grads = torch.autograd.grad(loss, params)
-            assert len(grads) == len(params)
+            accum_samples += self.batch_len_fn(d)
+            n_batches += 1
+            if (bi % world) == rank:
+                todo.append(d)
+        for _, grads in self._grads_per_batch(params, todo, cuda_enabled):
             self.kernels.grad_accum_multi(accs, list(grads))
-            del grads, loss
         self._all_reduce_sum(flat)
         return accs, n_batches
 

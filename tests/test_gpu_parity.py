@@ -759,6 +759,35 @@ def test_batched_suffix_is_exact_at_full_size(kern):
     assert np.array_equal(tables["sequential"], tables["batched"])
 
 
+@pytest.mark.parametrize("method", ["GradMagAbs_sum", "GradMagSquare_avg", "Real-GradMagAbs_sum"])
+def test_first_order_graph_replay_equals_eager(kern, method):
+    """Forward + backward captured once as a HIP graph and replayed per batch (first-order and
+    Real-* passes) == the eager autograd loop: same kernels in the same order -> same table."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    out = {}
+    for graphs in (True, False):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        for p in model.parameters():
+            p.requires_grad = True
+        batches = S.image_text_batches(16, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        ls = LayerSparsity(model, batches, loss_vision_language, 16, 0.5, 0.6, method, 1, 1e-3,
+                           mapping, kernels=kern, grad_graphs=graphs)
+        sp = ls.return_sparsity()
+        out[graphs] = (sp, {k: float(v.sum()) for k, v in ls.importance_measure.items()})
+        if graphs:
+            assert ls.stats_grad_graph["replays"] >= 8
+    assert out[True][0] == out[False][0]
+    assert out[True][1] == out[False][1]
+
+
 def test_fused_shape_ops_match_torch_chain():
     """Plumbing kernels of the shape modules' forward vs the torch op chains they replace."""
     from ecoflap_amd.shapes import fused
