@@ -131,10 +131,12 @@ class BLIPT5GlobalGradMagAbsPruner(BLIPT5GlobalPruner):
     def _accumulate(self, params):
         """(:259-296) — the accumulators stay in HBM, one multi-tensor launch per batch; data
         parallel as `LayerSparsity.accumulate_abs_grads` (one all-reduce per round)."""
-        ls = LayerSparsity(
-            self.model, self.data_loader, loss_vision_language, self.num_samples, 0.0, 1.0,
-            "GradMagAbs_sum", 1, 1e-3, {}, kernels=self._kernels(),
-            process_group=self.process_group)
+        ls = getattr(self, "_grad_engine", None)
+        if ls is None:            # one engine for all rounds: its captured fwd+bwd graph is reused
+            ls = self._grad_engine = LayerSparsity(
+                self.model, self.data_loader, loss_vision_language, self.num_samples, 0.0, 1.0,
+                "GradMagAbs_sum", 1, 1e-3, {}, kernels=self._kernels(),
+                process_group=self.process_group)
         return ls.accumulate_abs_grads(params)
 
 

@@ -469,25 +469,33 @@ class LayerSparsity:
                 yield d, grads
                 del grads, loss
             return
-        first = todo[0]
-        static = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}
-                  if isinstance(first, dict) else
-                  type(first)(v.clone() if torch.is_tensor(v) else v for v in first))
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                 # warm-up off the capture, as torch asks
-            for _ in range(2):
-                loss, batch_len = self.loss_func(model, static, cuda_enabled)
-                torch.autograd.grad(loss, params)
-        torch.cuda.current_stream().wait_stream(side)
-        if batch_len != self.batch_len_fn(first):
-            raise RuntimeError("loss_func batch_len differs from batch_len_fn")
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss, _ = self.loss_func(model, static, cuda_enabled)
-            grads = torch.autograd.grad(loss, params)
-        assert len(grads) == len(params)
-        self.stats_grad_graph = {"captured": 1, "replays": 0}
+        key = (next(iter(sigs)), tuple(id(p) for p in params))
+        cache = getattr(self, "_grad_graph_cache", None)
+        if cache is None or cache[0] != key:
+            first = todo[0]
+            static = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}
+                      if isinstance(first, dict) else
+                      type(first)(v.clone() if torch.is_tensor(v) else v for v in first))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):             # warm-up off the capture, as torch asks
+                for _ in range(2):
+                    loss, batch_len = self.loss_func(model, static, cuda_enabled)
+                    torch.autograd.grad(loss, params)
+            torch.cuda.current_stream().wait_stream(side)
+            if batch_len != self.batch_len_fn(first):
+                raise RuntimeError("loss_func batch_len differs from batch_len_fn")
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, _ = self.loss_func(model, static, cuda_enabled)
+                grads = torch.autograd.grad(loss, params)
+            assert len(grads) == len(params)
+            # the graph reads the parameters in place: later rounds (Real-*: pruned weights in
+            # the same storage) replay it as is
+            self._grad_graph_cache = cache = (key, graph, static, grads)
+            self.stats_grad_graph = {"captured": 0, "replays": 0}
+            self.stats_grad_graph["captured"] += 1
+        _, graph, static, grads = cache
         for d in todo:
             for dst, src in zip(tensors_of(static), tensors_of(d)):
                 dst.copy_(src, non_blocking=True)
