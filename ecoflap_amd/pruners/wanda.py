@@ -283,6 +283,11 @@ class _StageOneMixin:
         self.kernels = ls.kernels
         out = ls.return_sparsity()
         self.stage_stats["stage1"] = dict(ls.stats)
+        if hasattr(loss_func, "stats"):
+            self.stage_stats["stage1"]["suffix_forward"] = {
+                k: v for k, v in loss_func.stats.items() if k != "stages_not_batch_invariant"}
+            self.stage_stats["stage1"]["stages_not_batch_invariant"] = len(
+                loss_func.stats.get("stages_not_batch_invariant", []))
         self.layer_sparsity_engine = ls
         return out
 
