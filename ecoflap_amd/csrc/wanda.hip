@@ -98,6 +98,27 @@ __global__ __launch_bounds__(256) void colsq_final_kernel(float* __restrict__ sc
     scaler_row[c] = r + sq / n_new;         // += ... / nsamples
 }
 
+// the same update with the sample count kept on the device (graph-replayable: nothing in the
+// launch arguments changes from call to call); decay and n are formed as the host form does
+__global__ __launch_bounds__(256) void colsq_final_dev_kernel(float* __restrict__ scaler_row,
+                                                              const float* __restrict__ partial,
+                                                              int64_t cols, int nchunks,
+                                                              const int64_t* __restrict__ n_dev,
+                                                              int64_t batch) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t n0 = n_dev[0];
+    const float decay = (float)((double)n0 / (double)(n0 + batch));
+    const float n_new = (float)(n0 + batch);
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
+    const float nrm = __builtin_sqrtf(s);
+    const float sq = nrm * nrm;
+    const float r = scaler_row[c] * decay;
+    scaler_row[c] = r + sq / n_new;
+}
+__global__ void colsq_bump_kernel(int64_t* n_dev, int64_t batch) { n_dev[0] += batch; }
+
 static inline int colsq_rows_per_chunk(int64_t tokens, int64_t cols) {
     // ~512 workgroups over the 256 CUs, at least 64 rows (16 per wave) per workgroup so every
     // lane keeps several loads in flight and the second stage sums few partials
@@ -118,10 +139,30 @@ extern "C" size_t ecoflap_colsqnorm_workspace_bytes(int64_t tokens, int64_t cols
     return (size_t)colsq_nchunks(tokens, cols) * (size_t)cols * sizeof(float);
 }
 
+static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
+                            int dtype, int64_t nsamples_before, int64_t* nsamples_dev,
+                            int64_t batch, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens,
                                        int64_t cols, int dtype, int64_t nsamples_before,
                                        int64_t batch, void* workspace, size_t workspace_bytes,
                                        void* stream) {
+    return colsq_accum_impl(scaler_row, x, tokens, cols, dtype, nsamples_before, nullptr, batch,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int ecoflap_colsqnorm_accum_dev(float* scaler_row, const void* x, int64_t tokens,
+                                           int64_t cols, int dtype, int64_t* nsamples_dev,
+                                           int64_t batch, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+    if (!nsamples_dev) return ECOFLAP_ENULL;
+    return colsq_accum_impl(scaler_row, x, tokens, cols, dtype, 0, nsamples_dev, batch, workspace,
+                            workspace_bytes, stream);
+}
+
+static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
+                            int dtype, int64_t nsamples_before, int64_t* nsamples_dev,
+                            int64_t batch, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
     if (tokens <= 0 || cols <= 0 || nsamples_before < 0 || batch <= 0) return ECOFLAP_ESIZE;
     if (!scaler_row || !x || !workspace) return ECOFLAP_ENULL;
@@ -146,6 +187,13 @@ extern "C" int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t
     else { COLSQ(ECOFLAP_BF16) }
 #undef COLSQ
     ECO_CHECK_LAUNCH();
+    if (nsamples_dev) {
+        hipLaunchKernelGGL(colsq_final_dev_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                           s, scaler_row, partial, cols, nchunks, nsamples_dev, batch);
+        hipLaunchKernelGGL(colsq_bump_kernel, dim3(1), dim3(1), 0, s, nsamples_dev, batch);
+        ECO_CHECK_LAUNCH();
+        return 0;
+    }
     const float decay = (float)((double)nsamples_before / (double)(nsamples_before + batch));
     const float n_new = (float)(nsamples_before + batch);
     hipLaunchKernelGGL(colsq_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,

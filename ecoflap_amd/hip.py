@@ -23,7 +23,7 @@ EXPORTS = [
     "ecoflap_zo_perturb_units", "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
-    "ecoflap_colsqnorm_accum", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
+    "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
     "ecoflap_wanda_prune_matrix", "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
@@ -68,6 +68,7 @@ def load_library():
     lib.ecoflap_colsqnorm_workspace_bytes.restype = sz
     lib.ecoflap_colsqnorm_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
+    lib.ecoflap_colsqnorm_accum_dev.argtypes = [vp, vp, i64, i64, ci, vp, i64, vp, sz, vp]
     lib.ecoflap_wanda_workspace_bytes.restype = sz
     lib.ecoflap_wanda_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
@@ -259,6 +260,21 @@ class HipKernels:
             _ptr(scaler_row), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype],
             int(nsamples_before), int(batch), _ptr(ws), ws.numel(), _stream()),
             "ecoflap_colsqnorm_accum")
+
+    graph_safe = True     # launches only (no host copies / syncs): usable under HIP-graph capture
+
+    def colsqnorm_workspace(self, tokens, cols, device):
+        """A private workspace for `colsqnorm_accum_dev` (a captured graph keeps its address)."""
+        nb = self.lib.ecoflap_colsqnorm_workspace_bytes(tokens, cols)
+        return torch.empty(max(int(nb), 16), dtype=torch.uint8, device=device)
+
+    def colsqnorm_accum_dev(self, scaler_row, x2d, n_dev, batch, ws):
+        _gpu(scaler_row, "scaler_row")
+        _gpu(x2d, "x")
+        tokens, cols = x2d.shape
+        _check(self.lib.ecoflap_colsqnorm_accum_dev(
+            _ptr(scaler_row), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype], _ptr(n_dev),
+            int(batch), _ptr(ws), ws.numel(), _stream()), "ecoflap_colsqnorm_accum_dev")
 
     # ---- K7 ---------------------------------------------------------------------------
     def _wanda(self, fn, name, w, scaler_row, k, mask_out):

@@ -52,6 +52,9 @@ class WrappedGPT:
         self.layer_id = layer_id
         self.layer_name = layer_name
         self.kernels = kernels if kernels is not None else _hip.HipKernels()
+        self.n_dev = None          # device-side sample count while a block graph is captured / replayed
+        self.dev_ws = None
+        self.dev_batch = 0
 
     def add_batch(self, inp, out):
         if len(inp.shape) == 2:
@@ -60,6 +63,14 @@ class WrappedGPT:
         x = inp.reshape((-1, inp.shape[-1]))
         if not x.is_contiguous():
             x = x.contiguous()
+        if self.n_dev is not None:
+            # graph capture: same update, the count lives on the device (the replay loop keeps
+            # `nsamples` in step on the host)
+            if self.dev_ws is None:
+                self.dev_ws = self.kernels.colsqnorm_workspace(x.shape[0], x.shape[1], x.device)
+            self.kernels.colsqnorm_accum_dev(self.scaler_row, x, self.n_dev, tmp, self.dev_ws)
+            self.dev_batch = tmp
+            return
         self.kernels.colsqnorm_accum(self.scaler_row, x, self.nsamples, tmp)
         self.nsamples += tmp
 
@@ -210,6 +221,46 @@ class _BlockwiseWanda:
                 y = block(inps[j], **caches[j])
             return y[0] if take_first else y
 
+        # equally shaped calibration samples on the GPU: each block forward (with its K6 hooks
+        # in the first pass) is captured once as a HIP graph and replayed per sample — the loop
+        # is launch-bound (the reference's batch 1: ~40 kernels of a few microseconds per block)
+        graphed = (torch.is_tensor(inps[0]) and inps[0].is_cuda
+                   and n_batches >= int(getattr(self.owner, "graph_min_batches", 24))   # two captures per block cost ~5 ms
+                   and bool(getattr(self.owner, "use_graphs", True))
+                   and bool(getattr(self.kernels, "graph_safe", False))
+                   and getattr(self.owner, "local_method", "wanda") != "sparsegpt"
+                   and _uniform_calibration(inps, caches, n_batches))
+
+        def graph_pass(block, wrapped, keep):
+            """All n_batches samples through `block`: sample 0 eagerly (warm-up), one capture,
+            n-1 replays.  wrapped: the K6 statistics whose hooks are live (None: plain pass)."""
+            y0 = call(block, 0)
+            if keep:
+                outs[0] = y0
+            static_x = inps[0].clone()
+            static_kw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in caches[0].items()}
+            for w_ in (wrapped or {}).values():
+                w_.n_dev = torch.tensor([w_.nsamples], dtype=torch.int64, device=static_x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                with autocast():
+                    y = block(static_x, **static_kw)
+                y = y[0] if take_first else y
+            for j in range(1, n_batches):
+                static_x.copy_(inps[j], non_blocking=True)
+                for k, v in caches[j].items():
+                    if torch.is_tensor(v):
+                        static_kw[k].copy_(v, non_blocking=True)
+                graph.replay()
+                if keep:
+                    outs[j] = y.clone()
+                for w_ in (wrapped or {}).values():
+                    w_.nsamples += w_.dev_batch
+            for w_ in (wrapped or {}).values():
+                w_.n_dev, w_.dev_ws = None, None
+            torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
+            del graph
+
         for i in range(len(blocks)):
             block = blocks[i]
             subset = find_layers(block)
@@ -224,8 +275,11 @@ class _BlockwiseWanda:
                     lambda _m, inp, out, _n=name: wrapped[_n].add_batch(inp[0].data, out.data))
                 for name in wrapped
             ]
-            for j in range(n_batches):
-                outs[j] = call(block, j)
+            if graphed:
+                graph_pass(block, wrapped, keep=False)
+            else:
+                for j in range(n_batches):
+                    outs[j] = call(block, j)
             for h in handles:
                 h.remove()
             if not sparsegpt:
@@ -247,12 +301,38 @@ class _BlockwiseWanda:
                 else:                   # whole matrix, metric <= sorted[k] (:555-558)
                     k = int(weight.numel() * ratio)
                     self.kernels.wanda_prune_matrix(weight, wrapped[name].scaler_row, k)
-            for j in range(n_batches):
-                outs[j] = call(block, j)
+            if graphed:
+                graph_pass(block, None, keep=True)
+            else:
+                for j in range(n_batches):
+                    outs[j] = call(block, j)
             inps, outs = outs, inps
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
         return model
+
+
+def _uniform_calibration(inps, caches, n):
+    """Same shapes / dtypes for every sample's block input and cached kwargs, equal non-tensor
+    kwargs — what one captured graph can replay."""
+    def sig(x, c):
+        out = [tuple(x.shape), x.dtype]
+        for k in sorted(c):
+            v = c[k]
+            if torch.is_tensor(v):
+                out.append((k, tuple(v.shape), v.dtype, v.is_cuda))
+            elif v is None or isinstance(v, (bool, int, float, str)):
+                out.append((k, v))
+            else:
+                return None
+        return tuple(out)
+    first = sig(inps[0], caches[0])
+    if first is None:
+        return False
+    for j in range(1, n):
+        if not torch.is_tensor(inps[j]) or sig(inps[j], caches[j]) != first:
+            return False
+    return all(v.is_cuda for v in caches[0].values() if torch.is_tensor(v))
 
 
 def _t5_block_mapping(names, granularity, depth=4):

@@ -156,6 +156,14 @@ int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens,
                             int64_t cols, int dtype, int64_t nsamples_before,
                             int64_t batch, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Same update with `n` (WrappedGPT.nsamples, :58/:81) held in device memory: reads
+ * *nsamples_dev as nsamples_before and adds `batch` to it afterwards.  No launch argument
+ * changes between calls, so a block forward with its hooks can be captured once as a HIP
+ * graph and replayed per calibration sample. */
+int ecoflap_colsqnorm_accum_dev(float* scaler_row, const void* x, int64_t tokens,
+                                int64_t cols, int dtype, int64_t* nsamples_dev,
+                                int64_t batch, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K7  Wanda metric + selection + zeroing
