@@ -486,7 +486,7 @@ class LayerSparsity:
             if batch_len != self.batch_len_fn(first):
                 raise RuntimeError("loss_func batch_len differs from batch_len_fn")
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 loss, _ = self.loss_func(model, static, cuda_enabled)
                 grads = torch.autograd.grad(loss, params)
             assert len(grads) == len(params)

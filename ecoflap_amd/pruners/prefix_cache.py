@@ -400,7 +400,7 @@ class PrefixCachedLoss:
                 for i in range(k):      # eager once: library handles, workspaces
                     losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=bchain.pool):
+                with torch.cuda.graph(graph, pool=bchain.pool, capture_error_mode="thread_local"):
                     for i in range(k):
                         losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
             bundle[1], bundle[2] = graph, losses
@@ -481,7 +481,8 @@ class _StageGraphs:
         graph = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        kw = {"pool": self.pool}
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        kw = {"pool": self.pool, "capture_error_mode": "thread_local"}
         if self.stream is not None:
             kw["stream"] = self.stream
         last = (j == len(self.plan) - 1)

@@ -242,7 +242,7 @@ class _BlockwiseWanda:
             for w_ in (wrapped or {}).values():
                 w_.n_dev = torch.tensor([w_.nsamples], dtype=torch.int64, device=static_x.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(graph):
+            with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 with autocast():
                     y = block(static_x, **static_kw)
                 y = y[0] if take_first else y
