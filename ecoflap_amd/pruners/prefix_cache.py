@@ -99,6 +99,34 @@ def _slice_state(state, i, B, k):
     return state
 
 
+def _family(samples):
+    """Shape signature of a calibration batch: batches of one family replay the same graphs
+    (BLIP-VQA batches differ in their number of answers: one chain of graphs per family)."""
+    sig = []
+
+    def walk(o, path):
+        if torch.is_tensor(o):
+            sig.append((path, tuple(o.shape), str(o.dtype)))
+        elif isinstance(o, dict):
+            for k in sorted(o, key=str):
+                walk(o[k], path + (str(k),))
+        elif isinstance(o, (list, tuple)):
+            if o and all(isinstance(v, int) for v in o):
+                # per-sample counts (VQA answers per question): stage 0 turns them into an index
+                # tensor whose length is their sum — that, not the individual values, is shape
+                sig.append((path, "counts", len(o), sum(o)))
+                return
+            sig.append((path, "seq", len(o)))
+            for i, v in enumerate(o):
+                walk(v, path + (i,))
+        elif isinstance(o, (int, float, str, bool, type(None))):
+            sig.append((path, o))
+        else:
+            sig.append((path, type(o).__name__))
+    walk(samples, ())
+    return tuple(sig)
+
+
 class PrefixCachedLoss:
     """use_graphs=True (GPU only): the suffix from each entry stage is captured once into a
     HIP graph (torch.cuda.CUDAGraph -> hipGraph) and replayed for every later unit that
@@ -131,7 +159,10 @@ class PrefixCachedLoss:
         self.two_lanes = self.n_lanes > 1
         self.extra_lanes = None     # replicas (model copy + stream + graphs), built lazily
         self.requires_static_weights = self.use_graphs
-        self.chain = None           # per-stage graphs of lane A
+        self.chain = None           # per-stage graphs of lane A for the current batch family
+        self.chains = {}            # family -> _StageGraphs
+        self.families = {}          # id(samples) -> family
+        self.max_families = 16      # beyond that, batches of new shapes replay eagerly
         self._warmed = False
         self.plan = model.stage_plan()
         self.result = _vision_result if kind == "vision" else _vision_language_result
@@ -154,6 +185,7 @@ class PrefixCachedLoss:
 
     def reset(self):
         self.cache.clear()
+        self.families.clear()
         self.entry = 0
 
     # ---- the loss closure ----------------------------------------------------------------------
@@ -186,12 +218,31 @@ class PrefixCachedLoss:
             return len(samples["text_input"])
         return len(samples["label"])
 
+    def _use_family(self, samples):
+        """Point `self.chain` (and every lane's) at the graphs of this batch's shape family;
+        False when the family cap is reached (that batch then replays eagerly)."""
+        key = id(samples)
+        fam = self.families.get(key)
+        if fam is None:
+            fam = self.families[key] = _family(samples)
+        if fam not in self.chains:
+            if len(self.chains) >= self.max_families:
+                self.chain = None
+                return False
+            self.chains[fam] = _StageGraphs(self, self.plan, stream=None)
+        self.chain = self.chains[fam]
+        self._fam = fam
+        for lane in self.extra_lanes or []:
+            lane.use_family(fam)
+        return True
+
     def __call__(self, model, samples, cuda_enabled):
         assert model is self.model
         key = id(samples)
+        graphable = self.use_graphs and self._use_family(samples)
         self._ensure_cached(key, samples)
         idx, state = self.cache[key]
-        if self.use_graphs and idx > 0 and _on_gpu(state):
+        if graphable and idx > 0 and _on_gpu(state):
             loss = self._graphed_suffix(idx, state)
         else:
             loss = self.result(self._suffix(idx, state))
@@ -250,6 +301,8 @@ class PrefixCachedLoss:
         states = []
         for samples, _ in evals:
             key = id(samples)
+            if not (self.use_graphs and self._use_family(samples)):
+                can_fork = False
             self._ensure_cached(key, samples)
             states.append(self.cache[key])
         if can_fork:
@@ -263,9 +316,11 @@ class PrefixCachedLoss:
         else:
             for i in range(1, len(evals)):                      # replicas first, lane 0 last
                 lane = self.extra_lanes[i - 1]
+                self._use_family(evals[i][0])
                 lane.params[self._pair_name].data.copy_(evals[i][1])
                 losses[i] = lane.replay(*states[i])
                 self._account(states[i][0])
+            self._use_family(evals[0][0])
             self._pair_home.copy_(evals[0][1])
             losses[0] = self._graphed_suffix(*states[0])
             self._account(states[0][0])
@@ -341,22 +396,24 @@ class PrefixCachedLoss:
         if not self._warmed or entry < 1 or len(evals) > k:
             return None
         states = []
+        fams = set()
         for samples, _ in evals:
             key = id(samples)
+            if not self._use_family(samples):
+                return None
+            fams.add(self._fam)
             self._ensure_cached(key, samples)
             states.append(self.cache[key])
-        if not all(idx == entry and _on_gpu(st) for idx, st in states):
+        if len(fams) != 1 or not all(idx == entry and _on_gpu(st) for idx, st in states):
             return None
         B = self._batch_len(evals[0][0])
         S = self._batch_from(entry, evals, states, B)
         if S is None:
             return None
-        if self.chain is None:
-            self.chain = _StageGraphs(self, self.plan, stream=None)
-        bundle = self.bchains.get(k)
+        bundle = self.bchains.get((self._fam, k))
         if bundle is None:
             bundle = [_StageGraphs(self, self.plan, stream=None), None, None]
-            self.bchains[k] = bundle
+            self.bchains[(self._fam, k)] = bundle
         bchain = bundle[0]
         captured = S in bchain.graphs
         # 1. the per-evaluation part: owning stage (its theta in the parameter's storage), then
@@ -455,8 +512,6 @@ class PrefixCachedLoss:
             # capture (library handles, workspaces)
             self._warmed = True
             return self.result(self._suffix(idx, state))
-        if self.chain is None:
-            self.chain = _StageGraphs(self, self.plan, stream=None)
         return self.chain.replay(idx, state)
 
 
@@ -561,9 +616,16 @@ class _Lane:
         self.plan = self.model.stage_plan()
         self.params = dict(self.model.named_parameters())
         self.stream = torch.cuda.Stream()
-        self.chain = _StageGraphs(owner, self.plan, stream=self.stream)
+        self.chains = {}
+        self.chain = None
+        self.fam = None
         self.warmed = False
         self.prepared = set()
+
+    def use_family(self, fam):
+        if fam not in self.chains:
+            self.chains[fam] = _StageGraphs(self.owner, self.plan, stream=self.stream)
+        self.chain, self.fam = self.chains[fam], fam
 
     def run_prefix(self, entry, S, state, name, theta):
         """On this lane's stream: theta into the replica's parameter, then stages entry..S-1 of
@@ -575,7 +637,7 @@ class _Lane:
             if S > entry + 1:
                 out = self.chain.replay(entry + 1, out, stop=S)
             return out
-        if (entry, S) in self.prepared:
+        if (self.fam, entry, S) in self.prepared:
             with torch.cuda.stream(self.stream):
                 return go()
         torch.cuda.synchronize()
@@ -589,7 +651,7 @@ class _Lane:
                 self.stream.synchronize()
             out = go()
         torch.cuda.synchronize()
-        self.prepared.add((entry, S))
+        self.prepared.add((self.fam, entry, S))
         return out
 
     def replay(self, idx, state):

@@ -43,8 +43,8 @@ def task_forward(task, model, batch, device="cuda"):
 
 
 def _shape_signature(batch):
-    return tuple((tuple(t.shape), str(t.dtype)) if torch.is_tensor(t) else
-                 (tuple(t) if isinstance(t, (list, tuple)) else t) for t in batch)
+    from .prefix_cache import _family
+    return _family(batch)
 
 
 class _NoAutocast:
@@ -140,11 +140,12 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
                 and str(self.score_method).startswith("MEZO")):
             # same losses, bit for bit, re-entering at the block that owns the scored matrix
             # (the shapes' forward IS the composition of their stages).  HIP-graph replay on two
-            # lanes when every batch has the same shapes (caption, NLVR); VQA batches carry a
-            # varying number of answers and replay eagerly
+            # lanes, one chain of graphs per batch shape family (VQA batches differ in their
+            # number of answers); loaders with many different shapes replay eagerly
             from .prefix_cache import PrefixCachedLoss
-            uniform = len({_shape_signature(b) for b in self.data_loader}) == 1
-            graphs = (uniform and device.type == "cuda" and bool(getattr(self, "use_graphs", True)))
+            families = len({_shape_signature(b) for b in self.data_loader})
+            graphs = (families <= 8 and device.type == "cuda"
+                      and bool(getattr(self, "use_graphs", True)))
             loss_func = PrefixCachedLoss(self.model, kind="vision_language",
                                          batch_len_fn=lambda b: b[0].shape[0], use_graphs=graphs,
                                          n_lanes=int(getattr(self, "n_lanes", 2)) if graphs else 1)
