@@ -145,7 +145,8 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
             from .prefix_cache import PrefixCachedLoss
             families = len({_shape_signature(b) for b in self.data_loader})
             graphs = (families <= 8 and device.type == "cuda"
-                      and bool(getattr(self, "use_graphs", True)))
+                      and bool(getattr(self, "use_graphs", True))
+                      and bool(getattr(self.model, "stages_capturable", True)))
             loss_func = PrefixCachedLoss(self.model, kind="vision_language",
                                          batch_len_fn=lambda b: b[0].shape[0], use_graphs=graphs,
                                          n_lanes=int(getattr(self, "n_lanes", 2)) if graphs else 1)

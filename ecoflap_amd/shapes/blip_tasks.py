@@ -288,18 +288,34 @@ class BlipRetrieval(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def forward_itm(self, image, caption, alpha, idx):
+    # staged forward (contract of ecoflap_amd/pruners/prefix_cache.py): the ViT block by block,
+    # then everything after it as ONE stage — it draws its hard negatives with torch.multinomial
+    # (host sync, global RNG), so it is replayed eagerly, never captured
+    stages_capturable = False
+
+    def unpack(self, batch):
+        image, caption, idx = batch
         dev = self.device
-        image, caption, idx = image.to(dev), caption.to(dev), idx.to(dev)
-        idx = idx.view(-1, 1)
+        return {"image": image.to(dev), "caption": caption.to(dev), "idx": idx.to(dev)}
+
+    def stage_plan(self):
+        plan = vit_stages(self, self.visual_encoder)
+        plan.append(("itm", ["visual_encoder.norm.", "text_encoder.", "vision_proj.", "text_proj.",
+                             "itm_head.", "temp"], self._itm_stage))
+        return plan
+
+    def _itm_stage(self, st):
+        dev = self.device
+        caption = st["caption"]
+        idx = st["idx"].view(-1, 1)
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         pad = self.text_encoder.config.pad_token_id
-        image_embeds = self.visual_encoder(image)
+        image_embeds = self.visual_encoder.norm(st["x"])
         image_atts = torch.ones(image_embeds.shape[:-1], dtype=torch.long, device=dev)
         image_feat = F.normalize(self.vision_proj(image_embeds[:, 0, :]), dim=-1)
         att = (caption != pad).long()
-        bs = image.size(0)
+        bs = image_embeds.size(0)
         output_pos = self.text_encoder(caption, att, image_embeds, image_atts)
         text_output = self.text_encoder(caption, att, None, image_atts, mode="text")
         text_feat = F.normalize(self.text_proj(text_output[:, 0, :]), dim=-1)
@@ -322,7 +338,13 @@ class BlipRetrieval(nn.Module):
         vl = torch.cat([output_pos[:, 0, :], output_neg[:, 0, :]], dim=0)
         labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)],
                            dim=0).to(dev)
-        return F.cross_entropy(self.itm_head(vl), labels)
+        return {"loss": F.cross_entropy(self.itm_head(vl), labels)}
+
+    def forward_itm(self, image, caption, alpha, idx):
+        state = (image, caption, idx)
+        for _, _, fn in self.stage_plan():
+            state = fn(state)
+        return state["loss"]
 
 
 def blip_retrieval_base():

@@ -228,3 +228,12 @@ def test_upop_suffix_only_reforward_is_exact(golden_dir, tag):
     assert res[True][0] == res[False][0]
     for k, v in res[True][1].items():
         assert torch.equal(v, res[False][1][k]), k
+
+
+def test_retrieval_pruner_intended_mode_equals_reference_table(golden_dir):
+    """Whole pruner path for the retrieval task (exact prefix cache: ViT block by block, the
+    negative-sampling rest as one eager stage; torch-RNG coupling) -> the table the reference's
+    own LayerSparsity produces on forward_itm."""
+    g, _, table = run_task(golden_dir, "retrieval", "intended", OracleKernels())
+    names = [str(n) for n in g["retrieval_intended_names"]]
+    assert np.array_equal(np.array([table[k] for k in names]), g["retrieval_intended_sparsity"])
