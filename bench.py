@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 4, 6, 8],
                     help="2: theta+ and theta- suffixes replay concurrently (second weight "
                          "replica + second stream); 1: one after the other")
-    ap.add_argument("--eval-batch", type=int, default=8,
+    ap.add_argument("--eval-batch", type=int, default=16,
                     help="evaluations of a layer whose shared suffix runs once on their "
                          "concatenated states (exact; see pruners/prefix_cache.py)")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")

@@ -37,7 +37,7 @@ class LayerWiseBasePruner(BasePruner):
                  max_sparsity_per_layer=0.8, score_method="GradMagSquare_avg",
                  num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
                  prune_per_model=False, kernels=None, z_source="philox", process_group=None,
-                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=8, **kwargs):
+                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, **kwargs):
         super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
                          importance_scores_cache=importance_scores_cache,
                          keep_indices_or_masks_cache=keep_indices_or_masks_cache,

@@ -723,8 +723,9 @@ def test_upop_graph_replay_equals_full_forward(kern, golden_dir, tag):
         assert torch.equal(v, res[False][1][k]), k
 
 
-def test_batched_suffix_is_exact_at_full_size(kern):
-    """BLIP-2 shape at BASELINE size, four matrices (two ViT-g, two FlanT5): evaluating 8
+@pytest.mark.parametrize("k_evals", [8, 16])
+def test_batched_suffix_is_exact_at_full_size(kern, k_evals):
+    """BLIP-2 shape at BASELINE size, four matrices (two ViT-g, two FlanT5): evaluating 8 / 16
     perturbations per pass with the batch-invariant part of the suffix shared (FlanT5 stages on
     this system; the probe decides) gives the same loss table, bit for bit, as one suffix per
     evaluation; the guard never fires."""
@@ -749,7 +750,8 @@ def test_batched_suffix_is_exact_at_full_size(kern):
         for k in pick:
             dict(model.named_parameters())[k].data.copy_(init[k])
         loss = PrefixCachedLoss(model, use_graphs=True, n_lanes=1,
-                                eval_batch=8 if mode == "batched" else 1, verify_batched="all")
+                                eval_batch=k_evals if mode == "batched" else 1,
+                                verify_batched="all")
         np.random.seed(11)
         ls = LayerSparsity(model, batches, loss, 64, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3,
                            {k: k for k in pick}, kernels=kern, z_source="philox")
