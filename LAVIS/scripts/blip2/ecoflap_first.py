@@ -1,22 +1,9 @@
-"""ECoFLaP first-order |grad|*|W| + Wanda on BLIP-2 (reference: LAVIS/scripts/blip2/ecoflap_first.py:9-30)."""
+"""ECoFLaP first-order |grad|*|W| + Wanda on BLIP-2 (reference: LAVIS/scripts/blip2/ecoflap_first.py:9-30).
+Parameters of the job: LAVIS/scripts/_launch.py::JOBS["blip2/ecoflap_first"]."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _launch import launch  # noqa: E402
+from _launch import run  # noqa: E402
 
-method = "blipt5_wanda_pruner"
-sparsity_ratio_granularity = "block"
-score_method = "GradMagAbs_sum"
-ratio = 0.5
-ratios = f"{ratio}-1.0-1.0"
-max_sparsity_per_layer = f"{round(1.0 - ratio + 0.1, 1)}"
-job_id = f"cc3m-{method}_{ratios}_{score_method}{max_sparsity_per_layer}_{sparsity_ratio_granularity}"
-
-sys.exit(launch("blip2", (
-    f"--pruning_method '{method}' --save_pruned_model"
-    f" --score_method {score_method}"
-    f" --sparsity_ratio_granularity {sparsity_ratio_granularity}"
-    f" --max_sparsity_per_layer {max_sparsity_per_layer}"
-    f" --num_data_first_stage 128"
-    f" --t5_prune_spec 24-{ratios} --vit_prune_spec 39-{ratios} --job_id '{job_id}'")))
+sys.exit(run("blip2/ecoflap_first"))

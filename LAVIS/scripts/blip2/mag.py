@@ -1,15 +1,9 @@
-"""Global magnitude baseline on BLIP-2 (reference: LAVIS/scripts/blip2/mag.py:9-24)."""
+"""Global magnitude baseline on BLIP-2 (reference: LAVIS/scripts/blip2/mag.py:9-24).
+Parameters of the job: LAVIS/scripts/_launch.py::JOBS["blip2/mag"]."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _launch import launch  # noqa: E402
+from _launch import run  # noqa: E402
 
-method = "blipt5_global_mag_pruner"
-ratio = 0.5
-ratios = f"{ratio}-1.0-1.0"
-job_id = f"cc3m-{method}_{ratios}_global"
-
-sys.exit(launch("blip2", (
-    f"--pruning_method '{method}' --save_pruned_model --is_global"
-    f" --t5_prune_spec 24-{ratios} --vit_prune_spec 39-{ratios} --job_id '{job_id}'")))
+sys.exit(run("blip2/mag"))

@@ -1,24 +1,9 @@
-"""ECoFLaP zeroth-order + Wanda on FlanT5 (reference: LAVIS/scripts/t5/ecoflap.py:10-31)."""
+"""ECoFLaP zeroth-order + Wanda on FlanT5 (reference: LAVIS/scripts/t5/ecoflap.py:10-31).
+Parameters of the job: LAVIS/scripts/_launch.py::JOBS["t5/ecoflap"]."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from _launch import launch  # noqa: E402
+from _launch import run  # noqa: E402
 
-method = "t5_wanda_pruner"
-sparsity_ratio_granularity = "block"
-score_method = "MEZO-GradOnly_avg"
-ratio = 0.5
-ratios = f"{ratio}-1.0-1.0"
-max_sparsity_per_layer = f"{round(1.0 - ratio + 0.1, 1)}"
-prunining_dataset_batch_size = 8
-job_id = (f"cc3m-{method}_{ratios}_{score_method}{max_sparsity_per_layer}"
-          f"_{sparsity_ratio_granularity}_bs{prunining_dataset_batch_size}")
-
-sys.exit(launch("t5", (
-    f"--pruning_method '{method}' --save_pruned_model"
-    f" --score_method {score_method}"
-    f" --sparsity_ratio_granularity {sparsity_ratio_granularity}"
-    f" --max_sparsity_per_layer {max_sparsity_per_layer}"
-    f" --prunining_dataset_batch_size {prunining_dataset_batch_size}"
-    f" --t5_prune_spec 24-{ratios} --job_id '{job_id}'")))
+sys.exit(run("t5/ecoflap"))

@@ -1,6 +1,9 @@
-"""Loss closures handed to stage 1: `(model, batch, cuda_enabled) -> (loss, batch_len)`
-(LAVIS/lavis/compression/pruners/utils.py:21-67)."""
+"""Loss closures handed to stage 1, `(model, batch, cuda_enabled) -> (0-dim loss, batch_len)` —
+the three the LAVIS pruners use (LAVIS/lavis/compression/pruners/utils.py:21-67: the language
+and vision-language ones read the model's own "loss"; the vision one rebuilds a cross entropy
+from `predict()`'s x100-scaled zero-shot logits)."""
 import torch
+import torch.nn.functional as F
 
 
 def prepare_sample(samples, cuda_enabled=True, device=None):
@@ -11,29 +14,28 @@ def prepare_sample(samples, cuda_enabled=True, device=None):
             for k, v in samples.items()}
 
 
-def _device_of(model):
-    return next(iter(model.parameters())).device
+def _on_model_device(model, samples, cuda_enabled):
+    return prepare_sample(samples, cuda_enabled, next(iter(model.parameters())).device)
 
 
-def loss_vision_language(model, samples, cuda_enabled):
-    samples = prepare_sample(samples, cuda_enabled, _device_of(model))
-    loss = model(samples)["loss"]
-    return loss, len(samples["text_input"])
+def _model_loss(count_key):
+    """Closure for models whose forward returns {"loss": ...}; batch_len = len(batch[count_key])."""
+    def closure(model, samples, cuda_enabled):
+        batch = _on_model_device(model, samples, cuda_enabled)
+        return model(batch)["loss"], len(batch[count_key])
+    return closure
 
 
-def loss_language(model, samples, cuda_enabled):
-    samples = prepare_sample(samples, cuda_enabled, _device_of(model))
-    loss = model(samples)["loss"]
-    return loss, len(samples["text_input"])
+loss_vision_language = _model_loss("text_input")
+loss_vision_language.__name__ = "loss_vision_language"
+loss_language = _model_loss("text_input")
+loss_language.__name__ = "loss_language"
 
 
 def loss_vision(model, samples, cuda_enabled):
-    """Cross entropy of the zero-shot logits, undoing predict()'s x100 (utils.py:47-67)."""
-    samples = prepare_sample(samples, cuda_enabled, _device_of(model))
-    outputs = model.predict(samples)
-    logits = outputs["predictions"] / 100
-    targets = outputs["targets"]
-    probs = torch.nn.functional.softmax(logits, -1)
-    batch_index = torch.arange(len(targets)).to(targets.device)
-    log_probs = probs[batch_index, targets].log()
-    return -log_probs.mean(), len(targets)
+    """-mean(log softmax(predictions / 100)[target]) over the batch (utils.py:47-67: probabilities
+    first, then the log of the picked ones — kept in that order for the same roundings)."""
+    out = model.predict(_on_model_device(model, samples, cuda_enabled))
+    targets = out["targets"]
+    picked = F.softmax(out["predictions"] / 100, -1).gather(1, targets.view(-1, 1)).squeeze(1)
+    return -(picked.log().mean()), len(targets)

@@ -130,3 +130,27 @@ def test_pruned_checkpoint_reingest(tmp_path, monkeypatch):
     for k, v in fresh2.state_dict().items():
         if k.startswith("visual_encoder."):
             assert torch.equal(v, want[k]), k
+
+
+def test_launcher_table_produces_valid_harness_flags():
+    """Every LAVIS/scripts/** stub names a JOBS entry whose flag string the harness parser accepts
+    (reference method / score / ratio strings and job ids)."""
+    import shlex
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "LAVIS", "scripts"))
+    import _launch as L
+    import ecoflap_amd.harness as H
+    from ecoflap_amd.registry import registry
+    import ecoflap_amd.pruners  # noqa: F401  (registers the pruners)
+    for name, (shape, pruner, keep, opt, template) in L.JOBS.items():
+        assert os.path.exists(os.path.join(root, "LAVIS", "scripts", name + ".py")), name
+        assert registry.get_pruner_class(pruner) is not None, pruner
+        for eps in opt.get("eps_sweep", [None]):
+            flags = L.harness_flags(shape, pruner, keep, opt, template, eps=eps)
+            args = H.build_parser().parse_args(["--shape", shape] + shlex.split(flags))
+            assert args.pruning_method == pruner and args.save_pruned_model
+            assert "{" not in args.job_id and "None" not in args.job_id
+    a = H.build_parser().parse_args(shlex.split(L.harness_flags(*L.JOBS["blip2/ecoflap_zeroth"])))
+    assert a.job_id == "cc3m-blipt5_wanda_pruner_0.5-1.0-1.0_MEZO-GradOnly_sum0.6_block_bs8"
+    assert a.max_sparsity_per_layer == 0.6 and a.t5_prune_spec == "24-0.5-1.0-1.0"
