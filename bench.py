@@ -52,7 +52,7 @@ def parse():
                          "suffix-only re-forward (pruners/prefix_cache.py)")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch the suffix forwards eagerly instead of replaying HIP graphs")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 4, 6, 8],
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4, 6, 8],
                     help="2: theta+ and theta- suffixes replay concurrently (second weight "
                          "replica + second stream); 1: one after the other")
     ap.add_argument("--eval-batch", type=int, default=16,

@@ -154,7 +154,7 @@ class PrefixCachedLoss:
         self.invariant = {}         # stage -> batch invariant on this system (probed)
         if n_lanes is None:
             n_lanes = 2 if two_lanes else 1
-        assert n_lanes in (1, 2, 4, 6, 8)
+        assert n_lanes in (1, 2, 3, 4, 6, 8)
         self.n_lanes = n_lanes if self.use_graphs else 1
         self.two_lanes = self.n_lanes > 1
         self.extra_lanes = None     # replicas (model copy + stream + graphs), built lazily
