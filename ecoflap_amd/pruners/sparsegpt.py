@@ -30,6 +30,7 @@ class SparseGPT:
         self.columns = W.shape[1]
         self.H = torch.zeros((self.columns, self.columns), device=self.dev)
         self.nsamples = 0
+        self.factor = None          # (dead columns, Hinv) once pruned; shared within a block
         self.kernels = kernels if kernels is not None else _hip.HipKernels()
 
     def add_batch(self, inp, out):
@@ -60,23 +61,34 @@ class SparseGPT:
             H[diag, diag] += damp                                 # not positive definite yet
         raise RuntimeError("Hessian could not be made positive definite")
 
-    def fasterprune(self, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=.01):
+    def fasterprune(self, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=.01,
+                    same_hessian_as=None):
+        """`same_hessian_as`: a SparseGPT of this block that saw the very same inputs (q/k/v,
+        wi_0/wi_1, cross-attention k/v: bit-identical H, checked by the caller) and has already
+        been pruned — its dead-column mask and factor Hinv depend on H only and are reused
+        instead of being recomputed (two Cholesky factorisations and an inverse each)."""
         if prune_n != 0:
             raise NotImplementedError("N:M sparsity: prune_n is always 0 in the reference "
                                       "(layer_single_base_pruner.py:62)")
         W = self.layer.weight.data.clone().float()
         H = self.H
         del self.H
-        dead = torch.diag(H) == 0
-        H[dead, dead] = 1
-        W[:, dead] = 0
-        self._clamp_inf(H)
-        damp = percdamp * torch.mean(torch.diag(H))
-        H = self._damped_cholesky(H, damp, upper=False)
-        H = torch.cholesky_inverse(H)
-        self._clamp_inf(H)
-        damp = percdamp * torch.mean(torch.diag(H).abs())
-        Hinv = self._damped_cholesky(H, damp, upper=True).contiguous()
+        if same_hessian_as is not None and same_hessian_as.factor is not None:
+            dead, Hinv = same_hessian_as.factor
+            W[:, dead] = 0
+            del H
+        else:
+            dead = torch.diag(H) == 0
+            H[dead, dead] = 1
+            W[:, dead] = 0
+            self._clamp_inf(H)
+            damp = percdamp * torch.mean(torch.diag(H))
+            H = self._damped_cholesky(H, damp, upper=False)
+            H = torch.cholesky_inverse(H)
+            self._clamp_inf(H)
+            damp = percdamp * torch.mean(torch.diag(H).abs())
+            Hinv = self._damped_cholesky(H, damp, upper=True).contiguous()
+        self.factor = (dead, Hinv)
         for i1 in range(0, self.columns, blocksize):
             i2 = min(i1 + blocksize, self.columns)
             count = i2 - i1
@@ -89,6 +101,7 @@ class SparseGPT:
 
     def free(self):
         self.H = None
+        self.factor = None
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
 

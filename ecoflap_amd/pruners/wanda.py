@@ -286,6 +286,15 @@ class _BlockwiseWanda:
                 self._merge_statistics(wrapped)
             else:
                 self._merge_hessians(wrapped)
+            twins = {}
+            if sparsegpt:      # Linears fed by the same tensor have bit-identical Hessians
+                names_ = list(subset)
+                for a_i, a in enumerate(names_):
+                    for b in names_[:a_i]:
+                        if (b not in twins and wrapped[b].H.shape == wrapped[a].H.shape
+                                and torch.equal(wrapped[b].H, wrapped[a].H)):
+                            twins[a] = b
+                            break
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps) * count_factor
                 weight = subset[name].weight.data
@@ -293,14 +302,18 @@ class _BlockwiseWanda:
                 if sparsegpt:           # sparsegpt_pruner.py:394 / :650
                     wrapped[name].fasterprune(ratio, prune_n=self.owner.prune_n,
                                               prune_m=self.owner.prune_m, percdamp=0.01,
-                                              blocksize=128)
-                    wrapped[name].free()
+                                              blocksize=128,
+                                              same_hessian_as=wrapped.get(twins.get(name)))
+                    wrapped[name].H = None
                 elif mode == "rows":      # per output row, k smallest by stable order (:272-279)
                     k = int(weight.shape[1] * ratio)
                     self.kernels.wanda_prune_rows(weight, wrapped[name].scaler_row, k)
                 else:                   # whole matrix, metric <= sorted[k] (:555-558)
                     k = int(weight.numel() * ratio)
                     self.kernels.wanda_prune_matrix(weight, wrapped[name].scaler_row, k)
+            if sparsegpt:
+                for w_ in wrapped.values():
+                    w_.free()
             if graphed:
                 graph_pass(block, None, keep=True)
             else:
