@@ -301,7 +301,7 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * ls.stats.get("host_enqueue_seconds", 0.0) / args.steps,
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
-            "suffix_forward": (dict(run.loss_fns[-1].stats)
+            "suffix_forward": (_compact_stats(run.loss_fns[-1].stats)
                                if hasattr(run.loss_fns[-1], "stats") else None),
         },
     }
@@ -331,6 +331,15 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _compact_stats(stats):
+    out = dict(stats)
+    names = out.pop("stages_not_batch_invariant", None)
+    if names is not None:      # e.g. the 39 ViT-g blocks + the Q-Former bridge
+        out["stages_not_batch_invariant"] = len(names)
+        out["stages_not_batch_invariant_examples"] = sorted(names)[:2] + sorted(names)[-1:]
+    return out
 
 
 def load_pmc_traffic(kind, algorithmic_bytes_per_launch=None):
