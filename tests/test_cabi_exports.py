@@ -70,3 +70,37 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert lib.ecoflap_wanda_prune_matrix(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 4, 0, 16,
                                           None, ctypes.c_void_p(16), 1 << 20, None) == -3
     assert b"aligned" in lib.ecoflap_error_string(-5)
+
+
+def test_argument_errors_of_the_later_entry_points():
+    """Validation comes before any launch: the multi-tensor / global-threshold / device-counter
+    entry points reject bad arguments with the documented codes without a GPU."""
+    from ecoflap_amd import hip
+    lib = hip.load_library()
+    vp = ctypes.c_void_p
+    assert lib.ecoflap_grad_accum_multi(None, 0, None) == 0                       # no layers
+    assert lib.ecoflap_grad_accum_multi(None, 3, None) == -2                      # ENULL
+    assert lib.ecoflap_grad_accum_multi(None, -1, None) == -3                     # ESIZE
+    ws = lib.ecoflap_global_prune_workspace_bytes()
+    assert ws >= 3 * 2048 * 4
+    args = lambda **kw: [kw.get("table", vp(16)), kw.get("n", 2), kw.get("mode", 0), 3.0,   # noqa: E731
+                         kw.get("k", 5), kw.get("total", 100), kw.get("ws", vp(16)),
+                         kw.get("ws_bytes", ws), None]
+    assert lib.ecoflap_global_threshold_prune(*args(mode=4)) == -4                # EMODE
+    assert lib.ecoflap_global_threshold_prune(*args(k=0)) == -3                   # rank out of range
+    assert lib.ecoflap_global_threshold_prune(*args(k=101)) == -3
+    assert lib.ecoflap_global_threshold_prune(*args(total=1 << 33)) == -3         # 32-bit bins
+    assert lib.ecoflap_global_threshold_prune(*args(table=None)) == -2
+    assert lib.ecoflap_global_threshold_prune(*args(ws_bytes=16)) == -6           # EWORKSPACE
+    assert lib.ecoflap_count_zeros_multi(None, 0, None, None) == 0
+    assert lib.ecoflap_count_zeros_multi(vp(16), 2, None, None) == -2
+    # K6 with the sample count on the device: the counter pointer is mandatory
+    assert lib.ecoflap_colsqnorm_accum_dev(vp(16), vp(16), 8, 8, 0, None, 1, vp(16), 1 << 20, None) == -2
+    assert lib.ecoflap_colsqnorm_accum_dev(vp(16), vp(16), 8, 8, 0, vp(16), 0, vp(16), 1 << 20, None) == -3
+    assert lib.ecoflap_colsqnorm_accum_dev(vp(16), vp(16), 8, 8, 0, vp(16), 1, vp(16), 4, None) == -6
+    # plumbing ops of the shape modules
+    lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_float, ctypes.c_int, vp]
+    assert lib.ecoflap_add_layernorm(vp(16), None, vp(16), vp(16), None, vp(16), 4, 12, 1e-6, 1, None) == -3
+    assert lib.ecoflap_add_layernorm(vp(16), None, vp(16), vp(16), None, vp(16), 4, 16, 1e-6, 0, None) == -1
+    assert lib.ecoflap_add_layernorm(vp(16), vp(16), vp(16), vp(16), None, vp(16), 4, 16, 1e-6, 1, None) == -2
