@@ -11,8 +11,14 @@ positions over the model's 588 (ViT, T5 encoder, T5 decoder alike); the closing 
 the score reduction and the allocator are inside the timed region.
 
     python bench.py --gpus 1 --steps 12 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset): this process makes no
+GPU call at all; it starts N children of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set, backend nccl = RCCL), relays rank 0's JSON line and
+exits with the worst child return code.
 
 Weak scaling: every rank holds a full weight replica and scores the SAME matrices on its
 own 128 calibration pairs (16 batches of 8); N ranks = 128*N pairs per matrix
@@ -142,23 +148,92 @@ class TimedKernels:
         return {"launches": n, "avg_us": 1e6 * t / n, "bytes_per_launch": b / n, "gbs": b / t / 1e9}
 
 
+def self_launch(n, argv, script=None, timeout=None):
+    """Start `n` ranks of `script` (default: this file) as CHILD processes, one per GPU, and
+    return (worst return code, rank 0's stdout).  The caller has not touched the GPU (a process
+    that has initialised HIP must never be replaced by / fork another GPU user), so the children
+    are plain `subprocess` children with the launcher environment torch.distributed expects."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as rank0_out:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
+                        "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                        "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+            procs.append(subprocess.Popen(
+                [sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                stdout=rank0_out if r == 0 else sys.stderr, stderr=sys.stderr))
+        t_end = None if timeout is None else time.time() + timeout
+        worst = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            failed = any(c not in (None, 0) for c in codes)
+            if failed or (t_end is not None and time.time() > t_end):
+                # one rank died (the others would sit in a collective until the process group's
+                # own timeout) or the caller's limit passed: end exactly the PIDs started here
+                worst = 1 if failed else 124
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+                break
+            time.sleep(0.2)
+        for p in procs:
+            rc = p.returncode
+            if rc and worst != 124:               # a signal (negative) reads as 128 + signal
+                worst = max(worst, rc if rc > 0 else 128 - rc)
+        rank0_out.seek(0)
+        out0 = rank0_out.read()
+    return worst, out0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no GPU call before this point (module imports only)
+        visible = torch.cuda.device_count()         # counting devices does not initialise HIP
+        if visible < args.gpus and not args.same_device:
+            print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible",
+                  file=sys.stderr)
+            sys.exit(2)
+        rc, out0 = self_launch(args.gpus, sys.argv[1:])
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    rccl_ranks = None
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
         else:
             dist.init_process_group(args.dist_backend)
+        # read back from the process group, after one real collective on it
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert int(probe.item()) == world
+        rccl_ranks = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "all_reduce_of_ones": int(probe.item())}
 
     from ecoflap_amd import hip
     from ecoflap_amd.pruners import LayerSparsity
@@ -262,6 +337,9 @@ def main():
         "value": value,
         "unit": "layers/s (one layer = one weight matrix scored on 128 calibration pairs)",
         "n_gpus": world,
+        "rccl_ranks": (rccl_ranks["world_size"] if rccl_ranks and rccl_ranks["backend"] == "nccl"
+                       else None),
+        "process_group": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

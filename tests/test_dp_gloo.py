@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _run_case(method, k1_form, rank, world, cached):
+def _run_case(method, k1_form, rank, world, cached, n_samples=8, batch=2):
     from oracle_backend import OracleKernels, torch_cpu_normal
     from ecoflap_amd.pruners import LayerSparsity
     from ecoflap_amd.pruners.losses import loss_vision_language
@@ -27,13 +27,14 @@ def _run_case(method, k1_form, rank, world, cached):
     model = blip2_toy().eval()
     for p in model.parameters():
         p.requires_grad = True
-    batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    batches = S.image_text_batches(n_samples, batch, img_size=28, vocab=96, in_len=5, out_len=4,
+                                   seed=6)
     mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
                for k, v in model.named_parameters()
                if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
     np.random.seed(42)
     loss = PrefixCachedLoss(model) if cached else loss_vision_language
-    ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, method, 1, 1e-3, mapping,
+    ls = LayerSparsity(model, batches, loss, n_samples, 0.5, 0.6, method, 1, 1e-3, mapping,
                        kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form=k1_form)
     sp = ls.return_sparsity()
     weights = {k: v.detach().clone() for k, v in model.state_dict().items() if k in mapping}
@@ -41,12 +42,12 @@ def _run_case(method, k1_form, rank, world, cached):
     return sp, ls.loss_table, weights, sums, dict(ls.stats)
 
 
-def _worker(rank, world, port, method, k1_form, cached, out_dir):
+def _worker(rank, world, port, method, k1_form, cached, out_dir, n_samples=8, batch=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run_case(method, k1_form, rank, world, cached)
+        res = _run_case(method, k1_form, rank, world, cached, n_samples, batch)
         torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -72,6 +73,30 @@ def test_two_ranks_reproduce_single_process(tmp_path, method, k1_form, cached):
             for k, v in sums.items():                                  # double sums re-associate
                 assert abs(v - single[3][k]) <= 1e-6 * abs(v)
             assert sp == single[0]
+
+
+@pytest.mark.parametrize("world,n_samples,batch,k1_form", [
+    (3, 10, 2, "units"),      # 5 batches over 3 ranks: 2 / 2 / 1
+    (2, 6, 2, "triple"),      # 3 batches over 2 ranks: 2 / 1
+    (4, 8, 2, "units"),       # one batch per rank
+    (4, 4, 2, "units")])      # fewer batches than ranks: two ranks only carry the drift
+def test_uneven_shards_and_more_ranks_reproduce_single_process(tmp_path, world, n_samples, batch,
+                                                               k1_form):
+    method = "MEZO-GradOnly_sum"
+    single = _run_case(method, k1_form, 0, 1, False, n_samples, batch)
+    port = 35500 + (os.getpid() + 7 * world + n_samples) % 2000
+    mp.spawn(_worker, args=(world, port, method, k1_form, False, str(tmp_path), n_samples, batch),
+             nprocs=world, join=True)
+    n_forward = 0
+    for r in range(world):
+        sp, table, weights, sums, stats = torch.load(tmp_path / f"rank{r}.pt", weights_only=False)
+        assert stats["world_size"] == world
+        n_forward += stats["forwards"]
+        assert np.array_equal(table, single[1])
+        assert sp == single[0]
+        for k in weights:
+            assert torch.equal(weights[k], single[2][k]), k
+    assert n_forward == single[4]["forwards"]         # every unit evaluated by exactly one rank
 
 
 def _run_wanda(rank, world):
