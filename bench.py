@@ -69,6 +69,15 @@ def parse():
                     help="nccl (= RCCL) in production; 'gloo' + --same-device only to exercise "
                          "the N>1 code path on a single-GPU box")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--k1-blocker", default="spin", choices=["spin", "gemm", "none"],
+                    help="what keeps the launch stream busy while the host enqueues the event pair "
+                         "around a K1 launch: a one-thread spin kernel (default; leaves the chip's "
+                         "power state alone), four 4096^3 GEMMs (round 1; they pull the clock down "
+                         "for the kernel that follows), or nothing (the pair then also times the "
+                         "host's enqueue gap)")
+    ap.add_argument("--no-k1-events", action="store_true",
+                    help="no event pairs, no blocker: the uninstrumented loop (rocprofv3 "
+                         "cross-check of the K1 durations; the line then carries no roofline)")
     return ap.parse_args()
 
 
@@ -88,14 +97,55 @@ def strided(n_total, k, offset=0, run=6):
     return out
 
 
+class HipEvents:
+    """Raw hipEvent_t pairs through libamdhip64 (ctypes): `ecoflap_zo_perturb_units_timed` fills
+    them with the kernel's own begin / end timestamps."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.rt.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p,
+                                                ctypes.c_void_p]
+        self.rt.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.rt.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def pair(self):
+        out = []
+        for _ in range(2):
+            ev = self.ct.c_void_p()
+            rc = self.rt.hipEventCreate(self.ct.byref(ev))
+            assert rc == 0, f"hipEventCreate -> {rc}"
+            out.append(ev)
+        return tuple(out)
+
+    def elapsed_us(self, start, stop):
+        ms = self.ct.c_float()
+        assert self.rt.hipEventSynchronize(stop) == 0
+        rc = self.rt.hipEventElapsedTime(self.ct.byref(ms), start, stop)
+        assert rc == 0, f"hipEventElapsedTime -> {rc}"
+        return 1e3 * ms.value
+
+
 class TimedKernels:
-    """Wraps the HIP backend and brackets every K1 launch with events on the launch stream."""
+    """Wraps the HIP backend and times every K1 launch on the launch stream.
+
+    Layer-batched form (the bench's default, `units`): the launch itself carries the event pair
+    (`ecoflap_zo_perturb_units_timed` -> hipExtLaunchKernelGGL), which records the kernel's own
+    begin / end timestamps — the duration rocprofv3's kernel trace reports for the same dispatch;
+    nothing is queued around the launch and the loop runs as it does uninstrumented.
+    The other K1 forms (`triple`, `single`) keep a torch event pair behind a one-thread spin
+    kernel (see `_timed`)."""
 
     def __init__(self, inner):
         self.inner = inner
         self.enabled = False
-        self.records = []   # (start_event, end_event, algorithmic_bytes, kind)
+        self.records = []   # (start_event, end_event, algorithmic_bytes, kind, n_launches)
         self.blocker = None
+        self.spin_cycles = 600000
+        self.hip_events = None
+        self.unit_records = []   # (start, stop, algorithmic_bytes) raw HIP events
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
@@ -103,11 +153,15 @@ class TimedKernels:
     def _timed(self, kind, nbytes, fn, *a, n_launches=1, **kw):
         if not self.enabled:
             return fn(*a, **kw)
-        # The loop is host-bound (the GPU drains its queue while Python prepares the next
-        # launch), so an event pair would also time the host gap between its two records.
-        # ~0.6 ms of GEMMs queued first keep the GPU busy while the host enqueues
-        # start-event, kernel and stop-event back to back; it is not part of the timed span.
-        if self.blocker is not None:
+        # The GPU drains its queue while Python prepares the next launch, so a bare event pair
+        # would also time the host gap between its two records.  ~0.3 ms of a ONE-THREAD spin
+        # kernel queued first keeps the stream busy while the host enqueues start-event, kernel
+        # and stop-event back to back; it is not part of the timed span and, unlike the GEMMs
+        # round 1 used here, leaves the chip's power state alone (the same bf16 K1 launch:
+        # 156 us right after four 4096^3 GEMMs, 119 us after the spin; tools/k1_time.py).
+        if self.blocker == "spin":
+            torch.cuda._sleep(self.spin_cycles)
+        elif self.blocker is not None:
             for _ in range(4):
                 torch.mm(self.blocker, self.blocker)
         s = torch.cuda.Event(enable_timing=True)
@@ -126,12 +180,22 @@ class TimedKernels:
                            w_in, w_plus, w_minus, w_restored, zo_eps, seed, z)
 
     def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
-        owned = sum(1 for t in w_plus if t is not None)
-        chunks = max(1, -(-len(seeds) // self.inner.MAX_UNITS))   # launches of <= 32 units
-        # per launch: read W, write theta+/theta- of its owned units, write the drifted W
-        nbytes = (2 * owned + 2 * chunks) * w.element_size() * w.numel()
-        return self._timed("units", nbytes, self.inner.zo_perturb_units, w, zo_eps, seeds, w_plus,
-                           w_minus, z, n_launches=chunks)
+        if not self.enabled:
+            return self.inner.zo_perturb_units(w, zo_eps, seeds, w_plus, w_minus, z)
+        if self.hip_events is None:
+            self.hip_events = HipEvents()
+        s, n, mx = w.element_size(), w.numel(), self.inner.MAX_UNITS
+        chunks = [(c0, min(len(seeds), c0 + mx)) for c0 in range(0, len(seeds), mx)]
+        it = iter(chunks)
+
+        def events():
+            c0, c1 = next(it)
+            owned = sum(1 for t in w_plus[c0:c1] if t is not None)
+            pair = self.hip_events.pair()
+            # per launch: read W, write theta+/theta- of its owned units, write the drifted W
+            self.unit_records.append((pair[0], pair[1], (2 * owned + 2) * s * n))
+            return pair
+        return self.inner.zo_perturb_units(w, zo_eps, seeds, w_plus, w_minus, z, events=events)
 
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         nbytes = 2 * w.element_size() * w.numel()          # read W, write W
@@ -139,13 +203,18 @@ class TimedKernels:
                            seed, z)
 
     def summary(self, kind):
-        recs = [(s.elapsed_time(e) * 1e-3, b, n) for s, e, b, k, n in self.records if k == kind]
+        if kind == "units":
+            recs = [(self.hip_events.elapsed_us(a, b) * 1e-6, nb, 1) for a, b, nb in self.unit_records]
+        else:
+            recs = [(s.elapsed_time(e) * 1e-3, b, n) for s, e, b, k, n in self.records if k == kind]
         if not recs:
             return None
         t = sum(r[0] for r in recs)
         b = sum(r[1] for r in recs)
         n = sum(r[2] for r in recs)
-        return {"launches": n, "avg_us": 1e6 * t / n, "bytes_per_launch": b / n, "gbs": b / t / 1e9}
+        return {"launches": n, "avg_us": 1e6 * t / n, "bytes_per_launch": b / n, "gbs": b / t / 1e9,
+                "per_launch": [{"us": round(1e6 * r[0], 2), "bytes": r[1],
+                                "frac": round(r[1] / r[0] / 1e9 / HBM_PEAK_GBS, 4)} for r in recs]}
 
 
 def self_launch(n, argv, script=None, timeout=None):
@@ -271,7 +340,9 @@ def main():
     build_s = time.time() - t_build
 
     kern = TimedKernels(hip.HipKernels())
-    kern.blocker = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    kern.blocker = {"spin": "spin", "none": None,
+                    "gemm": torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+                    if args.k1_blocker == "gemm" else None}[args.k1_blocker]
 
     from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
 
@@ -296,7 +367,7 @@ def main():
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
                            z_source="philox", k1_form=args.k1_form)
-        kern.enabled = timed
+        kern.enabled = timed and not args.no_k1_events
         out = ls.return_sparsity()
         kern.enabled = False
         return ls, out
@@ -396,6 +467,10 @@ def main():
             "traffic_source": "profiles/k1_pmc_traffic.json (rocprofv3 --pmc, separate passes)",
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
+            "timing": ("kernel begin/end timestamps in HIP events attached to the launch "
+                       "(hipExtLaunchKernelGGL)" if kind == "units" else
+                       f"torch event pair behind a '{args.k1_blocker}' blocker"),
+            "per_launch": k1["per_launch"],
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
             "bytes_rule": {
                 "units": "(2*U+2)*s*numel per launch: read W once, write theta+/theta- for each of "

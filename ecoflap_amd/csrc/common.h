@@ -119,8 +119,16 @@ template <> struct Vec<ECOFLAP_BF16> {
     static __device__ __forceinline__ float round(float x) {
         return __uint_as_float(f2b(x) << 16);
     }
+    // x0 -> low half, x1 -> high half, round-to-nearest-even, NaN-preserving.  Explicit asm: the
+    // compiler only sometimes fuses two scalar casts into the packed convert, and its SLP
+    // vectoriser then re-pairs the operands and repacks the halves with extra SDWA ops.
+    static __device__ __forceinline__ uint32_t f2b_pk(float x0, float x1) {
+        uint32_t pk;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x0), "v"(x1));
+        return pk;
+    }
     static __device__ __forceinline__ uint32_t round_pair(float x0, float x1, float& r0, float& r1) {
-        const uint32_t pk = f2b(x0) | (f2b(x1) << 16);   // one v_cvt_pk_bf16_f32
+        const uint32_t pk = f2b_pk(x0, x1);
         r0 = __uint_as_float(pk << 16);
         r1 = __uint_as_float(pk & 0xffff0000u);
         return pk;

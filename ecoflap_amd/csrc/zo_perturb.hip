@@ -11,6 +11,7 @@
 // dtype per reference op, no fma contraction (-ffp-contract=off).
 // Algorithmic bytes: single pass 2*s per element; fused triple 4*s per element.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 // ---------------------------------------------------------------- Philox4x32
 #define PHILOX_M0 0xD2511F53u
@@ -40,47 +41,96 @@ static __device__ __forceinline__ void philox4x32(uint64_t counter, uint32_t k0,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// two N(0,1) draws from two 32-bit words
-static __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-    // u1 in (0, 1]: (a + 0.5) * 2^-32 ; u2 in [0, 1]: revolutions
+// ---------------------------------------------------------------- in-register z streams
+// Work unit of every K1 kernel: one lane owns TWO 16-byte vectors, v and v + 64 (the same lane
+// of two consecutive 1-KiB wave rows), i.e. a wave owns a "super-row" of 128 vectors; every
+// global access stays a fully coalesced 1 KiB per wave instruction.
+//
+// Stream N32 (fp32 storage): element e uses Philox call e/4 (counter = e/4, key = seed); words
+//   (w0,w1) -> elements 4c+0 = r cos, 4c+1 = r sin; (w2,w3) -> 4c+2, 4c+3.  32-bit radius word
+//   and 32-bit angle word per pair.
+// Stream N16 (fp16 / bf16 storage): a bf16 / fp16 z cannot resolve an angle finer than 2^-16 of
+//   a turn (its own rounding is 2^-9 / 2^-12 relative), so a pair takes a full 32-bit radius
+//   word (tail to 6.7 sigma, as N32) and a 16-bit angle: 48 bits per pair, THREE Philox calls
+//   per 16 elements instead of four.  Block g = 64*(v/128) + v%64 holds the 16 elements of
+//   vectors (128*(v/128) + v%64) and (that + 64); calls 3g, 3g+1, 3g+2 give words W[0..11];
+//   pair j (0..7): radius word W[j], angle = halfword j of W[8..11] (low half first);
+//   position p = 8*((v/64)%2) + e%8 = 4q + t takes pair 2q + (t&1), cos for t < 2, sin for
+//   t >= 2 — so that packed register i of a vector holds (r_a f(a), r_b f(b)) of two pairs and
+//   every rounding below is one packed convert of values that sit in adjacent registers.
+// oracle/ecoflap_oracle.c:oracle_normal_stream restates both (double-precision log2 / sqrt /
+// sin / cos rounded once to fp32; the hardware units differ from that by a few fp32 ulps, the
+// tolerance the generator test states).
+#define ECO_ROW 64          // vectors per wave row; a lane's two vectors are ECO_ROW apart
+
+static __device__ __forceinline__ float radius_of(uint32_t a) {
+    // u1 in (0, 1]: (a + 0.5) * 2^-32 ;  r = sqrt(-2 ln u1) = sqrt(-2 ln2 * log2 u1)
     const float u1 = __builtin_fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float u2 = (float)b * 2.3283064365386963e-10f;
-    // -2 ln(u1) = -2 ln2 * log2(u1)
-    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+}
+
+// two N(0,1) draws from two 32-bit words (N32)
+static __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u2 = (float)b * 2.3283064365386963e-10f;       // revolutions in [0, 1]
+    const float r = radius_of(a);
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-// z for the N elements of vector `vec` (element e = vec*N + i uses Philox counter e/4, word e%4)
+// N32: z for the 4 elements of fp32 vector `vec`
+static __device__ __forceinline__ void gen_z4(int64_t vec, uint32_t k0, uint32_t k1, float* z) {
+    uint32_t r[4];
+    philox4x32((uint64_t)vec, k0, k1, r);
+    box_muller(r[0], r[1], z[0], z[1]);
+    box_muller(r[2], r[3], z[2], z[3]);
+}
+
+// N16: z (already rounded to the storage dtype) for the 16 elements of block g:
+// z[0..7] -> vector (g/64)*128 + g%64, z[8..15] -> that + 64
 template <int DT>
-static __device__ __forceinline__ void gen_z(int64_t vec, uint32_t k0, uint32_t k1, float* z) {
-    constexpr int N = Vec<DT>::N;
+static __device__ __forceinline__ void gen_z16(int64_t g, uint32_t k0, uint32_t k1, float* z) {
+    uint32_t w[12];
+    philox4x32((uint64_t)(3 * g + 0), k0, k1, w + 0);
+    philox4x32((uint64_t)(3 * g + 1), k0, k1, w + 4);
+    philox4x32((uint64_t)(3 * g + 2), k0, k1, w + 8);
 #pragma unroll
-    for (int q = 0; q < N / 4; ++q) {
-        uint32_t r[4];
-        philox4x32((uint64_t)(vec * (N / 4) + q), k0, k1, r);
-        box_muller(r[0], r[1], z[4 * q + 0], z[4 * q + 1]);
-        box_muller(r[2], r[3], z[4 * q + 2], z[4 * q + 3]);
-    }
-    // torch.normal(dtype=param.dtype): the fp32 draw rounded to the storage dtype
-    if constexpr (DT == ECOFLAP_F32) {
-        return;
-    } else {
-#pragma unroll
-        for (int i = 0; i < N / 2; ++i)
-            Vec<DT>::round_pair(z[2 * i], z[2 * i + 1], z[2 * i], z[2 * i + 1]);
+    for (int q = 0; q < 4; ++q) {          // pairs a = 2q, b = 2q + 1
+        const uint32_t ang = w[8 + q];
+        const float ua = (float)(ang & 0xffffu) * 1.52587890625e-05f;   // exact: h * 2^-16
+        const float ub = (float)(ang >> 16) * 1.52587890625e-05f;
+        const float ra = radius_of(w[2 * q]), rb = radius_of(w[2 * q + 1]);
+        const float ca = __builtin_amdgcn_cosf(ua), cb = __builtin_amdgcn_cosf(ub);
+        const float sa = __builtin_amdgcn_sinf(ua), sb = __builtin_amdgcn_sinf(ub);
+        // torch.normal(dtype=param.dtype): the fp32 draw rounded to the storage dtype
+        Vec<DT>::round_pair(ra * ca, rb * cb, z[4 * q + 0], z[4 * q + 1]);
+        Vec<DT>::round_pair(ra * sa, rb * sb, z[4 * q + 2], z[4 * q + 3]);
     }
 }
 
-// scalar tail element
+// z of a lane's two vectors (v0 = 128R + lane, v1 = v0 + 64): z[0..N-1], z[N..2N-1]
+template <int DT>
+static __device__ __forceinline__ void gen_z_lane(int64_t v0, uint32_t k0, uint32_t k1, float* z) {
+    if constexpr (DT == ECOFLAP_F32) {
+        gen_z4(v0, k0, k1, z);
+        gen_z4(v0 + ECO_ROW, k0, k1, z + 4);
+    } else {
+        gen_z16<DT>(((v0 >> 7) << 6) + (v0 & 63), k0, k1, z);
+    }
+}
+
+// scalar tail element (n % N != 0: the last < N elements belong to no full vector)
 template <int DT>
 static __device__ __forceinline__ float gen_z1(int64_t e, uint32_t k0, uint32_t k1) {
-    uint32_t r[4];
-    philox4x32((uint64_t)(e >> 2), k0, k1, r);
-    float z[4];
-    box_muller(r[0], r[1], z[0], z[1]);
-    box_muller(r[2], r[3], z[2], z[3]);
-    return Vec<DT>::round(z[e & 3]);
+    if constexpr (DT == ECOFLAP_F32) {
+        float z[4];
+        gen_z4(e >> 2, k0, k1, z);
+        return z[e & 3];
+    } else {
+        const int64_t v = e >> 3;
+        float z[16];
+        gen_z16<DT>(((v >> 7) << 6) + (v & 63), k0, k1, z);
+        return z[(((v >> 6) & 1) << 3) + (e & 7)];
+    }
 }
 
 // one reference K1 application: three roundings (P:486)
@@ -99,7 +149,8 @@ static __device__ __forceinline__ float k1_step(float w, float z, float sf, floa
 // sf in {1,-2} and needs no rounding; u(+1) is shared by the first and third step.
 //   bf16: every rounding is one v_cvt_pk_bf16_f32 whose packed result is stored as is, and
 //         u(-2) = -2*u(+1) exactly (power-of-two scaling commutes with rounding: bf16 has the
-//         fp32 exponent range and |z*eps| > 1e-15 never reaches its subnormals).
+//         fp32 exponent range and |z*eps| > 1e-15 never reaches its subnormals), so
+//         theta- = rd(fma(u, -2, theta+)): the product is exact, one rounding, as torch's add.
 //   fp16: the three adds are v_pk_add_f16 on packed pairs — for two f16 operands one f16
 //         rounding equals torch's fp32-then-f16 rounding (24 >= 2*11+2 bits); z*eps and
 //         -2z*eps go through fp32 and an explicit convert each, because eps is not an f16
@@ -119,7 +170,8 @@ static __device__ __forceinline__ void unit_update(u32x4& st, const float* z, fl
             float ua, ub, pa, pb, ma, mb, ra, rb;
             Vec<DT>::round_pair(z[2 * i] * eps, z[2 * i + 1] * eps, ua, ub);
             plus[i] = Vec<DT>::round_pair(a0 + ua, a1 + ub, pa, pb);
-            minus[i] = Vec<DT>::round_pair(pa + ua * -2.0f, pb + ub * -2.0f, ma, mb);
+            minus[i] = Vec<DT>::round_pair(__builtin_fmaf(ua, -2.0f, pa), __builtin_fmaf(ub, -2.0f, pb),
+                                           ma, mb);
             st[i] = Vec<DT>::round_pair(ma + ua, mb + ub, ra, rb);
         }
     } else if constexpr (FAST && DT == ECOFLAP_F16) {
@@ -152,26 +204,69 @@ static __device__ __forceinline__ void unit_update(u32x4& st, const float* z, fl
 }
 
 // ---------------------------------------------------------------- kernels
+// Lane geometry shared by all of them: wave `R` (grid-stride over super-rows) owns vectors
+// [128R, 128R + 128); lane l owns v0 = 128R + l and v1 = v0 + 64 (either may lie past the end).
+struct LaneVecs {
+    int64_t v0, v1;
+    bool ok0, ok1;
+};
+static __device__ __forceinline__ LaneVecs lane_vecs(int64_t R, int64_t nvec) {
+    LaneVecs L;
+    L.v0 = (R << 7) + (threadIdx.x & 63);
+    L.v1 = L.v0 + ECO_ROW;
+    L.ok0 = L.v0 < nvec;
+    L.ok1 = L.v1 < nvec;
+    return L;
+}
+// One wave per workgroup, one super-row per wave.  Workgroups are dispatched round-robin over
+// the 8 XCDs (workgroup b runs on XCD b % 8, each with its own L2), so the row index is remapped
+// for every XCD to walk ONE contiguous eighth of the matrix: the 2*U+1 write streams of a pass
+// then reach HBM as 8 sequential fronts per stream instead of a 2-KiB interleave of all XCDs
+// (memory-only twin of the kernel, tools/micro/k1_stores.hip: 63-69 % -> 68-73 % of 8 TB/s).
+#define ECO_XCDS 8
+#define ECO_K1_THREADS 64
+#define ECO_FOR_SUPER_ROWS(R, nvec)                                                          \
+    for (int64_t nrows__ = ((nvec) + 127) >> 7, per__ = (int64_t)(gridDim.x / ECO_XCDS),      \
+                 R = (int64_t)(blockIdx.x % ECO_XCDS) * per__ + blockIdx.x / ECO_XCDS,        \
+                 once__ = 0;                                                                  \
+         once__ == 0 && R < nrows__; ++once__)
+
+static __device__ __forceinline__ u32x4 ld16_if(bool ok, const void* p, int64_t v) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (ok) r = ld16(p, v);
+    return r;
+}
+
+// z of the lane's two vectors from memory (parity mode)
+template <int DT>
+static __device__ __forceinline__ void load_z_lane(const void* zin, const LaneVecs& L, float* z) {
+    constexpr int N = Vec<DT>::N;
+    Vec<DT>::unpack(ld16_if(L.ok0, zin, L.v0), z);
+    Vec<DT>::unpack(ld16_if(L.ok1, zin, L.v1), z + N);
+}
+
 template <int DT, bool HAS_Z>
-__global__ __launch_bounds__(256) void zo_perturb_kernel(void* __restrict__ w,
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_kernel(void* __restrict__ w,
                                                          const void* __restrict__ zin,
                                                          int64_t n, float sf, float eps,
                                                          uint32_t k0, uint32_t k1) {
     constexpr int N = Vec<DT>::N;
     const int64_t nvec = n / N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        float wf[N], z[N];
-        const u32x4 wv = ld16(w, v);
+    ECO_FOR_SUPER_ROWS(R, nvec) {
+        const LaneVecs L = lane_vecs(R, nvec);
+        float wf[2 * N], z[2 * N];
+        const u32x4 w0 = ld16_if(L.ok0, w, L.v0), w1 = ld16_if(L.ok1, w, L.v1);
         if (HAS_Z) {
-            Vec<DT>::unpack(ld16(zin, v), z);
+            load_z_lane<DT>(zin, L, z);
         } else {
-            gen_z<DT>(v, k0, k1, z);
+            gen_z_lane<DT>(L.v0, k0, k1, z);
         }
-        Vec<DT>::unpack(wv, wf);
+        Vec<DT>::unpack(w0, wf);
+        Vec<DT>::unpack(w1, wf + N);
 #pragma unroll
-        for (int i = 0; i < N; ++i) wf[i] = k1_step<DT>(wf[i], z[i], sf, eps);
-        st16(w, v, Vec<DT>::pack(wf));
+        for (int i = 0; i < 2 * N; ++i) wf[i] = k1_step<DT>(wf[i], z[i], sf, eps);
+        if (L.ok0) st16(w, L.v0, Vec<DT>::pack(wf));
+        if (L.ok1) st16(w, L.v1, Vec<DT>::pack(wf + N));
     }
     // ragged tail (< N elements), one lane each
     const int64_t tail0 = nvec * N;
@@ -185,27 +280,37 @@ __global__ __launch_bounds__(256) void zo_perturb_kernel(void* __restrict__ w,
 // WRITE_PM = false: drift-only form (theta+ / theta- are not stored), used by ranks that do
 // not own the batch but must keep their replica's weights identical (SURVEY.md §8e iii).
 template <int DT, bool HAS_Z, bool WRITE_PM>
-__global__ __launch_bounds__(256) void zo_perturb_triple_kernel(
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_triple_kernel(
     const void* win, void* wplus, void* wminus, void* wrest,  // wplus may alias win
     const void* __restrict__ zin, int64_t n, float eps, uint32_t k0, uint32_t k1) {
     constexpr int N = Vec<DT>::N;
     const int64_t nvec = n / N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        float z[N];
-        u32x4 st = ld16(win, v);
+    ECO_FOR_SUPER_ROWS(R, nvec) {
+        const LaneVecs L = lane_vecs(R, nvec);
+        float z[2 * N];
+        u32x4 s0 = ld16_if(L.ok0, win, L.v0), s1 = ld16_if(L.ok1, win, L.v1);
         if (HAS_Z) {
-            Vec<DT>::unpack(ld16(zin, v), z);
+            load_z_lane<DT>(zin, L, z);
         } else {
-            gen_z<DT>(v, k0, k1, z);
+            gen_z_lane<DT>(L.v0, k0, k1, z);
         }
-        u32x4 pp, mm;
-        unit_update<DT, !HAS_Z>(st, z, eps, pp, mm);
-        if (WRITE_PM) {
-            st16(wplus, v, pp);
-            st16(wminus, v, mm);
+        u32x4 p0, m0, p1, m1;
+        unit_update<DT, !HAS_Z>(s0, z, eps, p0, m0);
+        unit_update<DT, !HAS_Z>(s1, z + N, eps, p1, m1);
+        if (L.ok0) {
+            if (WRITE_PM) {
+                st16(wplus, L.v0, p0);
+                st16(wminus, L.v0, m0);
+            }
+            st16(wrest, L.v0, s0);
         }
-        st16(wrest, v, st);
+        if (L.ok1) {
+            if (WRITE_PM) {
+                st16(wplus, L.v1, p1);
+                st16(wminus, L.v1, m1);
+            }
+            st16(wrest, L.v1, s1);
+        }
     }
     const int64_t tail0 = nvec * N;
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - tail0)) {
@@ -242,30 +347,39 @@ static __device__ __forceinline__ void st16_nt(void* p, int64_t vec_index, const
 }
 
 template <int DT, bool HAS_Z>
-__global__ __launch_bounds__(256) void zo_perturb_units_kernel(void* __restrict__ w, int64_t n,
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_units_kernel(void* __restrict__ w, int64_t n,
                                                                float eps, int n_units,
                                                                const UnitTable tab) {
     constexpr int N = Vec<DT>::N;
     const int64_t nvec = n / N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        u32x4 st = ld16(w, v);
+    ECO_FOR_SUPER_ROWS(R, nvec) {
+        const LaneVecs L = lane_vecs(R, nvec);
+        u32x4 s0 = ld16_if(L.ok0, w, L.v0), s1 = ld16_if(L.ok1, w, L.v1);
         for (int u = 0; u < n_units; ++u) {
-            float z[N];
+            float z[2 * N];
             if (HAS_Z) {
-                Vec<DT>::unpack(ld16(tab.z[u], v), z);
+                load_z_lane<DT>(tab.z[u], L, z);
             } else {
-                gen_z<DT>(v, (uint32_t)tab.seed[u], (uint32_t)(tab.seed[u] >> 32), z);
+                gen_z_lane<DT>(L.v0, (uint32_t)tab.seed[u], (uint32_t)(tab.seed[u] >> 32), z);
             }
-            u32x4 pp, mm;
-            unit_update<DT, !HAS_Z>(st, z, eps, pp, mm);
-            void* dst = tab.plus[u];
-            if (dst) {   // wave-uniform: not-owned units only carry the drift
-                st16_nt(dst, v, pp);
-                st16_nt(tab.minus[u], v, mm);
+            u32x4 p0, m0, p1, m1;
+            unit_update<DT, !HAS_Z>(s0, z, eps, p0, m0);
+            unit_update<DT, !HAS_Z>(s1, z + N, eps, p1, m1);
+            void* dp = tab.plus[u];
+            if (dp) {   // wave-uniform: not-owned units only carry the drift
+                void* dm = tab.minus[u];
+                if (L.ok0) {
+                    st16_nt(dp, L.v0, p0);
+                    st16_nt(dm, L.v0, m0);
+                }
+                if (L.ok1) {
+                    st16_nt(dp, L.v1, p1);
+                    st16_nt(dm, L.v1, m1);
+                }
             }
         }
-        st16(w, v, st);
+        if (L.ok0) st16(w, L.v0, s0);
+        if (L.ok1) st16(w, L.v1, s1);
     }
     const int64_t tail0 = nvec * N;
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - tail0)) {
@@ -287,15 +401,16 @@ __global__ __launch_bounds__(256) void zo_perturb_units_kernel(void* __restrict_
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void zo_fill_normal_kernel(void* __restrict__ zout, int64_t n,
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_fill_normal_kernel(void* __restrict__ zout, int64_t n,
                                                              uint32_t k0, uint32_t k1) {
     constexpr int N = Vec<DT>::N;
     const int64_t nvec = n / N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        float z[N];
-        gen_z<DT>(v, k0, k1, z);
-        st16(zout, v, Vec<DT>::pack(z));
+    ECO_FOR_SUPER_ROWS(R, nvec) {
+        const LaneVecs L = lane_vecs(R, nvec);
+        float z[2 * N];
+        gen_z_lane<DT>(L.v0, k0, k1, z);
+        if (L.ok0) st16(zout, L.v0, Vec<DT>::pack(z));
+        if (L.ok1) st16(zout, L.v1, Vec<DT>::pack(z + N));
     }
     const int64_t tail0 = nvec * N;
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - tail0)) {
@@ -317,14 +432,15 @@ __global__ __launch_bounds__(256) void philox_u32_kernel(uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- launch helpers
-// one 16-byte vector per lane (measured fastest on MI355X for 8-85 MB of traffic), grid-stride
-// only beyond 65536 workgroups
+// one single-wave workgroup per super-row of 128 vectors (two 16-byte vectors per lane),
+// rounded up to a multiple of the XCD count for the remap in ECO_FOR_SUPER_ROWS
 static inline unsigned grid_exact(int64_t nvec) {
-    int64_t b = (nvec + 255) / 256;
+    int64_t b = (nvec + 127) / 128;
     if (b < 1) b = 1;
-    if (b > 65536) b = 65536;
+    b = (b + ECO_XCDS - 1) / ECO_XCDS * ECO_XCDS;
     return (unsigned)b;
 }
+#define ECO_K1_MAX_ELEMS ((int64_t)1 << 40)   /* 2^31 workgroups of 128 16-byte vectors */
 
 
 // Memory-bound grid: enough 256-thread blocks to keep every CU's queues full
@@ -347,7 +463,7 @@ static inline unsigned grid_for(int64_t nvec) {
 extern "C" int ecoflap_zo_perturb(void* w, int64_t n, int dtype, float scaling_factor,
                                   float zo_eps, uint64_t seed, const void* z, void* stream) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    if (n < 0) return ECOFLAP_ESIZE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS) return ECOFLAP_ESIZE;
     if (n == 0) return 0;
     if (!w) return ECOFLAP_ENULL;
     if (!aligned16(w) || (z && !aligned16(z))) return ECOFLAP_EALIGN;
@@ -356,10 +472,10 @@ extern "C" int ecoflap_zo_perturb(void* w, int64_t n, int dtype, float scaling_f
     DISPATCH_DT(dtype, {
         const unsigned g = grid_exact(n / Vec<DT>::N);
         if (z)
-            hipLaunchKernelGGL((zo_perturb_kernel<DT, true>), dim3(g), dim3(256), 0, s, w, z, n,
+            hipLaunchKernelGGL((zo_perturb_kernel<DT, true>), dim3(g), dim3(ECO_K1_THREADS), 0, s, w, z, n,
                                scaling_factor, zo_eps, k0, k1);
         else
-            hipLaunchKernelGGL((zo_perturb_kernel<DT, false>), dim3(g), dim3(256), 0, s, w, z, n,
+            hipLaunchKernelGGL((zo_perturb_kernel<DT, false>), dim3(g), dim3(ECO_K1_THREADS), 0, s, w, z, n,
                                scaling_factor, zo_eps, k0, k1);
     });
     ECO_CHECK_LAUNCH();
@@ -367,14 +483,14 @@ extern "C" int ecoflap_zo_perturb(void* w, int64_t n, int dtype, float scaling_f
 }
 
 #define TRIPLE(HZ, PM)                                                                          \
-    hipLaunchKernelGGL((zo_perturb_triple_kernel<DT, HZ, PM>), dim3(g), dim3(256), 0, s, w_in, \
+    hipLaunchKernelGGL((zo_perturb_triple_kernel<DT, HZ, PM>), dim3(g), dim3(ECO_K1_THREADS), 0, s, w_in, \
                        w_plus, w_minus, w_restored, z, n, zo_eps, k0, k1)
 
 extern "C" int ecoflap_zo_perturb_triple(const void* w_in, void* w_plus, void* w_minus,
                                          void* w_restored, int64_t n, int dtype, float zo_eps,
                                          uint64_t seed, const void* z, void* stream) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    if (n < 0) return ECOFLAP_ESIZE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS) return ECOFLAP_ESIZE;
     if (n == 0) return 0;
     if (!w_in || !w_restored) return ECOFLAP_ENULL;
     const bool write_pm = (w_plus != nullptr) || (w_minus != nullptr);
@@ -397,12 +513,12 @@ extern "C" int ecoflap_zo_perturb_triple(const void* w_in, void* w_plus, void* w
     return 0;
 }
 
-extern "C" int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_eps, int n_units,
-                                        const uint64_t* seeds, void* const* w_plus,
-                                        void* const* w_minus, const void* const* z,
-                                        void* stream) {
+static int zo_perturb_units_impl(void* w, int64_t n, int dtype, float zo_eps, int n_units,
+                                 const uint64_t* seeds, void* const* w_plus,
+                                 void* const* w_minus, const void* const* z, void* stream,
+                                 hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    if (n < 0 || n_units < 0 || n_units > ECOFLAP_MAX_UNITS) return ECOFLAP_ESIZE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS || n_units < 0 || n_units > ECOFLAP_MAX_UNITS) return ECOFLAP_ESIZE;
     if (n == 0 || n_units == 0) return 0;
     if (!w || !seeds || !w_plus || !w_minus) return ECOFLAP_ENULL;
     if (!aligned16(w)) return ECOFLAP_EALIGN;
@@ -428,28 +544,49 @@ extern "C" int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DT(dtype, {
         const unsigned g = grid_exact(n / Vec<DT>::N);
+        // hipExtLaunchKernelGGL with null events is a plain launch; with events they take the
+        // kernel's own begin / end timestamps (the dispatch's completion signal — what rocprofv3
+        // reads), not the time markers queued around it take to be processed
         if (z)
-            hipLaunchKernelGGL((zo_perturb_units_kernel<DT, true>), dim3(g), dim3(256), 0, s, w, n,
-                               zo_eps, n_units, tab);
+            hipExtLaunchKernelGGL((zo_perturb_units_kernel<DT, true>), dim3(g), dim3(ECO_K1_THREADS), 0, s,
+                                  ev_start, ev_stop, 0, w, n, zo_eps, n_units, tab);
         else
-            hipLaunchKernelGGL((zo_perturb_units_kernel<DT, false>), dim3(g), dim3(256), 0, s, w, n,
-                               zo_eps, n_units, tab);
+            hipExtLaunchKernelGGL((zo_perturb_units_kernel<DT, false>), dim3(g), dim3(ECO_K1_THREADS), 0, s,
+                                  ev_start, ev_stop, 0, w, n, zo_eps, n_units, tab);
     });
     ECO_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_eps, int n_units,
+                                        const uint64_t* seeds, void* const* w_plus,
+                                        void* const* w_minus, const void* const* z,
+                                        void* stream) {
+    return zo_perturb_units_impl(w, n, dtype, zo_eps, n_units, seeds, w_plus, w_minus, z, stream,
+                                 nullptr, nullptr);
+}
+
+extern "C" int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, float zo_eps,
+                                              int n_units, const uint64_t* seeds,
+                                              void* const* w_plus, void* const* w_minus,
+                                              const void* const* z, void* stream,
+                                              void* start_event, void* stop_event) {
+    if (!start_event || !stop_event) return ECOFLAP_ENULL;
+    return zo_perturb_units_impl(w, n, dtype, zo_eps, n_units, seeds, w_plus, w_minus, z, stream,
+                                 (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
 extern "C" int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,
                                       void* stream) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    if (n < 0) return ECOFLAP_ESIZE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS) return ECOFLAP_ESIZE;
     if (n == 0) return 0;
     if (!z_out) return ECOFLAP_ENULL;
     if (!aligned16(z_out)) return ECOFLAP_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     DISPATCH_DT(dtype, {
-        hipLaunchKernelGGL((zo_fill_normal_kernel<DT>), dim3(grid_for(n / Vec<DT>::N)), dim3(256),
+        hipLaunchKernelGGL((zo_fill_normal_kernel<DT>), dim3(grid_exact(n / Vec<DT>::N)), dim3(ECO_K1_THREADS),
                            0, s, z_out, n, k0, k1);
     });
     ECO_CHECK_LAUNCH();

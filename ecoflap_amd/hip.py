@@ -20,7 +20,7 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
-    "ecoflap_zo_perturb_units", "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
+    "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
@@ -57,6 +57,7 @@ def load_library():
     lib.ecoflap_zo_perturb.argtypes = [vp, i64, ci, f32, f32, u64, vp, vp]
     lib.ecoflap_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, u64, vp, vp]
     lib.ecoflap_zo_perturb_units.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp]
+    lib.ecoflap_zo_perturb_units_timed.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
@@ -161,10 +162,11 @@ class HipKernels:
 
     MAX_UNITS = 32
 
-    def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None):
+    def zo_perturb_units(self, w, zo_eps, seeds, w_plus, w_minus, z=None, events=None):
         """All units of one layer in one launch (chunks of MAX_UNITS); w is updated in place
         to the final drifted weights, unit u's theta+/theta- land in w_plus[u]/w_minus[u]
-        (None, None = drift only)."""
+        (None, None = drift only).  events: optional callable -> (start, stop) raw hipEvent_t
+        handles per launch (ecoflap_zo_perturb_units_timed; bench.py's roofline leg)."""
         _gpu(w, "w")
         n_units = len(seeds)
         assert len(w_plus) == n_units and len(w_minus) == n_units
@@ -184,6 +186,12 @@ class HipKernels:
             z_a = None
             if z is not None:
                 z_a = (ctypes.c_void_p * m)(*[t.data_ptr() for t in z[c0:c1]])
+            if events is not None:
+                ev_start, ev_stop = events()
+                _check(self.lib.ecoflap_zo_perturb_units_timed(
+                    _ptr(w), w.numel(), DTYPE_CODE[w.dtype], float(zo_eps), m, seeds_a, plus_a,
+                    minus_a, z_a, _stream(), ev_start, ev_stop), "ecoflap_zo_perturb_units_timed")
+                continue
             _check(self.lib.ecoflap_zo_perturb_units(
                 _ptr(w), w.numel(), DTYPE_CODE[w.dtype], float(zo_eps), m, seeds_a, plus_a,
                 minus_a, z_a, _stream()), "ecoflap_zo_perturb_units")

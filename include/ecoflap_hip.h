@@ -74,8 +74,11 @@ const char* ecoflap_error_string(int code);
  *     t = rd(z * scaling_factor);  u = rd(t * zo_eps);  w = rd(w + u)
  * z: if `z` != NULL it is a device array of n elements of `dtype` (parity
  * mode: the caller supplies the reference's own torch.normal draw); if NULL,
- * z is generated in registers: Philox4x32-R (R = ECOFLAP_PHILOX_ROUNDS), key = seed, counter = e/4,
- * Box-Muller, rounded to `dtype` — the stream ecoflap_zo_fill_normal writes.
+ * z is generated in registers: Philox4x32-R (R = ECOFLAP_PHILOX_ROUNDS), key = seed, Box-Muller,
+ * rounded to `dtype` — the stream ecoflap_zo_fill_normal writes and
+ * oracle/ecoflap_oracle.c:oracle_normal_stream restates (fp32 storage: one Philox call per 4
+ * elements, 32-bit radius and angle words; fp16 / bf16: three calls per 16 elements, 32-bit
+ * radius word + 16-bit angle per Box-Muller pair; element layout in csrc/zo_perturb.hip).
  * w must be 16-byte aligned (torch allocations are).
  * ------------------------------------------------------------------------- */
 int ecoflap_zo_perturb(void* w, int64_t n, int dtype,
@@ -112,6 +115,16 @@ int ecoflap_zo_perturb_units(void* w, int64_t n, int dtype, float zo_eps,
                              int n_units, const uint64_t* seeds,
                              void* const* w_plus, void* const* w_minus,
                              const void* const* z, void* stream);
+
+/* Same launch, instrumented: start_event / stop_event (hipEvent_t created by the caller with
+ * timing enabled) receive the kernel's own begin / end timestamps (hipExtLaunchKernelGGL), so
+ * hipEventElapsedTime(start, stop) is the kernel duration rocprofv3 reports — no marker
+ * latency, no host gap.  bench.py's roofline leg uses it; the product loop uses the plain form. */
+int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, float zo_eps,
+                                   int n_units, const uint64_t* seeds,
+                                   void* const* w_plus, void* const* w_minus,
+                                   const void* const* z, void* stream,
+                                   void* start_event, void* stop_event);
 
 /* Materialise the in-register z stream of K1 for (seed, n, dtype). */
 int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,

@@ -42,6 +42,7 @@ class Oracle:
         L.oracle_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, vp]
         L.oracle_philox_u32.argtypes = [vp, i64, u64, ci]
         L.oracle_philox4x32.argtypes = [vp, vp, vp, ci]
+        L.oracle_normal_stream.argtypes = [vp, vp, i64, ci, u64, ci]
         L.oracle_absprod_reduce.argtypes = [vp, vp, i64, ci, ci, ci]
         L.oracle_absprod_reduce.restype = ctypes.c_double
         L.oracle_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64]
@@ -67,6 +68,15 @@ class Oracle:
         out = torch.empty(n, dtype=torch.int32)
         self.lib.oracle_philox_u32(_p(out), n, seed, rounds)
         return out
+
+    def normal_stream(self, n, dtype, seed, rounds, want_f32=False):
+        """The in-register z stream of K1 for (seed, n, dtype): tensor of `dtype`, and with
+        want_f32 also the fp32 values before the storage rounding."""
+        z = torch.empty(n, dtype=dtype)
+        z32 = torch.empty(n, dtype=torch.float32) if want_f32 else None
+        self.lib.oracle_normal_stream(_p(z32) if want_f32 else None, _p(z), n, DT[dtype], seed,
+                                      rounds)
+        return (z, z32) if want_f32 else z
 
     def philox4x32(self, ctr, key, rounds):
         import ctypes

@@ -125,6 +125,88 @@ void oracle_philox_u32(uint32_t* out, int64_t n, uint64_t seed, int rounds) {
     }
 }
 
+/* ------------------------------------------------------------------ in-register normal streams
+ * The build's own definition of z ~ N(0,1) "in param.dtype" (the reference draws it with
+ * torch.normal, P:482-485, whose stream is device specific; parity with the reference is taken
+ * with z supplied).  Restated step by step from ecoflap_amd/csrc/zo_perturb.hip:
+ *   radius:  u1 = fma((float)a, 2^-32, 2^-33)  (fp32, exact steps)
+ *            r  = sqrt_f32( -2 ln2 *_f32 log2_f32(u1) )
+ *   angle:   N32: u2 = (float)b *_f32 2^-32 turns;  N16: u2 = h * 2^-16 turns (exact)
+ *   z = r *_f32 cos(2 pi u2),  r *_f32 sin(2 pi u2);  then ONE rounding to the storage dtype.
+ * log2 / sqrt / sin / cos are evaluated in double and rounded once to fp32 (correctly rounded
+ * for all practical purposes); the GPU's v_log / v_sqrt / v_sin / v_cos units are accurate to
+ * a few fp32 ulps, not correctly rounded, so the GPU test compares z32 within a stated
+ * tolerance and the dtype-rounded stream exactly except where z32 sits on a rounding boundary.
+ *   N32 (fp32 storage): element e <- Philox call e/4; words (w0,w1) -> e%4 = 0 (cos), 1 (sin);
+ *        (w2,w3) -> 2, 3.
+ *   N16 (fp16 / bf16):  vector v = e/8; block g = 64*(v/128) + v%64 = vectors (128*(v/128) +
+ *        v%64, that + 64); calls 3g..3g+2 -> W[0..11]; pair j: radius W[j], angle halfword j of
+ *        W[8..11] (low half first); position p = 8*((v/64)%2) + e%8 = 4q + t takes pair
+ *        2q + (t&1), cos for t < 2, sin for t >= 2. */
+static const double TWO_PI = 6.283185307179586476925286766559;
+static float stream_radius(uint32_t a) {
+    const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float lg = (float)log2((double)u1);
+    const float t = -1.3862943611198906f * lg;
+    return (float)sqrt((double)t);
+}
+static void stream_block_words(uint32_t* w, int64_t first_call, int n_calls, uint64_t seed,
+                               int rounds) {
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int c = 0; c < n_calls; ++c) {
+        const uint64_t q = (uint64_t)(first_call + c);
+        const uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
+        oracle_philox4x32(w + 4 * c, ctr, key, rounds);
+    }
+}
+/* z32_out (optional): the fp32 value before the storage rounding; z_out (optional): `dt` */
+void oracle_normal_stream(float* z32_out, void* z_out, int64_t n, int dt, uint64_t seed,
+                          int rounds) {
+    if (dt == DT_F32) {
+        for (int64_t c = 0; 4 * c < n; ++c) {
+            uint32_t w[4];
+            float z[4];
+            stream_block_words(w, c, 1, seed, rounds);
+            for (int j = 0; j < 2; ++j) {
+                const float u2 = (float)w[2 * j + 1] * 2.3283064365386963e-10f;
+                const float r = stream_radius(w[2 * j]);
+                z[2 * j + 0] = r * (float)cos(TWO_PI * (double)u2);
+                z[2 * j + 1] = r * (float)sin(TWO_PI * (double)u2);
+            }
+            for (int i = 0; i < 4 && 4 * c + i < n; ++i) {
+                if (z32_out) z32_out[4 * c + i] = z[i];
+                if (z_out) ((float*)z_out)[4 * c + i] = z[i];
+            }
+        }
+        return;
+    }
+    const int64_t nvec = (n + 7) / 8;                 /* a ragged tail still belongs to its vector */
+    const int64_t nblocks = ((nvec + 127) / 128) * 64;
+    for (int64_t g = 0; g < nblocks; ++g) {
+        uint32_t w[12];
+        float z[16];
+        const int64_t v0 = (g / 64) * 128 + (g % 64);
+        if (v0 >= nvec) continue;
+        stream_block_words(w, 3 * g, 3, seed, rounds);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t ang = w[8 + q];
+            const float ua = (float)(ang & 0xffffu) * 1.52587890625e-05f;
+            const float ub = (float)(ang >> 16) * 1.52587890625e-05f;
+            const float ra = stream_radius(w[2 * q]), rb = stream_radius(w[2 * q + 1]);
+            z[4 * q + 0] = ra * (float)cos(TWO_PI * (double)ua);
+            z[4 * q + 1] = rb * (float)cos(TWO_PI * (double)ub);
+            z[4 * q + 2] = ra * (float)sin(TWO_PI * (double)ua);
+            z[4 * q + 3] = rb * (float)sin(TWO_PI * (double)ub);
+        }
+        for (int p = 0; p < 16; ++p) {
+            const int64_t e = (v0 + (p >= 8 ? 64 : 0)) * 8 + (p & 7);
+            if (e >= n) continue;
+            if (z32_out) z32_out[e] = z[p];
+            if (z_out) store_dt(z_out, e, dt, z[p]);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ K1 (P:473-486)
  * param.data = param.data + scaling_factor * z * zo_eps, three roundings. */
 static inline float k1_step(float w, float z, float sf, float eps, int dt) {

@@ -118,3 +118,35 @@ def test_philox_stream_bit_statistics(oracle):
     y = w2.astype(np.float64) / 2**32 - 0.5
     assert abs(np.corrcoef(x, y)[0, 1]) < 0.02
     assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 0.02
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_normal_stream_restatement_properties(oracle, dt):
+    """oracle_normal_stream (the build's in-register z, restated): prefix-stable in n, N(0,1)
+    moments, independent across seeds, and the documented element layout — the two outputs of a
+    Box-Muller pair satisfy z_cos^2 + z_sin^2 = -2 ln(u1) with u1 from the pair's radius word."""
+    rounds = philox_rounds()
+    n = 1 << 18
+    z, z32 = oracle.normal_stream(n, dt, 42, rounds, want_f32=True)
+    assert torch.equal(z[:1003], oracle.normal_stream(1003, dt, 42, rounds))
+    assert torch.equal(z[:1024 + 11], oracle.normal_stream(1024 + 11, dt, 42, rounds))
+    zd = z32.double()
+    assert abs(zd.mean().item()) < 8e-3 and abs(zd.var().item() - 1) < 1e-2
+    assert abs((zd ** 4).mean().item() - 3) < 8e-2
+    assert abs((zd[:-1] * zd[1:]).mean().item()) < 8e-3
+    other = oracle.normal_stream(n, dt, 43, rounds, want_f32=True)[1].double()
+    assert abs((zd * other).mean().item()) < 8e-3
+    if dt != torch.float32:
+        assert torch.equal(z, z32.to(dt))                       # one rounding to the storage dtype
+    # layout: first Box-Muller pair and its radius word
+    words = oracle.philox_u32(12, 42, rounds).numpy().astype(np.uint32)
+    u1 = np.float32(np.float32(words[0]) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33))
+    r2 = -2.0 * np.log(float(u1))
+    cos_i, sin_i = (0, 1) if dt == torch.float32 else (0, 2)     # N32: (cos, sin); N16: (cosA, cosB, sinA, sinB)
+    assert abs(float(z32[cos_i]) ** 2 + float(z32[sin_i]) ** 2 - r2) < 1e-5 * max(1.0, r2)
+    if dt != torch.float32:
+        ang = (int(words[8]) & 0xffff) / 65536.0                 # 16-bit angle, low half of W[8]
+        assert abs(float(z32[0]) - np.sqrt(r2) * np.cos(2 * np.pi * ang)) < 1e-5
+        # second vector of block 0 is vector 64: elements 512..519 come from pairs 4..7
+        u1b = np.float32(np.float32(words[4]) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33))
+        assert abs(float(z32[512]) ** 2 + float(z32[514]) ** 2 + 2.0 * np.log(float(u1b))) < 1e-4
