@@ -18,19 +18,37 @@
 // =====================================================================================
 // K6  column sum of squares -> running mean
 // =====================================================================================
-// stage 1: partial[chunk][col] = sum over the chunk's rows of x^2 (fp32)
-template <int DT, bool VECTOR>
-__global__ __launch_bounds__(256) void colsq_partial_kernel(const void* __restrict__ x,
-                                                            int64_t tokens, int64_t cols,
-                                                            int rows_per_chunk,
-                                                            float* __restrict__ partial) {
+// ONE launch per hooked input.  Workgroup (column block, row chunk) writes
+// partial[chunk][col] = sum over the chunk's rows of x^2 (fp32); the LAST chunk of a column block
+// to finish (ticket counter in the workspace) sums that block's partials in fixed chunk order —
+// so the result does not depend on which workgroup came last — and applies the reference's
+// update (W:80-84).  Tickets reset themselves: the workspace is zeroed once by its owner.
+// FROM_DEV: the sample count lives in device memory (graph-replayable: no launch argument
+// changes from call to call); the last workgroup of the whole grid then adds `batch` to it.
+struct ColsqArgs {
+    const void* x;
+    int64_t tokens, cols;
+    int rows_per_chunk, nchunks;
+    float* partial;          // [nchunks][cols]
+    unsigned* tickets;       // [gridDim.x + 1], zero between launches
+    float* scaler_row;
+    float decay, n_new;      // host form
+    int64_t* n_dev;          // device form
+    int64_t batch;
+};
+
+template <int DT, bool VECTOR, bool FROM_DEV>
+__global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
     constexpr int N = VECTOR ? Vec<DT>::N : 1;
     __shared__ float lds[4][64 * 8];
+    __shared__ unsigned last;
+    const void* __restrict__ x = a.x;
+    const int64_t tokens = a.tokens, cols = a.cols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cvec = (int64_t)blockIdx.x * 64 + lane;  // column vector handled by this lane
     const int64_t ncvec = cols / N;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-    int64_t r1 = r0 + rows_per_chunk;
+    const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_chunk;
+    int64_t r1 = r0 + a.rows_per_chunk;
     if (r1 > tokens) r1 = tokens;
     float acc[N];
 #pragma unroll
@@ -41,10 +59,10 @@ __global__ __launch_bounds__(256) void colsq_partial_kernel(const void* __restri
         for (; r + 12 < r1; r += 16) {
             float f0[N], f1[N], f2[N], f3[N];
             if (VECTOR) {
-                const u32x4 a = ld16(x, r * ncvec + cvec), b = ld16(x, (r + 4) * ncvec + cvec);
-                const u32x4 c = ld16(x, (r + 8) * ncvec + cvec), d = ld16(x, (r + 12) * ncvec + cvec);
-                Vec<DT>::unpack(a, f0); Vec<DT>::unpack(b, f1);
-                Vec<DT>::unpack(c, f2); Vec<DT>::unpack(d, f3);
+                const u32x4 va = ld16(x, r * ncvec + cvec), vb = ld16(x, (r + 4) * ncvec + cvec);
+                const u32x4 vc = ld16(x, (r + 8) * ncvec + cvec), vd = ld16(x, (r + 12) * ncvec + cvec);
+                Vec<DT>::unpack(va, f0); Vec<DT>::unpack(vb, f1);
+                Vec<DT>::unpack(vc, f2); Vec<DT>::unpack(vd, f3);
             } else {
                 f0[0] = Vec<DT>::load1(x, r * cols + cvec);
                 f1[0] = Vec<DT>::load1(x, (r + 4) * cols + cvec);
@@ -78,46 +96,59 @@ __global__ __launch_bounds__(256) void colsq_partial_kernel(const void* __restri
         for (int i = 0; i < N; ++i) {
             const float s = (lds[0][lane * N + i] + lds[1][lane * N + i]) +
                             (lds[2][lane * N + i] + lds[3][lane * N + i]);
-            partial[(int64_t)blockIdx.y * cols + cvec * N + i] = s;
+            // device-scope (sc1) store: written through this XCD's L2, so the workgroup that
+            // finishes the column block — possibly on another XCD — reads it without anyone
+            // having to write back or invalidate a whole L2 (what a release fence would do)
+            __hip_atomic_store(&a.partial[(int64_t)blockIdx.y * cols + cvec * N + i], s,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- last chunk of this column block finishes the update ------------------------------
+    __builtin_amdgcn_s_waitcnt(0);         // this wave's partial stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0)
+        last = (__hip_atomic_fetch_add(&a.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.nchunks - 1u);
+    __syncthreads();
+    if (!last) return;
+    float decay = a.decay, n_new = a.n_new;
+    if (FROM_DEV) {                        // formed as the host form does (double, then float)
+        const int64_t n0 = a.n_dev[0];
+        decay = (float)((double)n0 / (double)(n0 + a.batch));
+        n_new = (float)(n0 + a.batch);
+    }
+    const int64_t c0 = (int64_t)blockIdx.x * 64 * N;
+    for (int64_t c = c0 + threadIdx.x; c < c0 + 64 * N && c < cols; c += 256) {
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= a.nchunks; k += 8) {     // eight loads in flight, summed in chunk order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)          // device-scope loads: never a stale L2 line
+                t[j] = __hip_atomic_load(&a.partial[(int64_t)(k + j) * cols + c], __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+        }
+        for (; k < a.nchunks; ++k)
+            s += __hip_atomic_load(&a.partial[(int64_t)k * cols + c], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        const float nrm = __builtin_sqrtf(s);  // torch.norm(...): sqrt of the sum of squares
+        const float sq = nrm * nrm;            // ... ** 2
+        const float r = a.scaler_row[c] * decay;  // scaler_row *= n / (n + b)
+        a.scaler_row[c] = r + sq / n_new;         // += ... / nsamples
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&a.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FROM_DEV) {                    // every column block has read n_dev before its ticket
+            if (__hip_atomic_fetch_add(&a.tickets[gridDim.x], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+                __hip_atomic_store(&a.tickets[gridDim.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.n_dev[0] += a.batch;
+            }
         }
     }
 }
-
-// stage 2: fixed-order sum over chunks, then the reference's update (W:80-84)
-__global__ __launch_bounds__(256) void colsq_final_kernel(float* __restrict__ scaler_row,
-                                                          const float* __restrict__ partial,
-                                                          int64_t cols, int nchunks, float decay,
-                                                          float n_new) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
-    const float nrm = __builtin_sqrtf(s);  // torch.norm(...): sqrt of the sum of squares
-    const float sq = nrm * nrm;            // ... ** 2
-    const float r = scaler_row[c] * decay;  // scaler_row *= n / (n + b)
-    scaler_row[c] = r + sq / n_new;         // += ... / nsamples
-}
-
-// the same update with the sample count kept on the device (graph-replayable: nothing in the
-// launch arguments changes from call to call); decay and n are formed as the host form does
-__global__ __launch_bounds__(256) void colsq_final_dev_kernel(float* __restrict__ scaler_row,
-                                                              const float* __restrict__ partial,
-                                                              int64_t cols, int nchunks,
-                                                              const int64_t* __restrict__ n_dev,
-                                                              int64_t batch) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    const int64_t n0 = n_dev[0];
-    const float decay = (float)((double)n0 / (double)(n0 + batch));
-    const float n_new = (float)(n0 + batch);
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
-    const float nrm = __builtin_sqrtf(s);
-    const float sq = nrm * nrm;
-    const float r = scaler_row[c] * decay;
-    scaler_row[c] = r + sq / n_new;
-}
-__global__ void colsq_bump_kernel(int64_t* n_dev, int64_t batch) { n_dev[0] += batch; }
 
 static inline int colsq_rows_per_chunk(int64_t tokens, int64_t cols) {
     // ~512 workgroups over the 256 CUs, at least 64 rows (16 per wave) per workgroup so every
@@ -133,10 +164,14 @@ static inline int colsq_nchunks(int64_t tokens, int64_t cols) {
     const int rpc = colsq_rows_per_chunk(tokens, cols);
     return (int)((tokens + rpc - 1) / rpc);
 }
+// ticket area at the head of the workspace: FIXED size, so that calls with different shapes that
+// share one workspace never see another call's partial sums where they expect zeroed tickets
+#define COLSQ_MAX_COLBLOCKS 4095
+static inline size_t colsq_ticket_bytes(int64_t) { return (COLSQ_MAX_COLBLOCKS + 1) * sizeof(unsigned); }
 
 extern "C" size_t ecoflap_colsqnorm_workspace_bytes(int64_t tokens, int64_t cols) {
     if (tokens <= 0 || cols <= 0) return 0;
-    return (size_t)colsq_nchunks(tokens, cols) * (size_t)cols * sizeof(float);
+    return colsq_ticket_bytes(cols) + (size_t)colsq_nchunks(tokens, cols) * (size_t)cols * sizeof(float);
 }
 
 static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
@@ -168,36 +203,33 @@ static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, in
     if (!scaler_row || !x || !workspace) return ECOFLAP_ENULL;
     if (workspace_bytes < ecoflap_colsqnorm_workspace_bytes(tokens, cols)) return ECOFLAP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int rpc = colsq_rows_per_chunk(tokens, cols);
-    const int nchunks = colsq_nchunks(tokens, cols);
     const int nvec = dtype == ECOFLAP_F32 ? 4 : 8;
     const bool vector = (cols % nvec == 0) && aligned16(x);
     const int64_t ncv = vector ? cols / nvec : cols;
-    const dim3 grid((unsigned)((ncv + 63) / 64), (unsigned)nchunks);
-    float* partial = (float*)workspace;
-#define COLSQ(DT_)                                                                              \
-    if (vector)                                                                                 \
-        hipLaunchKernelGGL((colsq_partial_kernel<DT_, true>), grid, dim3(256), 0, s, x, tokens, \
-                           cols, rpc, partial);                                                 \
-    else                                                                                        \
-        hipLaunchKernelGGL((colsq_partial_kernel<DT_, false>), grid, dim3(256), 0, s, x, tokens, \
-                           cols, rpc, partial);
-    if (dtype == ECOFLAP_F32) { COLSQ(ECOFLAP_F32) }
-    else if (dtype == ECOFLAP_F16) { COLSQ(ECOFLAP_F16) }
-    else { COLSQ(ECOFLAP_BF16) }
+    if ((ncv + 63) / 64 > COLSQ_MAX_COLBLOCKS) return ECOFLAP_ESIZE;
+    ColsqArgs a;
+    a.x = x; a.tokens = tokens; a.cols = cols;
+    a.rows_per_chunk = colsq_rows_per_chunk(tokens, cols);
+    a.nchunks = colsq_nchunks(tokens, cols);
+    a.tickets = (unsigned*)workspace;
+    a.partial = (float*)((char*)workspace + colsq_ticket_bytes(cols));
+    a.scaler_row = scaler_row;
+    a.decay = (float)((double)nsamples_before / (double)(nsamples_before + batch));
+    a.n_new = (float)(nsamples_before + batch);
+    a.n_dev = nsamples_dev;
+    a.batch = batch;
+    const dim3 grid((unsigned)((ncv + 63) / 64), (unsigned)a.nchunks);
+#define COLSQ(DT_)                                                                                \
+    do {                                                                                          \
+        if (vector && nsamples_dev) hipLaunchKernelGGL((colsq_kernel<DT_, true, true>), grid, dim3(256), 0, s, a);   \
+        else if (vector) hipLaunchKernelGGL((colsq_kernel<DT_, true, false>), grid, dim3(256), 0, s, a);            \
+        else if (nsamples_dev) hipLaunchKernelGGL((colsq_kernel<DT_, false, true>), grid, dim3(256), 0, s, a);      \
+        else hipLaunchKernelGGL((colsq_kernel<DT_, false, false>), grid, dim3(256), 0, s, a);                       \
+    } while (0)
+    if (dtype == ECOFLAP_F32) COLSQ(ECOFLAP_F32);
+    else if (dtype == ECOFLAP_F16) COLSQ(ECOFLAP_F16);
+    else COLSQ(ECOFLAP_BF16);
 #undef COLSQ
-    ECO_CHECK_LAUNCH();
-    if (nsamples_dev) {
-        hipLaunchKernelGGL(colsq_final_dev_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
-                           s, scaler_row, partial, cols, nchunks, nsamples_dev, batch);
-        hipLaunchKernelGGL(colsq_bump_kernel, dim3(1), dim3(1), 0, s, nsamples_dev, batch);
-        ECO_CHECK_LAUNCH();
-        return 0;
-    }
-    const float decay = (float)((double)nsamples_before / (double)(nsamples_before + batch));
-    const float n_new = (float)(nsamples_before + batch);
-    hipLaunchKernelGGL(colsq_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
-                       scaler_row, partial, cols, nchunks, decay, n_new);
     ECO_CHECK_LAUNCH();
     return 0;
 }
@@ -205,10 +237,29 @@ static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, in
 // =====================================================================================
 // K7 common: sqrt(scaler_row) once per matrix (correctly rounded, = torch.sqrt)
 // =====================================================================================
-__global__ __launch_bounds__(256) void sqrt_cols_kernel(const float* __restrict__ scaler_row,
-                                                        float* __restrict__ sq, int64_t cols) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c < cols) sq[c] = __builtin_sqrtf(scaler_row[c]);
+// Block-level launches: every K7 kernel below serves up to ECOFLAP_WANDA_MAX_ITEMS matrices (all
+// the Linears of one transformer block) from ONE launch; the item of a workgroup / wave is found
+// from a prefix table in the kernel arguments (wave-uniform scalar search).
+#define WMAX ECOFLAP_WANDA_MAX_ITEMS
+
+template <typename G>
+static __device__ __forceinline__ int group_item(const G& g, int64_t idx) {
+    int it = 0;
+    while (it + 1 < g.n && idx >= g.start[it + 1]) ++it;
+    return it;
+}
+
+struct SqrtGroup {
+    int n;
+    int32_t start[WMAX + 1];      // workgroup prefix (256 columns each)
+    const float* src[WMAX];
+    float* dst[WMAX];
+    int64_t cols[WMAX];
+};
+__global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
+    const int it = group_item(g, blockIdx.x);
+    const int64_t c = (int64_t)(blockIdx.x - g.start[it]) * 256 + threadIdx.x;
+    if (c < g.cols[it]) g.dst[it][c] = __builtin_sqrtf(g.src[it][c]);
 }
 
 template <int DT>
@@ -322,17 +373,29 @@ static __device__ __forceinline__ uint32_t block_count_256(uint32_t v, uint32_t*
     return buf[0] + buf[1] + buf[2] + buf[3];
 }
 
+struct RowsGroup {
+    int n;
+    int32_t start[WMAX + 1];      // row prefix over the group's matrices
+    void* w[WMAX];
+    const float* sq[WMAX];
+    int64_t cols[WMAX];
+    int64_t k[WMAX];
+    uint8_t* mask[WMAX];
+};
+
 template <int DT, int NV>
-__global__ __launch_bounds__(256) void wanda_rows_reg_kernel(void* w, const float* __restrict__ sq,
-                                                             int64_t cols, int64_t k,
-                                                             uint8_t* mask_out) {
+__global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) {
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t lds8[8];
     __shared__ uint32_t wave4[4];
     const int tid = threadIdx.x;
-    const int64_t row = blockIdx.x;
+    const int it = group_item(g, blockIdx.x);
+    const int64_t row = blockIdx.x - g.start[it];
+    const int64_t cols = g.cols[it], k = g.k[it];
+    const float* __restrict__ sq = g.sq[it];
+    uint8_t* mask_out = g.mask[it];
     const int64_t nvec = cols / N;
-    void* wrow = (char*)w + row * cols * Vec<DT>::BYTES;
+    void* wrow = (char*)g.w[it] + row * cols * Vec<DT>::BYTES;
     u32x4 wv[NV];
     uint32_t m[NV][N];
 #pragma unroll
@@ -428,15 +491,18 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(void* w, const floa
 // scalar unit — the bitwise search needs no shuffle, no LDS and no barrier at all.
 // -------------------------------------------------------------------------------------
 template <int DT, int NV>
-__global__ __launch_bounds__(256) void wanda_rows_wave_kernel(void* w, const float* __restrict__ sq,
-                                                              int64_t rows, int64_t cols, int64_t k,
-                                                              uint8_t* mask_out) {
+__global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g) {
     constexpr int N = Vec<DT>::N;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;                   // whole wave leaves together
+    const int64_t grow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grow >= g.start[g.n]) return;          // whole wave leaves together
+    const int it = group_item(g, grow);
+    const int64_t row = grow - g.start[it];
+    const int64_t cols = g.cols[it], k = g.k[it];
+    const float* __restrict__ sq = g.sq[it];
+    uint8_t* mask_out = g.mask[it];
     const int64_t nvec = cols / N;
-    void* wrow = (char*)w + row * cols * Vec<DT>::BYTES;
+    void* wrow = (char*)g.w[it] + row * cols * Vec<DT>::BYTES;
     u32x4 wv[NV];
     uint32_t m[NV][N];
 #pragma unroll
@@ -461,8 +527,26 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(void* w, const flo
     const bool all = (k >= cols);
     uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
     if (!all) {
+        // k-th smallest (1-indexed) = largest T with #(m < T) < k, found bit by bit.  Two things
+        // keep the search short: it starts at the highest bit set anywhere in the row, and after
+        // the top 16 bits are fixed only the elements that share them (typically ~1 % of a row:
+        // sign + exponent + 7 mantissa bits) can still change a count — they are compacted to
+        // at most two per lane, and the 16 low rounds then cost 2 compares instead of N*NV.
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (lane + 64 * j < nvec) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) mx = m[j][i] > mx ? m[j][i] : mx;
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        const int top = mx ? 31 - __builtin_clz(mx) : -1;
         uint32_t prefix = 0;
-        for (int bit = 31; bit >= 0; --bit) {
+        for (int bit = top; bit >= 16; --bit) {
             const uint32_t cand = prefix | (1u << bit);
             uint32_t c = 0;
 #pragma unroll
@@ -471,16 +555,75 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(void* w, const flo
                 for (int i = 0; i < N; ++i) c += (uint32_t)__popcll(__ballot(m[j][i] < cand));
             if (c < (uint32_t)k) prefix = cand;
         }
-        T = prefix;
-        uint32_t less = 0;
+        // elements below the 16-bit bucket of the answer, and the bucket's population
+        uint32_t less16 = 0, ncand = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                less += (uint32_t)__popcll(__ballot(m[j][i] < T));
-                total_equal += (uint32_t)__popcll(__ballot(m[j][i] == T));
+                less16 += (uint32_t)__popcll(__ballot(m[j][i] < prefix));
+                ncand += (uint32_t)__popcll(__ballot((m[j][i] ^ prefix) < 0x10000u));
             }
-        take_equal = (uint32_t)k - less;
+        constexpr uint32_t CMAX = 2;                 // candidates per lane
+        __shared__ uint32_t cand_lds[4][64 * CMAX];
+        if (ncand <= 64 * CMAX) {                    // wave-uniform
+            uint32_t* mine = cand_lds[threadIdx.x >> 6];
+            uint32_t pos = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const bool hit = (m[j][i] ^ prefix) < 0x10000u;
+                    const uint64_t mask = __ballot(hit);
+                    if (hit) mine[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = m[j][i];
+                    pos += (uint32_t)__popcll(mask);
+                }
+            // (same wave wrote and reads: program order, no barrier needed on one SIMD)
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): LDS writes done
+            uint32_t cr[CMAX];
+            bool cv[CMAX];
+#pragma unroll
+            for (uint32_t c = 0; c < CMAX; ++c) {
+                cv[c] = lane + 64 * c < ncand;
+                cr[c] = cv[c] ? mine[lane + 64 * c] : 0u;
+            }
+            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                uint32_t c = less16;
+#pragma unroll
+                for (uint32_t q = 0; q < CMAX; ++q) c += (uint32_t)__popcll(__ballot(cv[q] && cr[q] < cand));
+                if (c < (uint32_t)k) prefix = cand;
+            }
+            T = prefix;
+            uint32_t less = less16;
+#pragma unroll
+            for (uint32_t q = 0; q < CMAX; ++q) {
+                less += (uint32_t)__popcll(__ballot(cv[q] && cr[q] < T));
+                total_equal += (uint32_t)__popcll(__ballot(cv[q] && cr[q] == T));
+            }
+            take_equal = (uint32_t)k - less;
+        } else {                                     // crowded bucket (few distinct values): all elements
+            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) c += (uint32_t)__popcll(__ballot(m[j][i] < cand));
+                if (c < (uint32_t)k) prefix = cand;
+            }
+            T = prefix;
+            uint32_t less = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    less += (uint32_t)__popcll(__ballot(m[j][i] < T));
+                    total_equal += (uint32_t)__popcll(__ballot(m[j][i] == T));
+                }
+            take_equal = (uint32_t)k - less;
+        }
     }
     const bool ordered = !all && (take_equal < total_equal);
     uint32_t running = 0;
@@ -525,48 +668,41 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(void* w, const flo
     }
 }
 
-template <int DT>
-static int launch_rows_wave(void* w, const float* sq, int64_t rows, int64_t cols, int64_t k,
-                            uint8_t* mask_out, hipStream_t s) {
-    constexpr int N = Vec<DT>::N;
-    const int64_t nvec = cols / N;
+static inline int rows_wave_class(int64_t nvec) {       // vectors per lane, one wave per row
     const int nv = (int)((nvec + 63) / 64);
-    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
-#define ROWS_WAVE(NV_)                                                                   \
-    hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, NV_>), grid, blk, 0, s, w, sq, rows, cols, k, \
-                       mask_out)
-    if (nv <= 1) ROWS_WAVE(1);
-    else if (nv <= 2) ROWS_WAVE(2);
-    else if (nv <= 4) ROWS_WAVE(4);
-    else if (nv <= 6) ROWS_WAVE(6);
-    else if (nv <= 8) ROWS_WAVE(8);
-    else if (nv <= 10) ROWS_WAVE(10);
-    else if (nv <= 12) ROWS_WAVE(12);
-    else return 1;
-#undef ROWS_WAVE
+    return nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
+}
+static inline int rows_reg_class(int64_t nvec) {        // vectors per thread, one workgroup per row
+    const int nv = (int)((nvec + 255) / 256);
+    static const int classes[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int c : classes)
+        if (nv <= c) return c;
     return 0;
 }
 
 template <int DT>
-static int launch_rows_reg(void* w, const float* sq, int64_t rows, int64_t cols, int64_t k,
-                           uint8_t* mask_out, hipStream_t s) {
-    constexpr int N = Vec<DT>::N;
-    const int64_t nvec = cols / N;
-    const int nv = (int)((nvec + 255) / 256);
-    const dim3 grid((unsigned)rows), blk(256);
-#define ROWS_REG(NV_)                                                                          \
-    hipLaunchKernelGGL((wanda_rows_reg_kernel<DT, NV_>), grid, blk, 0, s, w, sq, cols, k, mask_out)
-    if (nv <= 1) ROWS_REG(1);
-    else if (nv <= 2) ROWS_REG(2);
-    else if (nv <= 3) ROWS_REG(3);
-    else if (nv <= 4) ROWS_REG(4);
-    else if (nv <= 6) ROWS_REG(6);
-    else if (nv <= 8) ROWS_REG(8);
-    else if (nv <= 12) ROWS_REG(12);
-    else if (nv <= 16) ROWS_REG(16);
-    else return 1;
+static void launch_rows_wave(const RowsGroup& g, int nv, hipStream_t s) {
+    const dim3 grid((unsigned)((g.start[g.n] + 3) / 4)), blk(256);
+    if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1>), grid, blk, 0, s, g);
+    else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2>), grid, blk, 0, s, g);
+    else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4>), grid, blk, 0, s, g);
+}
+
+template <int DT>
+static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
+    const dim3 grid((unsigned)g.start[g.n]), blk(256);
+#define ROWS_REG(NV_) hipLaunchKernelGGL((wanda_rows_reg_kernel<DT, NV_>), grid, blk, 0, s, g)
+    switch (nv) {
+        case 1: ROWS_REG(1); break;
+        case 2: ROWS_REG(2); break;
+        case 3: ROWS_REG(3); break;
+        case 4: ROWS_REG(4); break;
+        case 6: ROWS_REG(6); break;
+        case 8: ROWS_REG(8); break;
+        case 12: ROWS_REG(12); break;
+        default: ROWS_REG(16); break;
+    }
 #undef ROWS_REG
-    return 0;
 }
 
 // =====================================================================================
@@ -577,17 +713,64 @@ struct MatrixSelState {
     uint32_t hist[3][2048];
 };
 
+// Matrix mode runs FEW, LARGE workgroups (1024 threads, at most 64 per matrix): every workgroup
+// merges its LDS histogram into the matrix's global one with one atomic per non-empty bin, and
+// those atomics all meet at the memory side — with 1024 workgroups per matrix that merge, not
+// the read of W, was the whole cost of a pass (measured: 74 us for a 50 MB ViT-g block).
+#define WM_THREADS 1024
+#define WM_WAVES (WM_THREADS / 64)
+#define WM_MAX_WGS 64
+#define WM_UNROLL 4
+#define WM_SQ_LDS 16384      // columns whose sqrt table is staged in LDS (64 KiB of the CU's 160)
+
+// sqrt(scaler_row) of the workgroup's matrix into LDS (every vector needs 2 x 16 bytes of it:
+// from global memory those were two dependent cache round trips per vector, most of a pass)
+static __device__ __forceinline__ const float* stage_sq(const float* __restrict__ sq, int64_t cols,
+                                                        float* lds) {
+    if (cols > WM_SQ_LDS) return sq;
+    for (int64_t c = threadIdx.x; c < cols; c += WM_THREADS) lds[c] = sq[c];
+    __syncthreads();
+    return lds;
+}
+static __device__ __forceinline__ u32x4 ld_sq4(const float* sq, int64_t i4) {
+    return *(const u32x4*)(sq + 4 * i4);      // LDS or global, 16-byte aligned either way
+}
+
+// inclusive scan of one value per thread over the 1024-thread block; returns (inclusive, total)
+static __device__ __forceinline__ uint32_t block_scan_wm(uint32_t v, uint32_t* lds_waves,
+                                                         uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();  // protect lds_waves reuse
+    if (lane == 63) lds_waves[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, t = 0;
+#pragma unroll
+    for (int k = 0; k < WM_WAVES; ++k) {
+        const uint32_t wk = lds_waves[k];
+        if (k < wave) base += wk;
+        t += wk;
+    }
+    total = t;
+    return x + base;
+}
+
 // Every workgroup resolves the previous passes itself from the global histograms (8 KB each,
 // L2-resident): bin = first bin whose inclusive count reaches `remaining`.  Identical in every
 // workgroup, so no separate "pick" launch and no inter-workgroup hand-off is needed.
 static __device__ __forceinline__ void pick_bin(const uint32_t* __restrict__ hist, int bins,
-                                                uint32_t remaining, uint32_t* wave4,
+                                                uint32_t remaining, uint32_t* lds_waves,
                                                 uint32_t* out2 /* LDS: bin, new remaining */) {
     uint32_t carry = 0;
-    for (int base = 0; base < bins; base += 256) {
+    for (int base = 0; base < bins; base += WM_THREADS) {
         const uint32_t cnt = hist[base + threadIdx.x];
         uint32_t total;
-        const uint32_t incl = block_scan_256(cnt, wave4, total) + carry;
+        const uint32_t incl = block_scan_wm(cnt, lds_waves, total) + carry;
         const uint32_t excl = incl - cnt;
         if (excl < remaining && remaining <= incl) {
             out2[0] = (uint32_t)(base + threadIdx.x);
@@ -621,96 +804,151 @@ static __device__ __forceinline__ void resolve(const MatrixSelState* st, int upt
     }
 }
 
+struct MatGroup {
+    int n;
+    int32_t start[WMAX + 1];      // workgroup prefix over the group's matrices
+    void* w[WMAX];
+    const float* sq[WMAX];
+    int64_t rows[WMAX];
+    int64_t cols[WMAX];
+    uint32_t rank0[WMAX];
+    MatrixSelState* st[WMAX];
+    uint8_t* mask[WMAX];
+};
+
 template <int DT, int PASS, bool VECTOR>
-__global__ __launch_bounds__(256) void wanda_matrix_hist_kernel(const void* __restrict__ w,
-                                                                const float* __restrict__ sq,
-                                                                int64_t rows, int64_t cols,
-                                                                uint32_t rank0, MatrixSelState* st) {
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const MatGroup g) {
+    const int it = group_item(g, blockIdx.x);
+    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    const void* __restrict__ w = g.w[it];
+    const float* sq = g.sq[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    const uint32_t rank0 = g.rank0[it];
+    MatrixSelState* st = g.st[it];
     constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
     constexpr int BITS = PASS == 2 ? 10 : 11;
     constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t h[2048];
-    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
-    for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) h[i] = 0;
     uint32_t prefix, remaining;
     resolve(st, PASS, rank0, wave4, out2, prefix, remaining);
     __syncthreads();
+    __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
+    if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
     if (VECTOR) {
         const int64_t vpr = cols / N;                 // vectors per row
         const int64_t nvec = rows * vpr;
-        for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-            const int64_t c0 = (v % vpr) * N;
-            float f[N];
-            Vec<DT>::unpack(ld16(w, v), f);
+        // WM_UNROLL independent 16-byte loads in flight per thread (one per stride of the
+        // workgroup set): with a single load per iteration the pass ran at the latency bound
+        const int64_t stride = (int64_t)nb * WM_THREADS;
+        // column of a vector without a 64-bit modulo per vector (that division was most of the
+        // pass's instructions): one 32-bit modulo up front, then add-and-wrap per stride
+        const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
+        uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
+        for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
+            u32x4 wv[WM_UNROLL];
 #pragma unroll
-            for (int q = 0; q < N / 4; ++q) {
-                const u32x4 s4 = ld16(sq, c0 / 4 + q);
+            for (int j = 0; j < WM_UNROLL; ++j)
+                if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
-                    if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+            for (int j = 0; j < WM_UNROLL; ++j) {
+                const int64_t v = v0 + j * stride;
+                const int64_t c0 = (int64_t)cv * N;
+                cv += step32;
+                if (cv >= vpr32) cv -= vpr32;
+                if (v >= nvec) continue;
+                float f[N];
+                Vec<DT>::unpack(wv[j], f);
+#pragma unroll
+                for (int q = 0; q < N / 4; ++q) {
+                    const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+                        if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+                    }
                 }
             }
         }
     } else {
-        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
-            for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        for (int64_t r = lb; r < rows; r += nb)
+            for (int64_t c = threadIdx.x; c < cols; c += WM_THREADS) {
                 const uint32_t b = metric_bits<DT>(w, r * cols + c, sq[c]);
                 if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (1 << BITS); i += 256)
+    for (int i = threadIdx.x; i < (1 << BITS); i += WM_THREADS)
         if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
 }
 
 template <int DT, bool VECTOR>
-__global__ __launch_bounds__(256) void wanda_matrix_apply_kernel(void* w,
-                                                                 const float* __restrict__ sq,
-                                                                 int64_t rows, int64_t cols,
-                                                                 uint32_t rank0,
-                                                                 const MatrixSelState* st,
-                                                                 uint8_t* mask_out) {
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const MatGroup g) {
+    const int it = group_item(g, blockIdx.x);
+    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    void* w = g.w[it];
+    const float* sq = g.sq[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    const uint32_t rank0 = g.rank0[it];
+    const MatrixSelState* st = g.st[it];
+    uint8_t* mask_out = g.mask[it];
     constexpr int N = Vec<DT>::N;
-    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
     uint32_t thres_bits, remaining;
     resolve(st, 3, rank0, wave4, out2, thres_bits, remaining);
     const float thres = __uint_as_float(thres_bits);
+    __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
+    if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
     if (VECTOR) {
         const int64_t vpr = cols / N;
         const int64_t nvec = rows * vpr;
-        for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-            const int64_t c0 = (v % vpr) * N;
-            float f[N];
-            Vec<DT>::unpack(ld16(w, v), f);
-            uint32_t lo = 0, hi = 0;
-            bool any = false;
+        const int64_t stride = (int64_t)nb * WM_THREADS;
+        const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
+        uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
+        for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
+            u32x4 wv[WM_UNROLL];
 #pragma unroll
-            for (int q = 0; q < N / 4; ++q) {
-                const u32x4 s4 = ld16(sq, c0 / 4 + q);
+            for (int j = 0; j < WM_UNROLL; ++j)
+                if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = 4 * q + i;
-                    // W_metric <= thres (W:556): false for NaN metrics, as in torch
-                    const bool prune = (__builtin_fabsf(f[e]) * __uint_as_float(s4[i])) <= thres;
-                    if (prune) { f[e] = 0.0f; any = true; }
-                    if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
-                    else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
+            for (int j = 0; j < WM_UNROLL; ++j) {
+                const int64_t v = v0 + j * stride;
+                const int64_t c0 = (int64_t)cv * N;
+                cv += step32;
+                if (cv >= vpr32) cv -= vpr32;
+                if (v >= nvec) continue;
+                float f[N];
+                Vec<DT>::unpack(wv[j], f);
+                uint32_t lo = 0, hi = 0;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < N / 4; ++q) {
+                    const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * q + i;
+                        // W_metric <= thres (W:556): false for NaN metrics, as in torch
+                        const bool prune = (__builtin_fabsf(f[e]) * __uint_as_float(s4[i])) <= thres;
+                        if (prune) { f[e] = 0.0f; any = true; }
+                        if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
+                        else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
+                    }
                 }
-            }
-            if (any) st16(w, v, Vec<DT>::pack(f));
-            if (mask_out) {
-                uint8_t* m = mask_out + v * N;
-                *(uint32_t*)m = lo;
-                if (N == 8) *(uint32_t*)(m + 4) = hi;
+                if (any) st16(w, v, Vec<DT>::pack(f));
+                if (mask_out) {
+                    uint8_t* m = mask_out + v * N;
+                    *(uint32_t*)m = lo;
+                    if (N == 8) *(uint32_t*)(m + 4) = hi;
+                }
             }
         }
     } else {
-        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
-            for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        for (int64_t r = lb; r < rows; r += nb)
+            for (int64_t c = threadIdx.x; c < cols; c += WM_THREADS) {
                 const int64_t i = r * cols + c;
                 const float mval = __uint_as_float(metric_bits<DT>(w, i, sq[c]));
                 const bool prune = mval <= thres;
@@ -720,107 +958,202 @@ __global__ __launch_bounds__(256) void wanda_matrix_apply_kernel(void* w,
     }
 }
 
+static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
+
 extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
     (void)rows;
     if (cols <= 0) return 0;
     // sqrt table (padded to 256 B) + matrix-mode selection state
-    return (((size_t)cols * sizeof(float) + 255) / 256) * 256 + sizeof(MatrixSelState);
+    return sq_bytes(cols) + sizeof(MatrixSelState);
 }
 
-static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
+extern "C" size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* items, int n_items) {
+    size_t total = 0;
+    if (!items) return 0;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].cols > 0) total += sq_bytes(items[i].cols) + sizeof(MatrixSelState);
+    return total;
+}
+
+static inline bool item_vector_ok(const ecoflap_wanda_item& it, const float* sq) {
+    const int nvec_elems = it.dtype == ECOFLAP_F32 ? 4 : 8;
+    // mask rows are written with 4/8-byte stores: cols % 8 keeps them aligned for 16-bit dtypes
+    return it.cols % nvec_elems == 0 && aligned16(it.w) && aligned16(sq) &&
+           (!it.mask_out || (((uintptr_t)it.mask_out) & 7u) == 0);
+}
+
+#define DT_SWITCH(dt, CALL)                                    \
+    do {                                                       \
+        if ((dt) == ECOFLAP_F32) { CALL(ECOFLAP_F32); }        \
+        else if ((dt) == ECOFLAP_F16) { CALL(ECOFLAP_F16); }   \
+        else { CALL(ECOFLAP_BF16); }                           \
+    } while (0)
+
+// All Linears of one transformer block in one call: one sqrt launch, one selection launch per
+// (dtype, register class) of the rows-mode matrices, 3 histogram launches + 1 apply launch for
+// ALL matrix-mode matrices of a dtype — instead of 2 (rows) / 6 (matrix) launches per matrix.
+// Besides the launch count this is what fills the chip: one T5 matrix has 2048-5120 rows (2-5
+// waves per SIMD for the one-wave-per-row kernel), a T5 block has 18-28 thousand.
+extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_items,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_items < 0 || n_items > WMAX) return ECOFLAP_ESIZE;
+    if (n_items == 0) return 0;
+    if (!items) return ECOFLAP_ENULL;
+    for (int i = 0; i < n_items; ++i) {
+        const ecoflap_wanda_item& it = items[i];
+        if (!dtype_ok(it.dtype)) return ECOFLAP_EDTYPE;
+        if (it.mode != ECOFLAP_WANDA_ROWS && it.mode != ECOFLAP_WANDA_MATRIX) return ECOFLAP_EMODE;
+        if (it.rows <= 0 || it.cols <= 0 || it.k < 0) return ECOFLAP_ESIZE;
+        if (it.mode == ECOFLAP_WANDA_ROWS && it.cols > WANDA_ROWS_MAX_COLS) return ECOFLAP_ESIZE;
+        // the reference indexes sorted[k]: k == numel raises IndexError there (W:555)
+        if (it.mode == ECOFLAP_WANDA_MATRIX &&
+            (it.k >= it.rows * it.cols || it.rows * it.cols >= (int64_t)0xffffffffLL))
+            return ECOFLAP_ESIZE;
+        if (it.rows > 0x7fffffffLL / 2) return ECOFLAP_ESIZE;
+        if (!it.w || !it.scaler_row) return ECOFLAP_ENULL;
+    }
+    if (!workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_wanda_block_workspace_bytes(items, n_items)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+
+    // workspace: sqrt tables, then the selection states (contiguous: one memset)
+    float* sq[WMAX];
+    MatrixSelState* st[WMAX];
+    char* p = (char*)workspace;
+    for (int i = 0; i < n_items; ++i) { sq[i] = (float*)p; p += sq_bytes(items[i].cols); }
+    bool any_matrix = false;
+    for (int i = 0; i < n_items; ++i) {
+        st[i] = (MatrixSelState*)p;
+        p += sizeof(MatrixSelState);
+        any_matrix = any_matrix || items[i].mode == ECOFLAP_WANDA_MATRIX;
+    }
+    if (any_matrix) {
+        hipError_t e = hipMemsetAsync(st[0], 0, sizeof(MatrixSelState) * (size_t)n_items, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    {
+        SqrtGroup g;
+        g.n = n_items;
+        g.start[0] = 0;
+        for (int i = 0; i < n_items; ++i) {
+            g.src[i] = items[i].scaler_row; g.dst[i] = sq[i]; g.cols[i] = items[i].cols;
+            g.start[i + 1] = g.start[i] + (int32_t)((items[i].cols + 255) / 256);
+        }
+        hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)g.start[n_items]), dim3(256), 0, s, g);
+        ECO_CHECK_LAUNCH();
+    }
+
+    bool done[WMAX];
+    for (int i = 0; i < n_items; ++i) done[i] = false;
+
+    // ---- rows mode -------------------------------------------------------------------------
+    for (int i = 0; i < n_items; ++i) {
+        if (done[i] || items[i].mode != ECOFLAP_WANDA_ROWS) continue;
+        const ecoflap_wanda_item& a = items[i];
+        const int nve = a.dtype == ECOFLAP_F32 ? 4 : 8;
+        if (!item_vector_ok(a, sq[i])) {     // odd widths / unaligned views: the LDS form, per matrix
+            const size_t lds = ((size_t)a.cols + 256 + 4 + 4) * sizeof(uint32_t);
+#define ROWS_LDS(DT_) hipLaunchKernelGGL((wanda_rows_kernel<DT_>), dim3((unsigned)a.rows), dim3(256), lds, s, a.w, sq[i], a.cols, a.k, a.mask_out)
+            DT_SWITCH(a.dtype, ROWS_LDS);
+#undef ROWS_LDS
+            ECO_CHECK_LAUNCH();
+            done[i] = true;
+            continue;
+        }
+        // measured on MI355X: the wave form wins up to 256 vectors per row (2048 bf16 columns),
+        // the workgroup form beyond
+        const int64_t nvec = a.cols / nve;
+        const bool wave = nvec <= 256;
+        const int cls = wave ? rows_wave_class(nvec) : rows_reg_class(nvec);
+        RowsGroup g;
+        g.n = 0;
+        g.start[0] = 0;
+        for (int j = i; j < n_items; ++j) {
+            const ecoflap_wanda_item& b = items[j];
+            if (done[j] || b.mode != ECOFLAP_WANDA_ROWS || b.dtype != a.dtype || !item_vector_ok(b, sq[j]))
+                continue;
+            const int64_t nvb = b.cols / nve;
+            const bool wb = nvb <= 256;
+            if (wb != wave || (wb ? rows_wave_class(nvb) : rows_reg_class(nvb)) != cls) continue;
+            if ((int64_t)g.start[g.n] + b.rows > 0x7fffffffLL) continue;   // next group
+            g.w[g.n] = b.w; g.sq[g.n] = sq[j]; g.cols[g.n] = b.cols; g.k[g.n] = b.k; g.mask[g.n] = b.mask_out;
+            g.start[g.n + 1] = g.start[g.n] + (int32_t)b.rows;
+            ++g.n;
+            done[j] = true;
+        }
+#define ROWS_GO(DT_) do { if (wave) launch_rows_wave<DT_>(g, cls, s); else launch_rows_reg<DT_>(g, cls, s); } while (0)
+        DT_SWITCH(a.dtype, ROWS_GO);
+#undef ROWS_GO
+        ECO_CHECK_LAUNCH();
+    }
+
+    // ---- matrix mode -----------------------------------------------------------------------
+    for (int i = 0; i < n_items; ++i) {
+        if (done[i]) continue;
+        const ecoflap_wanda_item& a = items[i];
+        const bool vec = item_vector_ok(a, sq[i]);
+        MatGroup g;
+        g.n = 0;
+        g.start[0] = 0;
+        for (int j = i; j < n_items; ++j) {
+            const ecoflap_wanda_item& b = items[j];
+            if (done[j] || b.dtype != a.dtype || item_vector_ok(b, sq[j]) != vec) continue;
+            const int64_t n = b.rows * b.cols;
+            // >= 4 vectors per thread and pass; at most WM_MAX_WGS histogram merges per matrix
+            int64_t nb = vec ? (n / (b.dtype == ECOFLAP_F32 ? 4 : 8) + 4 * WM_THREADS - 1) / (4 * WM_THREADS)
+                             : (b.rows + 3) / 4;
+            if (nb < 1) nb = 1;
+            if (nb > WM_MAX_WGS) nb = WM_MAX_WGS;
+            g.w[g.n] = b.w; g.sq[g.n] = sq[j]; g.rows[g.n] = b.rows; g.cols[g.n] = b.cols;
+            g.rank0[g.n] = (uint32_t)(b.k + 1);     // sorted[k], 0-indexed -> (k+1)-th smallest
+            g.st[g.n] = st[j]; g.mask[g.n] = b.mask_out;
+            g.start[g.n + 1] = g.start[g.n] + (int32_t)nb;
+            ++g.n;
+            done[j] = true;
+        }
+        const dim3 grid((unsigned)g.start[g.n]), blk(WM_THREADS);
+#define MATRIX_GO(DT_)                                                                              \
+    do {                                                                                            \
+        if (vec) {                                                                                  \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, true>), grid, blk, 0, s, g);       \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, true>), grid, blk, 0, s, g);       \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, true>), grid, blk, 0, s, g);       \
+            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, true>), grid, blk, 0, s, g);         \
+        } else {                                                                                    \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, false>), grid, blk, 0, s, g);      \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, false>), grid, blk, 0, s, g);      \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, false>), grid, blk, 0, s, g);      \
+            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, false>), grid, blk, 0, s, g);        \
+        }                                                                                           \
+    } while (0)
+        DT_SWITCH(a.dtype, MATRIX_GO);
+#undef MATRIX_GO
+        ECO_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+static int wanda_single(void* w, const float* scaler_row, int64_t rows, int64_t cols, int dtype,
+                        int64_t k, uint8_t* mask_out, int mode, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    ecoflap_wanda_item it;
+    it.w = w; it.scaler_row = scaler_row; it.rows = rows; it.cols = cols; it.k = k;
+    it.mask_out = mask_out; it.dtype = dtype; it.mode = mode;
+    return ecoflap_wanda_prune_block(&it, 1, workspace, workspace_bytes, stream);
+}
 
 extern "C" int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
                                         int64_t cols, int dtype, int64_t k, uint8_t* mask_out,
                                         void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    if (rows <= 0 || cols <= 0 || k < 0 || cols > WANDA_ROWS_MAX_COLS) return ECOFLAP_ESIZE;
-    if (!w || !scaler_row || !workspace) return ECOFLAP_ENULL;
-    if (workspace_bytes < ecoflap_wanda_workspace_bytes(rows, cols)) return ECOFLAP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    float* sq = (float*)workspace;
-    hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
-                       scaler_row, sq, cols);
-    ECO_CHECK_LAUNCH();
-    const int nvec_elems = dtype == ECOFLAP_F32 ? 4 : 8;
-    // mask rows are written with 4/8-byte stores: cols % 8 keeps them aligned for 16-bit dtypes
-    if (cols % nvec_elems == 0 && aligned16(w) && aligned16(sq) &&
-        (!mask_out || (((uintptr_t)mask_out) & 7u) == 0)) {
-        // measured on MI355X: the wave form wins up to 256 vectors per row (2048 bf16 columns),
-        // the workgroup form beyond
-        int miss = 1;
-        if (cols / nvec_elems <= 256) {
-            if (dtype == ECOFLAP_F32) miss = launch_rows_wave<ECOFLAP_F32>(w, sq, rows, cols, k, mask_out, s);
-            else if (dtype == ECOFLAP_F16) miss = launch_rows_wave<ECOFLAP_F16>(w, sq, rows, cols, k, mask_out, s);
-            else miss = launch_rows_wave<ECOFLAP_BF16>(w, sq, rows, cols, k, mask_out, s);
-        }
-        if (!miss) {
-            ECO_CHECK_LAUNCH();
-            return 0;
-        }
-        if (dtype == ECOFLAP_F32) miss = launch_rows_reg<ECOFLAP_F32>(w, sq, rows, cols, k, mask_out, s);
-        else if (dtype == ECOFLAP_F16) miss = launch_rows_reg<ECOFLAP_F16>(w, sq, rows, cols, k, mask_out, s);
-        else miss = launch_rows_reg<ECOFLAP_BF16>(w, sq, rows, cols, k, mask_out, s);
-        if (!miss) {
-            ECO_CHECK_LAUNCH();
-            return 0;
-        }
-    }
-    const size_t lds = ((size_t)cols + 256 + 4 + 4) * sizeof(uint32_t);
-    if (dtype == ECOFLAP_F32)
-        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_F32>), dim3((unsigned)rows), dim3(256), lds, s,
-                           w, sq, cols, k, mask_out);
-    else if (dtype == ECOFLAP_F16)
-        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_F16>), dim3((unsigned)rows), dim3(256), lds, s,
-                           w, sq, cols, k, mask_out);
-    else
-        hipLaunchKernelGGL((wanda_rows_kernel<ECOFLAP_BF16>), dim3((unsigned)rows), dim3(256), lds,
-                           s, w, sq, cols, k, mask_out);
-    ECO_CHECK_LAUNCH();
-    return 0;
-}
-
-template <int DT>
-static int wanda_matrix_launch(void* w, const float* sq, int64_t n, int64_t cols, int64_t k,
-                               MatrixSelState* st, uint8_t* mask_out, hipStream_t s) {
-    const int64_t rows = n / cols;
-    const bool vector = (cols % Vec<DT>::N == 0) && aligned16(w) && aligned16(sq) &&
-                        (!mask_out || (((uintptr_t)mask_out) & 7u) == 0);
-    int64_t b = vector ? (n / Vec<DT>::N + 255) / 256 : rows;
-    if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
-    const dim3 grid((unsigned)b), blk(256);
-    const uint32_t rank0 = (uint32_t)(k + 1);      // sorted[k], 0-indexed -> (k+1)-th smallest
-#define MATRIX_PASSES(V)                                                                        \
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 0, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 1, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
-    hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT, 2, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st); \
-    hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT, V>), grid, blk, 0, s, w, sq, rows, cols, rank0, st, mask_out)
-    if (vector) { MATRIX_PASSES(true); } else { MATRIX_PASSES(false); }
-#undef MATRIX_PASSES
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    return wanda_single(w, scaler_row, rows, cols, dtype, k, mask_out, ECOFLAP_WANDA_ROWS, workspace,
+                        workspace_bytes, stream);
 }
 
 extern "C" int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
                                           int64_t cols, int dtype, int64_t k, uint8_t* mask_out,
                                           void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
-    const int64_t n = rows * cols;
-    // the reference indexes sorted[k]: k == numel raises IndexError there (W:555)
-    if (rows <= 0 || cols <= 0 || k < 0 || k >= n || n >= (int64_t)0xffffffffLL) return ECOFLAP_ESIZE;
-    if (!w || !scaler_row || !workspace) return ECOFLAP_ENULL;
-    if (workspace_bytes < ecoflap_wanda_workspace_bytes(rows, cols)) return ECOFLAP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    float* sq = (float*)workspace;
-    MatrixSelState* st = (MatrixSelState*)((char*)workspace + sq_bytes(cols));
-    hipError_t e = hipMemsetAsync(st, 0, sizeof(MatrixSelState), s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
-                       scaler_row, sq, cols);
-    ECO_CHECK_LAUNCH();
-    if (dtype == ECOFLAP_F32) return wanda_matrix_launch<ECOFLAP_F32>(w, sq, n, cols, k, st, mask_out, s);
-    if (dtype == ECOFLAP_F16) return wanda_matrix_launch<ECOFLAP_F16>(w, sq, n, cols, k, st, mask_out, s);
-    return wanda_matrix_launch<ECOFLAP_BF16>(w, sq, n, cols, k, st, mask_out, s);
+    return wanda_single(w, scaler_row, rows, cols, dtype, k, mask_out, ECOFLAP_WANDA_MATRIX,
+                        workspace, workspace_bytes, stream);
 }
 
 // =====================================================================================

@@ -24,7 +24,8 @@ EXPORTS = [
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
-    "ecoflap_wanda_prune_matrix", "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
+    "ecoflap_wanda_prune_matrix", "ecoflap_wanda_block_workspace_bytes", "ecoflap_wanda_prune_block",
+    "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_count_zeros_multi",
@@ -33,6 +34,17 @@ EXPORTS = [
 
 class EcoflapHipError(RuntimeError):
     pass
+
+
+class WandaItem(ctypes.Structure):
+    """`ecoflap_wanda_item` (include/ecoflap_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("scaler_row", ctypes.c_void_p),
+                ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("k", ctypes.c_int64),
+                ("mask_out", ctypes.c_void_p), ("dtype", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+WANDA_MAX_ITEMS = 16
+WANDA_ROWS, WANDA_MATRIX = 0, 1
 
 
 _lib = None
@@ -74,6 +86,9 @@ def load_library():
     lib.ecoflap_wanda_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
+    lib.ecoflap_wanda_block_workspace_bytes.restype = sz
+    lib.ecoflap_wanda_block_workspace_bytes.argtypes = [vp, ci]
+    lib.ecoflap_wanda_prune_block.argtypes = [vp, ci, vp, sz, vp]
     lib.ecoflap_mask_mul.argtypes = [vp, vp, i64, ci, vp]
     lib.ecoflap_grad_accum_multi.argtypes = [vp, ci, vp]
     lib.ecoflap_global_prune_workspace_bytes.restype = sz
@@ -113,15 +128,19 @@ def _ptr(t):
 
 
 class Workspace:
-    """Caller-owned scratch, grown on demand and reused (no allocation inside launches)."""
+    """Caller-owned scratch, grown on demand and reused (no allocation inside launches).
+    zeroed=True: filled with zeros when (re)allocated, for kernels that keep self-resetting
+    ticket counters in it (K6) — such a workspace is not shared with other kernels."""
 
-    def __init__(self):
+    def __init__(self, zeroed=False):
         self.buf = None
+        self.zeroed = zeroed
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            alloc = torch.zeros if self.zeroed else torch.empty
+            self.buf = alloc(nbytes, dtype=torch.uint8, device=device)
         return self.buf
 
 
@@ -133,6 +152,7 @@ class HipKernels:
     def __init__(self):
         self.lib = load_library()
         self.ws = Workspace()
+        self.k6_ws = Workspace(zeroed=True)
 
     # ---- K1 ---------------------------------------------------------------------------
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
@@ -263,7 +283,7 @@ class HipKernels:
         _gpu(x2d, "x")
         tokens, cols = x2d.shape
         nb = self.lib.ecoflap_colsqnorm_workspace_bytes(tokens, cols)
-        ws = self.ws.get(nb, x2d.device)
+        ws = self.k6_ws.get(nb, x2d.device)      # zeroed when (re)allocated: K6's ticket counters
         _check(self.lib.ecoflap_colsqnorm_accum(
             _ptr(scaler_row), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype],
             int(nsamples_before), int(batch), _ptr(ws), ws.numel(), _stream()),
@@ -274,7 +294,7 @@ class HipKernels:
     def colsqnorm_workspace(self, tokens, cols, device):
         """A private workspace for `colsqnorm_accum_dev` (a captured graph keeps its address)."""
         nb = self.lib.ecoflap_colsqnorm_workspace_bytes(tokens, cols)
-        return torch.empty(max(int(nb), 16), dtype=torch.uint8, device=device)
+        return torch.zeros(max(int(nb), 16), dtype=torch.uint8, device=device)    # tickets start at 0
 
     def colsqnorm_accum_dev(self, scaler_row, x2d, n_dev, batch, ws):
         _gpu(scaler_row, "scaler_row")
@@ -303,6 +323,32 @@ class HipKernels:
     def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
         self._wanda(self.lib.ecoflap_wanda_prune_matrix, "ecoflap_wanda_prune_matrix", w,
                     scaler_row, k, mask_out)
+
+    def wanda_prune_block(self, items):
+        """items: [(w, scaler_row, mode, k, mask_out_or_None)], mode "rows" / "matrix": all
+        the Linears of one transformer block, pruned by shared launches
+        (ecoflap_wanda_prune_block); same results as one call per matrix."""
+        for c0 in range(0, len(items), WANDA_MAX_ITEMS):
+            chunk = items[c0:c0 + WANDA_MAX_ITEMS]
+            arr = (WandaItem * len(chunk))()
+            for a, (w, scaler_row, mode, k, mask_out) in zip(arr, chunk):
+                _gpu(w, "w")
+                _gpu(scaler_row, "scaler_row")
+                if mask_out is not None:
+                    _gpu(mask_out, "mask_out")
+                if scaler_row.dtype != torch.float32:
+                    raise EcoflapHipError("scaler_row must be float32")
+                a.w, a.scaler_row = w.data_ptr(), scaler_row.data_ptr()
+                a.rows, a.cols = w.shape
+                a.k = int(k)
+                a.mask_out = mask_out.data_ptr() if mask_out is not None else None
+                a.dtype = DTYPE_CODE[w.dtype]
+                a.mode = {"rows": WANDA_ROWS, "matrix": WANDA_MATRIX}[mode]
+            nb = self.lib.ecoflap_wanda_block_workspace_bytes(ctypes.byref(arr), len(chunk))
+            ws = self.ws.get(nb, chunk[0][0].device)
+            _check(self.lib.ecoflap_wanda_prune_block(ctypes.byref(arr), len(chunk), _ptr(ws),
+                                                      ws.numel(), _stream()),
+                   "ecoflap_wanda_prune_block")
 
     # ---- Real-* global iterative pruning ---------------------------------------------------------
     def grad_accum_multi(self, accs, grads):

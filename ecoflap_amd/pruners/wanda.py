@@ -295,6 +295,7 @@ class _BlockwiseWanda:
                                 and torch.equal(wrapped[b].H, wrapped[a].H)):
                             twins[a] = b
                             break
+            block_items = []
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps) * count_factor
                 weight = subset[name].weight.data
@@ -306,11 +307,15 @@ class _BlockwiseWanda:
                                               same_hessian_as=wrapped.get(twins.get(name)))
                     wrapped[name].H = None
                 elif mode == "rows":      # per output row, k smallest by stable order (:272-279)
-                    k = int(weight.shape[1] * ratio)
-                    self.kernels.wanda_prune_rows(weight, wrapped[name].scaler_row, k)
+                    block_items.append((weight, wrapped[name].scaler_row, "rows",
+                                        int(weight.shape[1] * ratio), None))
                 else:                   # whole matrix, metric <= sorted[k] (:555-558)
-                    k = int(weight.numel() * ratio)
-                    self.kernels.wanda_prune_matrix(weight, wrapped[name].scaler_row, k)
+                    block_items.append((weight, wrapped[name].scaler_row, "matrix",
+                                        int(weight.numel() * ratio), None))
+            if block_items:
+                # the block's selections are independent of each other (the reference's per-Linear
+                # loop reads only that Linear's weight and statistic): one call, shared launches
+                self.kernels.wanda_prune_block(block_items)
             if sparsegpt:
                 for w_ in wrapped.values():
                     w_.free()

@@ -163,6 +163,11 @@ int ecoflap_absprod_reduce_multi(const int64_t* table, int n_layers,
  * replaces WrappedGPT.add_batch   LAVIS/lavis/compression/pruners/wanda_pruner.py:71-84
  *     scaler_row *= n/(n+b); n += b; scaler_row += norm(x, 2, dim=tokens)**2 / n
  * x: [tokens, cols] row-major of `dtype`; scaler_row: float[cols].
+ * ONE launch per call: the last row chunk of every column block to finish (ticket counters at
+ * the head of the workspace) sums the block's partials in fixed order and applies the update.
+ * The workspace must be ZEROED ONCE by its owner (hipMemset after allocation); the tickets
+ * reset themselves, so it can be reused by later calls — on the same stream, one call at a
+ * time — without another memset.
  * ------------------------------------------------------------------------- */
 size_t ecoflap_colsqnorm_workspace_bytes(int64_t tokens, int64_t cols);
 int ecoflap_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens,
@@ -196,6 +201,27 @@ int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
                                int64_t cols, int dtype, int64_t k,
                                uint8_t* mask_out, void* workspace,
                                size_t workspace_bytes, void* stream);
+
+/* Block-level form: every Linear of one transformer block in ONE call (the reference prunes
+ * them one after another inside its per-block loop, wanda_pruner.py:253-283 / :534-562; the
+ * selections are independent).  Same results as n_items single calls, bit for bit; the launches
+ * are shared: one sqrt launch, one selection launch per (dtype, register class) of the rows-mode
+ * items, three histogram launches + one apply launch for all matrix-mode items of a dtype. */
+#define ECOFLAP_WANDA_MAX_ITEMS 16
+#define ECOFLAP_WANDA_ROWS   0
+#define ECOFLAP_WANDA_MATRIX 1
+typedef struct ecoflap_wanda_item {
+    void* w;                   /* [rows, cols] of `dtype`, pruned in place */
+    const float* scaler_row;   /* float[cols] */
+    int64_t rows, cols;
+    int64_t k;                 /* rows mode: columns zeroed per row; matrix mode: index into the sort */
+    uint8_t* mask_out;         /* optional uint8[rows*cols], 1 where zeroed */
+    int dtype;
+    int mode;                  /* ECOFLAP_WANDA_ROWS / ECOFLAP_WANDA_MATRIX */
+} ecoflap_wanda_item;
+size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* items, int n_items);
+int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_items,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * SparseGPT block step

@@ -77,6 +77,11 @@ class OracleKernels:
         if mask_out is not None:
             mask_out.copy_(m)
 
+    def wanda_prune_block(self, items):
+        for w, scaler_row, mode, k, mask_out in items:
+            (self.wanda_prune_rows if mode == "rows" else self.wanda_prune_matrix)(
+                w, scaler_row, k, mask_out)
+
     # Real-*: the reference's own torch formulation (layer_single_base_pruner.py:156-245,
     # :446-471) on host copies — the checker for the multi-tensor HIP kernels
     def grad_accum_multi(self, accs, grads):

@@ -312,6 +312,42 @@ def test_colsqnorm_vs_oracle(kern, oracle, dt, tokens, cols):
     np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), rtol=2e-6)
 
 
+def test_colsqnorm_single_launch_shared_workspace_and_device_count(kern, oracle):
+    """K6 is one launch: the last row chunk of a column block finishes the update (ticket counters
+    at the head of the workspace, self-resetting).  A sequence of differently shaped inputs through
+    ONE shared workspace, repeated, and the device-side sample count of the graph-replayable form:
+    equal to the oracle (2e-6), run to run bit-identical."""
+    shapes = [(8 * 257, 1408, torch.float16), (8 * 257, 6144, torch.float16), (384, 2048, torch.bfloat16),
+              (37, 130, torch.float32), (384, 5120, torch.bfloat16), (8 * 257, 1408, torch.float32)]
+    torch.manual_seed(5)
+    xs = [(torch.randn(t, c) * 1.3).to(dt) for t, c, dt in shapes]
+    runs = []
+    for rep in range(2):
+        outs = []
+        for x in xs:
+            s = torch.zeros(x.shape[1], device="cuda")
+            for step in range(3):
+                kern.colsqnorm_accum(s, gpu(x), 8 * step, 8)
+            outs.append(s.cpu())
+        runs.append(outs)
+    for x, a, b in zip(xs, runs[0], runs[1]):
+        assert torch.equal(a, b)
+        ref = torch.zeros(x.shape[1])
+        for step in range(3):
+            oracle.colsqnorm_accum(ref, x, 8 * step, 8)
+        np.testing.assert_allclose(a.numpy(), ref.numpy(), rtol=2e-6)
+    # device-side count: same numbers, n advanced by the kernel itself
+    x = xs[1]
+    s_host, s_dev = torch.zeros(6144, device="cuda"), torch.zeros(6144, device="cuda")
+    n_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = kern.colsqnorm_workspace(x.shape[0], x.shape[1], "cuda")
+    for step in range(4):
+        kern.colsqnorm_accum(s_host, gpu(x), 8 * step, 8)
+        kern.colsqnorm_accum_dev(s_dev, gpu(x), n_dev, 8, ws)
+    assert int(n_dev.item()) == 32
+    assert torch.equal(s_host, s_dev)
+
+
 # ------------------------------------------------------------------------------ K7
 def _ties(w, levels):
     return (torch.round(w * levels) / levels)
@@ -393,6 +429,55 @@ def test_wanda_full_size_properties(kern):
     kern.wanda_prune_matrix(w2, s, k, mask)
     assert torch.equal(mask.bool(), want)
     assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
+
+
+def test_wanda_block_call_equals_oracle_per_matrix(kern, oracle):
+    """ecoflap_wanda_prune_block: all Linears of a block through shared launches (rows-mode items
+    of two register classes + an odd-width item that takes the LDS form, matrix-mode items of two
+    dtypes, with and without masks) == the oracle matrix by matrix, bit for bit."""
+    torch.manual_seed(21)
+    spec = [("rows", 96, 2048, torch.bfloat16, 0.5, True), ("rows", 64, 2048, torch.bfloat16, 0.37, False),
+            ("rows", 40, 5120, torch.bfloat16, 0.6, True), ("rows", 33, 1000, torch.bfloat16, 0.5, True),
+            ("rows", 17, 257, torch.bfloat16, 0.41, True), ("rows", 24, 512, torch.float16, 0.5, True),
+            ("matrix", 128, 1408, torch.float16, 0.5, True), ("matrix", 96, 704, torch.float16, 0.45, False),
+            ("matrix", 50, 130, torch.float32, 0.3, True), ("matrix", 31, 77, torch.float16, 0.52, True),
+            ("rows", 20, 2048, torch.bfloat16, 0.0, True), ("rows", 20, 1024, torch.bfloat16, 1.0, True)]
+    items, refs = [], []
+    for mode, rows, cols, dt, frac, want_mask in spec:
+        w = (_ties(torch.randn(rows, cols) * 0.05, 200)).to(dt)      # some equal metrics
+        sr = torch.round((torch.rand(cols) + 0.1) * 8) / 8
+        k = int(cols * frac) if mode == "rows" else min(int(rows * cols * frac), rows * cols - 1)
+        mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda") if want_mask else None
+        wg = gpu(w.clone())
+        items.append((wg, gpu(sr), mode, k, mask))
+        wr = w.clone()
+        mref = (oracle.wanda_prune_rows if mode == "rows" else oracle.wanda_prune_matrix)(wr, sr, k)
+        refs.append((wr, mref))
+    kern.wanda_prune_block(items)
+    for (wg, _, mode, k, mask), (wr, mref) in zip(items, refs):
+        assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8)), (mode, tuple(wg.shape))
+        if mask is not None:
+            assert torch.equal(mask.cpu(), mref), (mode, tuple(wg.shape))
+
+
+def test_wanda_block_full_size_blocks_equal_single_calls(kern):
+    """A ViT-g block (4 fp16 matrices, matrix mode) and a FlanT5-XL decoder block (11 bf16
+    matrices, rows mode) at BASELINE size: block call == one call per matrix, bit for bit."""
+    torch.manual_seed(3)
+    vit = [(4224, 1408), (1408, 1408), (6144, 1408), (1408, 6144)]
+    t5 = [(2048, 2048)] * 8 + [(5120, 2048)] * 2 + [(2048, 5120)]
+    for mode, shapes, dt in (("matrix", vit, torch.float16), ("rows", t5, torch.bfloat16)):
+        ws = [(torch.randn(r, c, device="cuda") * 0.02).to(dt) for r, c in shapes]
+        srs = [torch.rand(c, device="cuda") + 0.05 for _, c in shapes]
+        ks = [int((c if mode == "rows" else r * c) * 0.5) for r, c in shapes]
+        single = [w.clone() for w in ws]
+        for w, sr, k in zip(single, srs, ks):
+            (kern.wanda_prune_rows if mode == "rows" else kern.wanda_prune_matrix)(w, sr, k)
+        block = [w.clone() for w in ws]
+        kern.wanda_prune_block([(w, sr, mode, k, None) for w, sr, k in zip(block, srs, ks)])
+        for a, b in zip(single, block):
+            assert torch.equal(a, b)
+            assert abs((b == 0).float().mean().item() - 0.5) < 0.01
 
 
 # ------------------------------------------------------------------------------ K8

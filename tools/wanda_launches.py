@@ -13,17 +13,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecoflap_amd import hip  # noqa: E402
 
 
-def timed(fn, n_sets, reps=3):
-    blocker = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
-    for i in range(n_sets):
+def timed(fn, n_sets, reps=3, fresh=False):
+    """fresh: the call changes its input (pruning): warm up on set 0 only, time sets 1..n-1 once."""
+    for i in range(1 if fresh else n_sets):
         fn(i)
     torch.cuda.synchronize()
     out = []
-    for _ in range(reps):
-        for _ in range(4):
-            blocker @ blocker
-        evs = []
-        for i in range(n_sets):
+    for _ in range(1 if fresh else reps):
+        torch.cuda._sleep(2000000)     # keeps the stream busy while the host enqueues (no GEMMs:
+        evs = []                       # they would pull the clock down for what follows)
+        for i in range(1 if fresh else 0, n_sets):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); fn(i); e.record(); evs.append((s, e))
         torch.cuda.synchronize()
@@ -54,15 +53,36 @@ def main():
                                        ("vit proj 1408x1408", 1408, 1408, torch.float16, "matrix")]:
         es = torch.empty(0, dtype=dt).element_size()
         nbytes = 2 * es * rows * cols + 4 * cols
-        sets = max(2, int(6e8 // (rows * cols * es)))
+        sets = max(3, int(6e8 // (rows * cols * es)))
         ws = [(torch.randn(rows, cols, device="cuda") * 0.02).to(dt) for _ in range(sets)]
         sr = torch.rand(cols, device="cuda") + 0.05
         if mode == "rows":
             fn = lambda i: kern.wanda_prune_rows(ws[i], sr, cols // 2)          # noqa: E731
         else:
             fn = lambda i: kern.wanda_prune_matrix(ws[i], sr, rows * cols // 2)  # noqa: E731
-        med, mn = timed(fn, sets, reps=1)   # pruning is idempotent but rewrites zeros: 1 rep on fresh data
+        med, mn = timed(fn, sets, fresh=True)
         res.append((f"K7 {mode}", name, nbytes, med, mn))
+        del ws
+    # K7 per transformer block: all its Linears through ecoflap_wanda_prune_block
+    blocks = [("vit-g block (4 fp16 matrices)", "matrix", torch.float16,
+               [(4224, 1408), (1408, 1408), (6144, 1408), (1408, 6144)]),
+              ("t5 encoder block (7 bf16)", "rows", torch.bfloat16,
+               [(2048, 2048)] * 4 + [(5120, 2048)] * 2 + [(2048, 5120)]),
+              ("t5 decoder block (11 bf16)", "rows", torch.bfloat16,
+               [(2048, 2048)] * 8 + [(5120, 2048)] * 2 + [(2048, 5120)])]
+    for name, mode, dt, shapes in blocks:
+        es = 2
+        nbytes = sum(2 * es * r * c + 4 * c for r, c in shapes)
+        sets = max(3, int(8e8 // (nbytes // 2)))
+        wsets = [[(torch.randn(r, c, device="cuda") * 0.02).to(dt) for r, c in shapes]
+                 for _ in range(sets)]
+        srs = [torch.rand(c, device="cuda") + 0.05 for _, c in shapes]
+        ks = [int((c if mode == "rows" else r * c) * 0.5) for r, c in shapes]
+        fn = lambda i: kern.wanda_prune_block(                                   # noqa: E731
+            [(w, sr, mode, k, None) for w, sr, k in zip(wsets[i], srs, ks)])
+        med, mn = timed(fn, sets, fresh=True)
+        res.append((f"K7 {mode} block", name, nbytes, med, mn))
+        del wsets
     for k, name, nbytes, med, mn in res:
         print(f"{k:14s} {name:24s} {nbytes/1e6:8.1f} MB  median {med:8.1f} us  min {mn:8.1f} us  "
               f"{nbytes/med/1e3:7.0f} GB/s ({nbytes/med/1e3/80:5.1f}% of 8 TB/s)")
