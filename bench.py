@@ -75,6 +75,9 @@ def parse():
                          "power state alone), four 4096^3 GEMMs (round 1; they pull the clock down "
                          "for the kernel that follows), or nothing (the pair then also times the "
                          "host's enqueue gap)")
+    ap.add_argument("--profile-host", default=None,
+                    help="cProfile the timed region's host side into this file (diagnosis only: "
+                         "the profiler slows the loop)")
     ap.add_argument("--no-k1-events", action="store_true",
                     help="no event pairs, no blocker: the uninstrumented loop (rocprofv3 "
                          "cross-check of the K1 durations; the line then carries no roofline)")
@@ -336,7 +339,8 @@ def main():
     group_of = lambda k: ".".join(k.split(".")[:4 if k.startswith("t5_model") else 3])  # noqa: E731
     full_mapping = {k: group_of(k) for k in prunable}
     n_total = len(prunable)
-    numel_total = sum(dict(model.named_parameters())[k].numel() for k in prunable)
+    params_by_name = dict(model.named_parameters())
+    numel_total = sum(params_by_name[k].numel() for k in prunable)
     build_s = time.time() - t_build
 
     kern = TimedKernels(hip.HipKernels())
@@ -387,7 +391,13 @@ def main():
     layer_ids = strided(n_total, args.steps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ls, table = run(layer_ids, timed=True)
+    if args.profile_host:
+        import cProfile
+        prof = cProfile.Profile()
+        ls, table = prof.runcall(run, layer_ids, True)
+        prof.dump_stats(args.profile_host)
+    else:
+        ls, table = run(layer_ids, timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -375,6 +375,12 @@ class HipKernels:
         dev = weights[0].device
         table = torch.tensor(rows, dtype=torch.int64, device=dev)
         total = sum(r[3] for r in rows)
+        if total >= 2 ** 32 - 1:
+            # histogram bins and the in-block scans of the selection kernels are 32-bit
+            raise EcoflapHipError(
+                f"global threshold over {total} elements: one selection covers at most 2^32 - 2 "
+                "(4 294 967 294) elements (BLIP-2 FlanT5-XL has 3 701 932 032); prune per "
+                "sub-model (prune_per_model) or layer-wise, or split the call")
         ws = self.ws.get(self.lib.ecoflap_global_prune_workspace_bytes(), dev)
         _check(self.lib.ecoflap_global_threshold_prune(
             _ptr(table), len(rows), int(mode), float(n_batches), int(k), int(total), _ptr(ws),

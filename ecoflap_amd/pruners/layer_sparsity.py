@@ -173,11 +173,35 @@ class LayerSparsity:
                 params.append(v)
         return names, params
 
+    def calibration_prefix(self):
+        """The batches one pass of the reference's loop visits (:519-525: it leaves the loader
+        once `accum_samples >= num_samples`): the loader is consumed LAZILY up to that point —
+        never `list(loader)`, a UPop entrypoint hands over its whole training loader — and the
+        prefix is taken ONCE and reused for every layer and both losses of a pair.  For a
+        deterministic loader (LAVIS's DataLoaderWrapper, lists) that is what the reference sees,
+        which re-iterates the loader per layer; a shuffling loader would give the reference a
+        fresh random prefix per layer — the same distribution, not the same batches."""
+        if isinstance(self.data_loader, (list, tuple)):
+            seq = self.data_loader
+        else:
+            seq = iter(self.data_loader)
+        out, accum = [], 0
+        for d in seq:
+            if accum >= self.num_samples:
+                break
+            out.append(d)
+            n = self.batch_len_fn(d)
+            for _ in range(self.num_noise):           # (:525-541: every noise draw spends samples)
+                if accum >= self.num_samples:
+                    break
+                accum += n
+        return out
+
     def build_zeroth_order_schedule(self, names):
         """Replay the reference's loop nest (:512-549) on the host only, consuming the
         global NumPy RNG at exactly the points it does, and return the list of units
         (layer index, batch index, noise index, seed, batch_len)."""
-        batches = list(self.data_loader)
+        batches = self.calibration_prefix()
         lens = [self.batch_len_fn(b) for b in batches]
         units = []
         for li, _ in enumerate(names):
@@ -207,7 +231,12 @@ class LayerSparsity:
         batches, units = self.build_zeroth_order_schedule(names)
         self.seed_schedule = units
         n_units = len(units)
-        table = torch.zeros((max(n_units, 1), 2), dtype=torch.float32, device=device)
+        # the loss pair of a unit, in the loss tensor's OWN dtype (fp32 for every loss closure of
+        # the reference; a model returning a bf16 / fp16 loss has its subtraction and division
+        # done in that dtype, as `(loss1 - loss2) / (2 * zo_eps)` is at :544): allocated on the
+        # first loss
+        table = None
+        self._table_shape = (max(n_units, 1), 2)
 
         by_layer = {}
         for u, unit in enumerate(units):
@@ -239,6 +268,10 @@ class LayerSparsity:
                         None if self.z_source == "philox" else zs)
                 static_w = bool(getattr(self.loss_func, "requires_static_weights", False))
                 paired = static_w and bool(getattr(self.loss_func, "supports_pairs", lambda: False)())
+                if paired and self.couple_torch_rng:
+                    raise RuntimeError(
+                        "couple_torch_rng needs one loss at a time (the torch RNG is re-seeded "
+                        "before each loss, :482): use a loss closure without lanes / batching")
                 final = home.clone() if static_w else None   # graphs bake the address of `home`
                 if paired:
                     self.loss_func.begin_layer_weights(name, home)
@@ -256,8 +289,9 @@ class LayerSparsity:
                             u = layer_units[j]
                             if batch_len != units[u][4]:
                                 raise RuntimeError("loss_func batch_len differs from the schedule")
-                            table[u, 0].copy_(l1.detach().float(), non_blocking=True)
-                            table[u, 1].copy_(l2.detach().float(), non_blocking=True)
+                            table = self._table_for(table, l1, device)
+                            table[u, 0].copy_(l1.detach(), non_blocking=True)
+                            table[u, 1].copy_(l2.detach(), non_blocking=True)
                             n_forward += 2
                 for j, (u, mine) in enumerate(zip(layer_units, owned)):
                     if not mine or paired:
@@ -267,14 +301,14 @@ class LayerSparsity:
                         home.copy_(plus[j])
                     else:
                         param.data = plus[j]    # theta + eps z
-                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen,
-                                    rng=(units[u][3], param))
+                    table = self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen,
+                                            rng=(units[u][3], param))
                     if static_w:
                         home.copy_(minus[j])
                     else:
                         param.data = minus[j]   # theta - eps z
-                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen,
-                                    rng=(units[u][3], param))
+                    table = self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen,
+                                            rng=(units[u][3], param))
                     n_forward += 2
                 if static_w:
                     home.copy_(final)
@@ -293,10 +327,10 @@ class LayerSparsity:
                     param.data = cur
                     self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
                     if mine:
-                        self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
+                        table = self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     self.kernels.zo_perturb(cur, -2, zo_eps, seed, z)
                     if mine:
-                        self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
+                        table = self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     self.kernels.zo_perturb(cur, 1, zo_eps, seed, z)
                     n_forward += 2 * int(mine)
                     continue
@@ -304,9 +338,9 @@ class LayerSparsity:
                     minus, restored = spare
                     self.kernels.zo_perturb_triple(cur, cur, minus, restored, zo_eps, seed, z)
                     param.data = cur            # theta + eps z
-                    self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
+                    table = self._loss_into(table, u, 0, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     param.data = minus          # theta - eps z
-                    self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
+                    table = self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen, rng=(seed, param))
                     param.data = restored       # "recovered" weights, with the reference's drift
                     cur, spare = restored, [minus, cur]
                     n_forward += 2
@@ -322,12 +356,15 @@ class LayerSparsity:
             del spare
 
         t_enqueued = time.time() - t0            # host done; the device may still be replaying
+        if table is None:                        # this rank evaluated nothing (more ranks than batches)
+            table = torch.zeros(self._table_shape, dtype=torch.float32, device=device)
         if world > 1:
             self._all_reduce_sum(table)          # each entry is written by exactly one rank
-        # (loss1 - loss2) / (2 eps) with torch's own fp32 tensor ops on the loss tensors'
-        # device, as the reference evaluates it per pair (:544); ONE sync for the run.
-        projected = ((table[:, 0] - table[:, 1]) / (2 * zo_eps)).cpu().numpy()
-        self.loss_table = table.cpu().numpy()
+        # (loss1 - loss2) / (2 eps) with torch's own tensor ops in the loss dtype on the loss
+        # tensors' device, as the reference evaluates it per pair (:544), then `.item()` ->
+        # python float; ONE sync for the run.
+        projected = ((table[:, 0] - table[:, 1]) / (2 * zo_eps)).float().cpu().numpy()
+        self.loss_table = table.float().cpu().numpy()
 
         grad_sum = {}
         for li, name in enumerate(names):
@@ -372,6 +409,13 @@ class LayerSparsity:
         if self.z_source != "philox":
             self._draw_z(seed, param)     # leaves the generator where the reference's draw does
 
+    def _table_for(self, table, loss, device):
+        if table is None:
+            table = torch.zeros(self._table_shape, dtype=loss.dtype, device=device)
+        elif table.dtype != loss.dtype:
+            raise RuntimeError(f"loss dtype changed within a run: {table.dtype} -> {loss.dtype}")
+        return table
+
     def _loss_into(self, table, unit, col, batch, cuda_enabled, expected_len, rng=None):
         if rng is not None:
             self._couple_rng(*rng)
@@ -381,7 +425,9 @@ class LayerSparsity:
             raise RuntimeError(
                 f"loss_func reported batch_len {batch_len}, schedule assumed {expected_len}; "
                 "pass batch_len_fn matching the loss closure")
-        table[unit, col].copy_(loss.detach().float(), non_blocking=True)
+        table = self._table_for(table, loss, table.device if table is not None else loss.device)
+        table[unit, col].copy_(loss.detach(), non_blocking=True)
+        return table
 
     def _weight_sums(self, params, mode):
         device = params[0].device
@@ -469,7 +515,11 @@ class LayerSparsity:
                 yield d, grads
                 del grads, loss
             return
-        key = (next(iter(sigs)), tuple(id(p) for p in params))
+        # the captured graph bakes in the parameters' storage addresses and the loss closure:
+        # a re-pointed `param.data` (model_reset's .type(), the non-static K1 forms) or another
+        # loss_func must not replay it
+        key = (next(iter(sigs)), tuple((id(p), p.data_ptr()) for p in params), id(self.loss_func),
+               id(self.model))
         cache = getattr(self, "_grad_graph_cache", None)
         if cache is None or cache[0] != key:
             first = todo[0]

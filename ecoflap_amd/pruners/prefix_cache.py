@@ -150,8 +150,10 @@ class PrefixCachedLoss:
         assert verify_batched in ("first", "entries", "all")
         self.verify_batched = verify_batched
         self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
-        self._verified = set()      # (entry, S) whose batched losses were checked bit for bit
-        self.invariant = {}         # stage -> batch invariant on this system (probed)
+        # both guards are per batch-shape FAMILY: which library kernel a GEMM gets (Stream-K,
+        # split-K) depends on M/N/K, so invariance measured at one shape says nothing about another
+        self._verified = set()      # (family, entry, S) whose batched losses were checked bit for bit
+        self.invariant = {}         # (family, k, stage) -> batch invariant on this system (probed)
         if n_lanes is None:
             n_lanes = 2 if two_lanes else 1
         assert n_lanes in (1, 2, 3, 4, 6, 8)
@@ -364,7 +366,7 @@ class PrefixCachedLoss:
                             a.shape == b_.shape and torch.equal(a, b_) for a, b_ in zip(flat_a, flat_b)):
                         same = False
                         break
-                self.invariant[j] = same
+                self.invariant[(self._fam, k, j)] = same
                 if same and sum(t.numel() for t in flat_a) < 65536 and self.verify_batched != "all":
                     # too few values for one comparison to rule out a lucky agreement (toy
                     # shapes): fall back to checking every chunk against the sequential losses
@@ -373,15 +375,16 @@ class PrefixCachedLoss:
                 ins = outs
         self.stats["invariance_probes"] = self.stats.get("invariance_probes", 0) + 1
         self.stats["stages_not_batch_invariant"] = sorted(
-            self.plan[j][0] for j, ok in self.invariant.items() if not ok)
+            {self.plan[j][0] for (_, _, j), ok in self.invariant.items() if not ok})
 
     def _batch_from(self, entry, evals, states, B):
         """First stage S > entry such that S..n-2 are all batch invariant (None: nothing to share)."""
         n = len(self.plan)
-        if any(j not in self.invariant for j in range(entry + 1, n - 1)):
-            self._probe_invariance(entry, evals, states, B)
+        fam, k = self._fam, self.eval_batch
+        if any((fam, k, j) not in self.invariant for j in range(entry + 1, n - 1)):
+            self._probe_invariance(entry, evals, states, B)      # every new family is probed
         S = n - 1
-        while S - 1 > entry and self.invariant.get(S - 1, False):
+        while S - 1 > entry and self.invariant.get((fam, k, S - 1), False):
             S -= 1
         return S if S <= n - 2 else None
 
@@ -475,10 +478,10 @@ class PrefixCachedLoss:
         losses = [bundle[2][i].clone() for i in range(len(evals))]
         import os
         check = (self.verify_batched == "all" or bool(os.environ.get("ECOFLAP_VERIFY_BATCHED"))
-                 or ((entry, S) not in self._verified
+                 or ((self._fam, entry, S) not in self._verified
                      and (self.verify_batched == "entries" or len(self._verified) < 4)))
         if check:
-            self._verified.add((entry, S))
+            self._verified.add((self._fam, entry, S))
             # "entries": one unit (theta+, theta-) per check, its slot rotating from check to
             # check; "all" / "first": the whole chunk
             if self.verify_batched == "entries" and not os.environ.get("ECOFLAP_VERIFY_BATCHED"):

@@ -143,6 +143,13 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
             # lanes, one chain of graphs per batch shape family (VQA batches differ in their
             # number of answers); loaders with many different shapes replay eagerly
             from .prefix_cache import PrefixCachedLoss
+            # shape families over the bounded prefix stage 1 will visit — never the whole loader
+            # (the UPop entrypoints pass their full training loader)
+            probe = LayerSparsity(self.model, self.data_loader, None, self.num_data_first_stage,
+                                  original_sparsity, self.max_sparsity_per_layer, self.score_method,
+                                  self.num_noise, self.noise_eps, {}, kernels=self.kernels,
+                                  batch_len_fn=lambda b: b[0].shape[0])
+            self.data_loader = probe.calibration_prefix()     # fixed list: same batches downstream
             families = len({_shape_signature(b) for b in self.data_loader})
             graphs = (families <= 8 and device.type == "cuda"
                       and bool(getattr(self, "use_graphs", True))

@@ -54,3 +54,72 @@ def test_uniform_calibration_detection():
     assert _uniform_calibration(ragged, caches2, 3) is False
     lists = [{"encoder_hidden_states": [torch.zeros(1, 2, 8)] * 2} for _ in range(3)]
     assert _uniform_calibration(inps, lists, 3) is False     # NLVR's twin states: eager path
+
+
+class _CountingLoader:
+    """Re-iterable loader that records how many batches were drawn and fails past a limit —
+    stands in for a UPop entrypoint's full (shuffled) training loader."""
+
+    def __init__(self, batches, limit):
+        self.batches, self.limit, self.drawn = batches, limit, 0
+
+    def __iter__(self):
+        for i, b in enumerate(self.batches):
+            assert i < self.limit, "the loader was consumed past the calibration prefix"
+            self.drawn += 1
+            yield b
+
+
+def test_calibration_prefix_is_lazy_and_follows_the_reference_stop_rule():
+    """layer_single_base_pruner.py:519-541: leave the loader once accum_samples >= num_samples;
+    every noise draw spends samples.  Never list(loader)."""
+    import torch
+    from oracle_backend import OracleKernels
+    from ecoflap_amd.pruners import LayerSparsity
+    batches = [{"text_input": ["a"] * 4, "i": i} for i in range(100)]
+    model = torch.nn.Linear(2, 2)
+    for num_samples, num_noise, want in [(8, 1, 2), (9, 1, 3), (8, 2, 1), (16, 3, 2), (1, 1, 1)]:
+        loader = _CountingLoader(batches, limit=want + 1)       # the break needs one look-ahead
+        ls = LayerSparsity(model, loader, None, num_samples, 0.5, 0.6, "MEZO-GradOnly_sum", num_noise,
+                           1e-3, {}, kernels=OracleKernels())
+        got = ls.calibration_prefix()
+        assert [b["i"] for b in got] == list(range(want)), (num_samples, num_noise)
+        assert loader.drawn <= want + 1
+
+
+def test_loss_table_keeps_the_loss_dtype():
+    """(loss1 - loss2) / (2 eps) is evaluated in the loss tensor's own dtype (reference :544)."""
+    import numpy as np
+    import torch
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd.pruners import LayerSparsity
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 1)).eval()
+    batches = [{"text_input": ["x"] * 4, "x": torch.randn(4, 8)} for _ in range(2)]
+
+    def run(loss_dtype):
+        def loss_fn(m, b, cuda_enabled):
+            return (m(b["x"]).float().pow(2).mean() * 100).to(loss_dtype), 4
+        torch.manual_seed(0)
+        for p, q in zip(model.parameters(), init):
+            p.data.copy_(q)
+        np.random.seed(1)
+        ls = LayerSparsity(model, batches, loss_fn, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3,
+                           {"0.weight": "a", "1.weight": "b"}, kernels=OracleKernels(),
+                           z_source=torch_cpu_normal, k1_form="single")
+        ls.return_sparsity()
+        return ls.loss_table, {k: float(v) for k, v in ls.importance_measure.items()}
+
+    init = [p.data.clone() for p in model.parameters()]
+    t32, s32 = run(torch.float32)
+    tbf, sbf = run(torch.bfloat16)
+    # the bf16 table holds bf16 values, and the projected gradient is the bf16 difference
+    assert np.array_equal(tbf, torch.from_numpy(t32).to(torch.bfloat16).float().numpy())
+    want = {}
+    for name, rows in (("0.weight", (0, 1)), ("1.weight", (2, 3))):
+        acc = np.float32(0)
+        for r in rows:
+            d = (torch.tensor(tbf[r, 0], dtype=torch.bfloat16) - torch.tensor(tbf[r, 1], dtype=torch.bfloat16)) / (2 * 1e-3)
+            acc = np.float32(acc + np.float32(abs(float(d))))
+        want[name] = float(acc)
+    assert sbf == want and sbf != s32
