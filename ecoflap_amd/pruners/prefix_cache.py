@@ -21,6 +21,14 @@ perturbed through the optional `begin_layer(name)` hook.
 import torch
 
 
+def _sync_timed(stats):
+    """torch.cuda.synchronize(), its wall time added to stats["host_blocked_seconds"]."""
+    import time
+    t0 = time.time()
+    torch.cuda.synchronize()
+    stats["host_blocked_seconds"] = stats.get("host_blocked_seconds", 0.0) + time.time() - t0
+
+
 def _vision_language_result(state):
     return state["loss"]
 
@@ -136,7 +144,8 @@ class PrefixCachedLoss:
     into the parameter's own storage instead of re-pointing `param.data`."""
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
-                 two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries"):
+                 two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries",
+                 group_batch=4, assume_not_invariant=()):
         self.model = model
         self.use_graphs = bool(use_graphs)
         # eval_batch = k > 1 (graphs only): k evaluations of a layer (theta+/theta- of k/2 units)
@@ -149,6 +158,16 @@ class PrefixCachedLoss:
         # whole-tensor comparison of a few hundred values can agree by luck); "first": 4 chunks
         assert verify_batched in ("first", "entries", "all")
         self.verify_batched = verify_batched
+        # group_batch = g (1 < g < k): stages between the owning stage and the first shared one
+        # that are batch invariant at g concatenated evaluations (measured: the EVA ViT-g blocks at
+        # 4, not at 8 or 16) run once per GROUP of g evaluations instead of once per evaluation
+        self.group_batch = int(group_batch) if (self.use_graphs and group_batch) else 0
+        # stage-name prefixes treated as NOT shareable at k whatever the probe finds (always safe:
+        # it only moves work from the shared pass to the per-evaluation / per-group part; the
+        # tests use it to drive the group path on toy shapes, where everything is invariant)
+        self.assume_not_invariant = tuple(assume_not_invariant)
+        self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
+        self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
         self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
         # both guards are per batch-shape FAMILY: which library kernel a GEMM gets (Stream-K,
         # split-K) depends on M/N/K, so invariance measured at one shape says nothing about another
@@ -353,20 +372,30 @@ class PrefixCachedLoss:
                 ins.append(self.plan[entry][2](st))
             while len(ins) < k:
                 ins.append(ins[-1])
-            for j in range(entry + 1, n - 1):
-                outs = [self.plan[j][2](x) for x in ins]
-                both = self.plan[j][2](_cat_states(ins, B))
-                same = True
-                for i, o in enumerate(outs):
-                    got = _slice_state(both, i, B, k)
+            g = self.group_batch if 1 < self.group_batch < k else 0
+
+            def slots_equal(both, outs_, width):
+                flat_a = []
+                for i, o in enumerate(outs_):
+                    got = _slice_state(both, i, B, width)
                     flat_a, flat_b = [], []
                     _map_tensors(o, lambda t: flat_a.append(t) or t)
                     _map_tensors(got, lambda t: flat_b.append(t) or t)
                     if len(flat_a) != len(flat_b) or not all(
                             a.shape == b_.shape and torch.equal(a, b_) for a, b_ in zip(flat_a, flat_b)):
-                        same = False
-                        break
+                        return False, flat_a
+                return True, flat_a
+
+            for j in range(entry + 1, n - 1):
+                outs = [self.plan[j][2](x) for x in ins]
+                same, flat_a = slots_equal(self.plan[j][2](_cat_states(ins, B)), outs, k)
+                if self.plan[j][0].startswith(self.assume_not_invariant or ("\0",)):
+                    same = False
                 self.invariant[(self._fam, k, j)] = same
+                if g:        # the same question for groups of g (first and last group of the chunk)
+                    ok_g = all(slots_equal(self.plan[j][2](_cat_states(ins[a:a + g], B)),
+                                           outs[a:a + g], g)[0] for a in (0, k - g))
+                    self.invariant[(self._fam, g, j)] = ok_g
                 if same and sum(t.numel() for t in flat_a) < 65536 and self.verify_batched != "all":
                     # too few values for one comparison to rule out a lucky agreement (toy
                     # shapes): fall back to checking every chunk against the sequential losses
@@ -375,7 +404,11 @@ class PrefixCachedLoss:
                 ins = outs
         self.stats["invariance_probes"] = self.stats.get("invariance_probes", 0) + 1
         self.stats["stages_not_batch_invariant"] = sorted(
-            {self.plan[j][0] for (_, _, j), ok in self.invariant.items() if not ok})
+            {self.plan[j][0] for (_, kk, j), ok in self.invariant.items()
+             if not ok and kk == self.eval_batch})
+        self.stats["stages_invariant_in_groups"] = len(
+            {j for (_, kk, j), ok in self.invariant.items() if ok and kk == self.group_batch
+             and not self.invariant.get((self._fam, self.eval_batch, j), False)})
 
     def _batch_from(self, entry, evals, states, B):
         """First stage S > entry such that S..n-2 are all batch invariant (None: nothing to share)."""
@@ -433,7 +466,25 @@ class PrefixCachedLoss:
         main = torch.cuda.current_stream()
         for lane in lanes:
             lane.stream.wait_stream(main)        # K1's theta and the previous pass are complete
-        for i, ((samples, theta), (_, st)) in enumerate(zip(evals, states)):
+        # stages entry+1 .. R-1: batch invariant in groups of g evaluations (not at k)
+        g = self.group_batch if 1 < self.group_batch < k else 0
+        R = entry + 1
+        if g and captured:
+            while R < S and self.invariant.get((self._fam, g, R), False):
+                R += 1
+        used_groups = R > entry + 1
+        if used_groups:
+            slot_in = bchain.graphs[S][1]
+            todo = list(enumerate(zip(evals, states)))
+            for gi, a in enumerate(range(0, len(todo), g)):
+                lane = lanes[gi % (len(lanes) + 1) - 1] if (lanes and gi % (len(lanes) + 1)) else None
+                items = [(i, theta, st) for i, ((_, theta), (_, st)) in todo[a:a + g]]
+                self._run_group(lane, entry, R, S, items, slot_in, B)
+            self.stats["grouped_evals"] = self.stats.get("grouped_evals", 0) + len(evals)
+            evals_iter = []
+        else:
+            evals_iter = list(enumerate(zip(evals, states)))
+        for i, ((samples, theta), (_, st)) in evals_iter:
             lane = lanes[i % (len(lanes) + 1) - 1] if (lanes and i % (len(lanes) + 1)) else None
             if lane is not None:
                 out = lane.run_prefix(entry, S, st, self._pair_name, theta)
@@ -490,16 +541,91 @@ class PrefixCachedLoss:
             else:
                 sel = list(range(len(evals)))
             want = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
+            import time
+            t_chk = time.time()
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))   # one sync
+            self.stats["host_blocked_seconds"] = (self.stats.get("host_blocked_seconds", 0.0)
+                                                  + time.time() - t_chk)
             self.stats["batched_checks"] = self.stats.get("batched_checks", 0) + 1
             if not same:
                 if os.environ.get("ECOFLAP_DEBUG_BATCHED"):
                     print("batched mismatch at", self.plan[entry][0], "S", S,
                           [float(losses[i]) for i in sel], [float(x) for x in want], flush=True)
+                if used_groups:
+                    # the group path first: the shared pass has its own record of clean checks
+                    self.stats["grouping_disabled_at"] = self.plan[entry][0]
+                    self.group_batch = 0
+                    self._verified.discard((self._fam, entry, S))     # re-check without groups
+                    return self._sequential(model, evals, cuda_enabled)
                 self.stats["batched_disabled_at"] = self.plan[entry][0]
                 self.eval_batch = 1
                 return self._sequential(model, evals, cuda_enabled)
         return losses
+
+    def _run_group(self, lane, entry, R, S, items, slot_in, B):
+        """items = [(slot, theta, state)] (at most g): the owning stage per evaluation (its theta
+        in the parameter's storage), stages entry+1..R-1 ONCE on the group's concatenated states
+        (batch g*B graphs), stages R..S-1 per evaluation again (not invariant in groups: the
+        Q-Former bridge), each result into its slot of the shared pass's input.  lane None = the
+        model itself on the current stream; otherwise a replica on its own stream.  The first use
+        of a (lane, entry, R, S) captures with the device quiescent."""
+        g = self.group_batch
+        fam = self._fam
+        if lane is None:
+            chain, home, stream = self.chain, self._pair_home, None
+            gch = self.gchains.get((fam, g))
+            if gch is None:
+                gch = self.gchains[(fam, g)] = _StageGraphs(self, self.plan, stream=None)
+            plan = self.plan
+        else:
+            chain, home, stream = lane.chain, lane.params[self._pair_name].data, lane.stream
+            gch = lane.group_chain((fam, g))
+            plan = lane.plan
+        key = (id(lane), fam, entry, R, S)
+        ready = key in self._group_ready
+
+        def body():
+            if not ready and (entry + 1) not in gch.graphs:
+                # once per chain: eager pass at the group's batch (library handles, workspaces),
+                # then the captures below
+                outs = []
+                for _, theta, st in items:
+                    home.copy_(theta)
+                    outs.append(_map_tensors(chain.run_stage(entry, st), lambda t: t.clone()))
+                while len(outs) < g:
+                    outs.append(outs[-1])
+                cat = _cat_states(outs, B)
+                with torch.no_grad():
+                    x = cat
+                    for j in range(entry + 1, R):
+                        x = plan[j][2](x)
+                gch.ensure(entry + 1, cat, stop=R)
+            for pos, (_, theta, st) in enumerate(items):
+                home.copy_(theta)
+                _copy_slot(gch.graphs[entry + 1][1], chain.run_stage(entry, st), pos, B)
+            mid = gch.replay(entry + 1, None, stop=R)
+            for pos, (slot, _, _) in enumerate(items):
+                x = _slice_state(mid, pos, B, g)
+                if S > R:
+                    x = chain.replay(R, x, stop=S)
+                _copy_slot(slot_in, x, slot, B)
+
+        if ready:
+            if stream is None:
+                body()
+            else:
+                with torch.cuda.stream(stream):
+                    body()
+            return
+        _sync_timed(self.stats)
+        if stream is None:
+            with torch.no_grad():
+                body()
+        else:
+            with torch.cuda.stream(stream), torch.no_grad():
+                body()
+        _sync_timed(self.stats)
+        self._group_ready.add(key)
 
     def pair(self, model, samples, cuda_enabled, theta_plus, theta_minus):
         return self.multi(model, [(samples, theta_plus, theta_minus)], cuda_enabled)[0]
@@ -629,6 +755,12 @@ class _Lane:
         self.fam = None
         self.warmed = False
         self.prepared = set()
+        self.gchains = {}
+
+    def group_chain(self, key):
+        if key not in self.gchains:
+            self.gchains[key] = _StageGraphs(self.owner, self.plan, stream=self.stream)
+        return self.gchains[key]
 
     def use_family(self, fam):
         if fam not in self.chains:
@@ -648,7 +780,7 @@ class _Lane:
         if (self.fam, entry, S) in self.prepared:
             with torch.cuda.stream(self.stream):
                 return go()
-        torch.cuda.synchronize()
+        _sync_timed(self.owner.stats)
         with torch.cuda.stream(self.stream), torch.no_grad():
             if not self.warmed:                    # once: eager pass on this stream
                 self.warmed = True
@@ -658,7 +790,7 @@ class _Lane:
                     out = self.plan[j][2](out)
                 self.stream.synchronize()
             out = go()
-        torch.cuda.synchronize()
+        _sync_timed(self.owner.stats)
         self.prepared.add((self.fam, entry, S))
         return out
 

@@ -621,7 +621,8 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_toy
     res = []
-    for mode in ("full", "suffix", "graph", "graph2", "graph4", "batched4", "batched8x2"):
+    for mode in ("full", "suffix", "graph", "graph2", "graph4", "batched4", "batched8x2",
+                 "grouped8x2", "grouped8"):
         torch.manual_seed(0)
         model = blip2_toy(fp32=fp32).eval().to("cuda")
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
@@ -638,7 +639,16 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
                 "batched4": PrefixCachedLoss(model, use_graphs=True, eval_batch=4,
                                              verify_batched="all"),
                 "batched8x2": PrefixCachedLoss(model, use_graphs=True, eval_batch=8, n_lanes=2,
-                                               verify_batched="all")}[mode]
+                                               verify_batched="all"),
+                # ViT stages (and the bridge) declared not shareable at 8: they run once per
+                # GROUP of 4 evaluations where the probe finds them invariant at 4, per
+                # evaluation otherwise — on both lanes / on one
+                "grouped8x2": PrefixCachedLoss(model, use_graphs=True, eval_batch=8, n_lanes=2,
+                                               verify_batched="all", group_batch=4,
+                                               assume_not_invariant=("visual_encoder", "bridge")),
+                "grouped8": PrefixCachedLoss(model, use_graphs=True, eval_batch=8, n_lanes=1,
+                                             verify_batched="all", group_batch=2,
+                                             assume_not_invariant=("visual_encoder",))}[mode]
         np.random.seed(3)
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=kern, z_source="philox")
@@ -646,9 +656,14 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
         res.append((ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
         if mode.startswith("graph"):
             assert loss.stats["graph_replays"] > 100 and loss.stats["graph_captures"] >= 4
-        if mode.startswith("batched"):      # the shared suffix ran batched (or the guard fell back)
+        if mode.startswith("batched") or mode.startswith("grouped"):
+            # the shared suffix ran batched (or the guard fell back)
             assert loss.stats.get("batched_evals", 0) > 0, loss.stats
             assert loss.stats.get("invariance_probes", 0) >= 1
+        if mode.startswith("grouped"):
+            # (on toy tensors the probe can be lucky; the every-chunk check then switches the
+            # group path off — the tables below are exact either way)
+            assert loss.stats.get("grouped_evals", 0) > 0, loss.stats
     for other in res[1:]:
         assert np.array_equal(res[0][0], other[0])
         assert res[0][1] == other[1]
@@ -901,9 +916,9 @@ def test_upop_graph_replay_equals_full_forward(kern, golden_dir, tag):
         assert torch.equal(v, res[False][1][k]), k
 
 
-@pytest.mark.parametrize("k_evals", [8, 16])
-def test_batched_suffix_is_exact_at_full_size(kern, k_evals):
-    """BLIP-2 shape at BASELINE size, four matrices (two ViT-g, two FlanT5): evaluating 8 / 16
+@pytest.mark.parametrize("k_evals,lanes", [(8, 1), (16, 1), (16, 2)])
+def test_batched_suffix_is_exact_at_full_size(kern, k_evals, lanes):
+    """BLIP-2 shape at BASELINE size, six matrices (four ViT-g, two FlanT5): evaluating 8 / 16
     perturbations per pass with the batch-invariant part of the suffix shared (FlanT5 stages on
     this system; the probe decides) gives the same loss table, bit for bit, as one suffix per
     evaluation; the guard never fires."""
@@ -921,13 +936,13 @@ def test_batched_suffix_is_exact_at_full_size(kern, k_evals):
                                    device=dev)
     names = [k for k, v in model.named_parameters()
              if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
-    pick = [names[60], names[61], names[300], names[500]]
+    pick = [names[60], names[61], names[62], names[63], names[300], names[500]]   # 4 ViT-g, 2 FlanT5
     init = {k: dict(model.named_parameters())[k].data.clone() for k in pick}
     tables = {}
     for mode in ("sequential", "batched"):
         for k in pick:
             dict(model.named_parameters())[k].data.copy_(init[k])
-        loss = PrefixCachedLoss(model, use_graphs=True, n_lanes=1,
+        loss = PrefixCachedLoss(model, use_graphs=True, n_lanes=lanes if mode == "batched" else 1,
                                 eval_batch=k_evals if mode == "batched" else 1,
                                 verify_batched="all")
         np.random.seed(11)
@@ -936,10 +951,14 @@ def test_batched_suffix_is_exact_at_full_size(kern, k_evals):
         ls.return_sparsity()
         tables[mode] = ls.loss_table.copy()
         if mode == "batched":
-            assert loss.stats.get("batched_evals", 0) >= 48, loss.stats
+            assert loss.stats.get("batched_evals", 0) >= 64, loss.stats
             assert "batched_disabled_at" not in loss.stats, loss.stats
             bad = loss.stats.get("stages_not_batch_invariant", [])
             assert not any(b.startswith("t5_model") for b in bad), bad
+            # the ViT-g blocks are not shareable at 8 / 16 on this system but are in groups of 4:
+            # the two ViT matrices' evaluations ran grouped
+            assert loss.stats.get("grouped_evals", 0) >= k_evals, loss.stats
+            assert "grouping_disabled_at" not in loss.stats, loss.stats
     assert np.array_equal(tables["sequential"], tables["batched"])
 
 
