@@ -27,6 +27,7 @@ EXPORTS = [
     "ecoflap_wanda_prune_matrix", "ecoflap_wanda_block_workspace_bytes", "ecoflap_wanda_prune_block",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
+    "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_count_zeros_multi",
 ]
@@ -96,6 +97,9 @@ def load_library():
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
+    lib.ecoflap_hessian_workspace_bytes.restype = sz
+    lib.ecoflap_hessian_workspace_bytes.argtypes = [i64, i64]
+    lib.ecoflap_hessian_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
     lib.ecoflap_allocate_sparsity.argtypes = [vp, vp, ci, i64, f64, vp, vp]
     _lib = lib
     return lib
@@ -153,6 +157,7 @@ class HipKernels:
         self.lib = load_library()
         self.ws = Workspace()
         self.k6_ws = Workspace(zeroed=True)
+        self.hess_ws = Workspace()
 
     # ---- K1 ---------------------------------------------------------------------------
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
@@ -408,6 +413,21 @@ class HipKernels:
             "ecoflap_sparsegpt_block")
 
     # ---- K8 ---------------------------------------------------------------------------
+    def hessian_accum(self, H, x2d, nsamples_before, batch):
+        """H <- n/(n+b) H + 2/(n+b) x^T x on the matrix cores (fp16 / bf16 x, fp32 H)."""
+        _gpu(H, "H")
+        _gpu(x2d, "x")
+        if H.dtype != torch.float32 or x2d.dtype not in (torch.float16, torch.bfloat16):
+            raise EcoflapHipError("hessian_accum: H fp32, x fp16 / bf16")
+        tokens, cols = x2d.shape
+        if tuple(H.shape) != (cols, cols):
+            raise EcoflapHipError("hessian_accum: H must be [cols, cols]")
+        nb = self.lib.ecoflap_hessian_workspace_bytes(tokens, cols)
+        ws = self.hess_ws.get(nb, x2d.device)
+        _check(self.lib.ecoflap_hessian_accum(
+            _ptr(H), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype], int(nsamples_before),
+            int(batch), _ptr(ws), ws.numel(), _stream()), "ecoflap_hessian_accum")
+
     def mask_mul(self, g, keep_mask):
         _gpu(g, "g")
         _gpu(keep_mask, "keep_mask")

@@ -5,8 +5,9 @@ Host-side mirror of LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:
   T5 / VIT / BLIPT5 LayerSparseGPTPruner (:226-963): same block-sequential loop as the Wanda
   pruners with SparseGPT in place of WrappedGPT; registered names kept.
 
-The Hessian update and the trailing update are plain GEMMs (torch.addmm -> hipBLASLt) and the
-factorisations are rocSOLVER calls; the per-block threshold + sequential sweep, which torch
+The Hessian update of fp16 / bf16 activations is a hand-written MFMA SYRK
+(`ecoflap_hessian_accum`, csrc/syrk.hip; fp32 activations and the trailing update are plain
+library GEMMs, torch.addmm -> hipBLASLt) and the factorisations are rocSOLVER calls; the per-block threshold + sequential sweep, which torch
 runs as ~1000 small kernels per 128 columns, is one fused HIP step
 (`ecoflap_sparsegpt_block`, csrc/sparsegpt.hip).
 """
@@ -21,6 +22,8 @@ from .wanda import BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPrun
 
 
 class SparseGPT:
+    use_mfma_hessian = True     # False: the reference's fp32 expression through the library GEMM
+
     def __init__(self, layer, kernels=None):
         self.layer = layer
         self.dev = self.layer.weight.device
@@ -39,6 +42,14 @@ class SparseGPT:
             inp = inp.unsqueeze(0)
         tmp = inp.shape[0]
         x = inp.reshape((-1, inp.shape[-1]))
+        if (self.use_mfma_hessian and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+                and hasattr(self.kernels, "hessian_accum")):
+            # fp16 / bf16 activations (the forward under autocast): beta*H + alpha*x^T x on the
+            # matrix cores, upper triangle once (csrc/syrk.hip)
+            self.kernels.hessian_accum(self.H, x if x.is_contiguous() else x.contiguous(),
+                                       self.nsamples, tmp)
+            self.nsamples += tmp
+            return
         self.H *= self.nsamples / (self.nsamples + tmp)
         self.nsamples += tmp
         xs = math.sqrt(2 / self.nsamples) * x.float()

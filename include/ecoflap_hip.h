@@ -240,6 +240,21 @@ int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hi
                             const uint8_t* mask_in, float* err_out, uint8_t* mask_out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* SparseGPT Hessian accumulation, the path's one GEMM-shaped
+ * contraction, on the matrix cores:
+ * replaces SparseGPT.add_batch   LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:71-82
+ *     H *= n/(n+b); n += b; inp = sqrt(2/n) * x.float().t(); H += inp @ inp.t()
+ * as  H <- (n/(n+b)) * H + (2/(n+b)) * X^T X  with X = [tokens, cols] of fp16 / bf16 (the
+ * Linear's input as the forward produced it under autocast; an fp32 X returns ECOFLAP_EDTYPE:
+ * the caller keeps the library GEMM for it), fp32 accumulation in v_mfma_f32_32x32x16_*,
+ * upper-triangle tiles computed once and mirrored.  H: float[cols, cols], both triangles kept.
+ * Agreement with the reference's fp32 expression: 1e-5 relative (products are exact, the sums
+ * re-associate). */
+size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols);
+int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, int64_t cols,
+                          int dtype, int64_t nsamples_before, int64_t batch,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * "Real-*" global iterative pruning
  * replaces, in layer_single_base_pruner.py:156-245 / :446-471, the per-element accumulator

@@ -83,6 +83,27 @@ def main():
         med, mn = timed(fn, sets, fresh=True)
         res.append((f"K7 {mode} block", name, nbytes, med, mn))
         del wsets
+    # SparseGPT Hessian (MFMA SYRK): flops against the dense fp16 / bf16 peak
+    flops_rows = []
+    for name, tokens, cols, dt in [("vit fc2 input [2056, 6144] fp16", 8 * 257, 6144, torch.float16),
+                                   ("vit qkv input [2056, 1408] fp16", 8 * 257, 1408, torch.float16),
+                                   ("t5 wo input [384, 5120] bf16", 384, 5120, torch.bfloat16)]:
+        xs = [torch.randn(tokens, cols, device="cuda").to(dt) for _ in range(3)]
+        H = torch.zeros(cols, cols, device="cuda")
+        med, mn = timed(lambda i: kern.hessian_accum(H, xs[i], 8 * i, 8), 3)
+        nt = -(-cols // 128)
+        flops = 2.0 * tokens * 128 * 128 * nt * (nt + 1) / 2        # tiles actually computed
+        flops_rows.append((name, flops, med))
+        import math
+        xf = [x.float() for x in xs]
+        def ref(i):
+            H.mul_(0.5)
+            H.addmm_(xf[i].t(), xf[i])
+        medr, _ = timed(ref, 3)
+        flops_rows.append((name + " (torch fp32 addmm, full square)", 2.0 * tokens * cols * cols, medr))
+    for name, flops, med in flops_rows:
+        print(f"{'Hessian SYRK':14s} {name:52s} {flops/1e9:8.1f} GFLOP  median {med:8.1f} us  "
+              f"{flops/med/1e6:7.1f} TFLOP/s ({flops/med/1e6/2500*100:5.1f}% of 2.5 PFLOP/s dense)")
     for k, name, nbytes, med, mn in res:
         print(f"{k:14s} {name:24s} {nbytes/1e6:8.1f} MB  median {med:8.1f} us  min {mn:8.1f} us  "
               f"{nbytes/med/1e3:7.0f} GB/s ({nbytes/med/1e3/80:5.1f}% of 8 TB/s)")
