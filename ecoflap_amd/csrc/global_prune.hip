@@ -201,10 +201,30 @@ static __device__ __forceinline__ void gp_resolve(const GlobalSelState* st, int 
 
 // NOTE: a histogram bin can receive more than 2^32 hits only if > 4 G scores share 11 leading
 // bits; the host rejects totals >= 2^32 per launch group instead (see below).
+// get_mask's protection step (:160-167): per layer, the scores >= its num_to_set-th largest are
+// raised to finfo.max before the global threshold is taken.  `protect[layer]` is that per-layer
+// threshold as an order-preserving key (GP_NO_PROTECT: none); it comes from a first, PER-LAYER
+// run of the same three histogram passes (`ranks` != null: one selection state and one rank per
+// layer, rank 0 = layer skipped).
+#define GP_NO_PROTECT 0xffffffffu
+#define GP_KEY_FLT_MAX 0xff7fffffu        // gp_key(FLT_MAX)
+
+static __device__ __forceinline__ uint32_t gp_protected_key(uint32_t b, uint32_t prot) {
+    return (prot != GP_NO_PROTECT && b >= prot) ? GP_KEY_FLT_MAX : b;
+}
+
 template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void gp_hist_kernel(const int64_t* __restrict__ table,
                                                       float n_batches, unsigned long long rank0,
-                                                      GlobalSelState* st) {
+                                                      GlobalSelState* st,
+                                                      const unsigned long long* __restrict__ ranks,
+                                                      const uint32_t* __restrict__ protect) {
+    if (ranks) {                              // per-layer selection
+        rank0 = ranks[blockIdx.y];
+        if (rank0 == 0) return;
+        st += blockIdx.y;
+    }
+    const uint32_t prot = protect ? protect[blockIdx.y] : GP_NO_PROTECT;
     constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
     constexpr int BITS = PASS == 2 ? 10 : 11;
     constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
@@ -225,12 +245,14 @@ __global__ __launch_bounds__(256) void gp_hist_kernel(const int64_t* __restrict_
         load8_u8(r.mask, v, mv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint32_t b = gp_key(gp_score_v<MODE>(wv[e], MODE == 3 ? 0.0f : av[e], n_batches, mv[e]));
+            const uint32_t b = gp_protected_key(
+                gp_key(gp_score_v<MODE>(wv[e], MODE == 3 ? 0.0f : av[e], n_batches, mv[e])), prot);
             if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
         }
     }
     for (int64_t i = ng * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
-        const uint32_t b = gp_key(gp_score<MODE>(load_any(r.w, i, r.dt), r.acc, i, n_batches, r.mask[i]));
+        const uint32_t b = gp_protected_key(
+            gp_key(gp_score<MODE>(load_any(r.w, i, r.dt), r.acc, i, n_batches, r.mask[i])), prot);
         if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
     }
     __syncthreads();
@@ -238,15 +260,33 @@ __global__ __launch_bounds__(256) void gp_hist_kernel(const int64_t* __restrict_
         if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
 }
 
+// per-layer thresholds of the protection step, as keys (rank 0: GP_NO_PROTECT)
+__global__ __launch_bounds__(256) void gp_layer_keys_kernel(const GlobalSelState* st,
+                                                            const unsigned long long* __restrict__ ranks,
+                                                            uint32_t* __restrict__ keys) {
+    __shared__ uint32_t wave4[4];
+    __shared__ unsigned long long out2[2];
+    const unsigned long long rank = ranks[blockIdx.x];
+    if (rank == 0) {                          // block-uniform
+        if (threadIdx.x == 0) keys[blockIdx.x] = GP_NO_PROTECT;
+        return;
+    }
+    uint32_t key;
+    gp_resolve(st + blockIdx.x, 3, rank, wave4, out2, key);
+    if (threadIdx.x == 0) keys[blockIdx.x] = key;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict__ table,
                                                        float n_batches, unsigned long long rank0,
-                                                       const GlobalSelState* st) {
+                                                       const GlobalSelState* st,
+                                                       const uint32_t* __restrict__ protect) {
     __shared__ uint32_t wave4[4];
     __shared__ unsigned long long out2[2];
     uint32_t thres_bits;
     gp_resolve(st, 3, rank0, wave4, out2, thres_bits);
     const float thres = gp_unkey(thres_bits);
+    const uint32_t prot = protect ? protect[blockIdx.y] : GP_NO_PROTECT;
     const GpRow r = gp_row(table, blockIdx.y);
     void* w = (void*)r.w;
     uint8_t* mask = (uint8_t*)r.mask;
@@ -262,7 +302,8 @@ __global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict
         mo[1] = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float sc = gp_score_v<MODE>(wv[e], MODE == 3 ? 0.0f : av[e], n_batches, mv[e]);
+            float sc = gp_score_v<MODE>(wv[e], MODE == 3 ? 0.0f : av[e], n_batches, mv[e]);
+            if (prot != GP_NO_PROTECT && gp_key(sc) >= prot) sc = 3.4028234663852886e38f;   // finfo.max
             const bool keep = sc > thres;
             mo[e >> 2] |= (keep ? 1u : 0u) << (8 * (e & 3));
             wv[e] = wv[e] * (keep ? 1.0f : 0.0f);
@@ -272,7 +313,8 @@ __global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict
     }
     for (int64_t i = ng * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) {
         const float wv = load_any(w, i, r.dt);
-        const float s = gp_score<MODE>(wv, r.acc, i, n_batches, mask[i]);
+        float s = gp_score<MODE>(wv, r.acc, i, n_batches, mask[i]);
+        if (prot != GP_NO_PROTECT && gp_key(s) >= prot) s = 3.4028234663852886e38f;
         const bool keep = s > thres;                      // masks[k] = (v > threshold)   (:180)
         mask[i] = keep ? 1 : 0;
         // v.data *= masks[k]  (:231): a product, so a pruned negative weight becomes -0
@@ -281,6 +323,31 @@ __global__ __launch_bounds__(256) void gp_apply_kernel(const int64_t* __restrict
 }
 
 extern "C" size_t ecoflap_global_prune_workspace_bytes(void) { return sizeof(GlobalSelState); }
+
+// with the protection step: [global state][per-layer states][per-layer keys]
+extern "C" size_t ecoflap_global_prune_protected_workspace_bytes(int n_layers) {
+    if (n_layers <= 0) return 0;
+    return sizeof(GlobalSelState) * ((size_t)n_layers + 1) + (((size_t)n_layers * 4 + 255) / 256) * 256;
+}
+
+static int gp_run(const int64_t* table, int n_layers, int mode, float n_batches,
+                  unsigned long long rank0, GlobalSelState* st,
+                  const unsigned long long* ranks, const uint32_t* protect, bool apply,
+                  hipStream_t s) {
+    const dim3 grid(GP_SLICES, (unsigned)n_layers), blk(256);
+#define GP_RUN(MODE)                                                                        \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 0>), grid, blk, 0, s, table, n_batches, rank0, st, ranks, protect); \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 1>), grid, blk, 0, s, table, n_batches, rank0, st, ranks, protect); \
+    hipLaunchKernelGGL((gp_hist_kernel<MODE, 2>), grid, blk, 0, s, table, n_batches, rank0, st, ranks, protect); \
+    if (apply) hipLaunchKernelGGL((gp_apply_kernel<MODE>), grid, blk, 0, s, table, n_batches, rank0, st, protect)
+    if (mode == 0) { GP_RUN(0); }
+    else if (mode == 1) { GP_RUN(1); }
+    else if (mode == 2) { GP_RUN(2); }
+    else { GP_RUN(3); }
+#undef GP_RUN
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 // table: device int64[n_layers][5] rows {w_ptr, acc_ptr(float), mask_ptr(uint8), numel, dtype};
 // k: rank (1-indexed) of the threshold among all scores = num_to_zero_out (:173).
@@ -297,20 +364,35 @@ extern "C" int ecoflap_global_threshold_prune(const int64_t* table, int n_layers
     GlobalSelState* st = (GlobalSelState*)workspace;
     hipError_t e = hipMemsetAsync(st, 0, sizeof(GlobalSelState), s);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(GP_SLICES, (unsigned)n_layers), blk(256);
-    const unsigned long long rank0 = (unsigned long long)k;
-#define GP_RUN(MODE)                                                                        \
-    hipLaunchKernelGGL((gp_hist_kernel<MODE, 0>), grid, blk, 0, s, table, n_batches, rank0, st); \
-    hipLaunchKernelGGL((gp_hist_kernel<MODE, 1>), grid, blk, 0, s, table, n_batches, rank0, st); \
-    hipLaunchKernelGGL((gp_hist_kernel<MODE, 2>), grid, blk, 0, s, table, n_batches, rank0, st); \
-    hipLaunchKernelGGL((gp_apply_kernel<MODE>), grid, blk, 0, s, table, n_batches, rank0, st)
-    if (mode == 0) { GP_RUN(0); }
-    else if (mode == 1) { GP_RUN(1); }
-    else if (mode == 2) { GP_RUN(2); }
-    else { GP_RUN(3); }
-#undef GP_RUN
+    return gp_run(table, n_layers, mode, n_batches, (unsigned long long)k, st, nullptr, nullptr, true, s);
+}
+
+// The same with get_mask's protection step (:160-167).  protect_ranks: device int64[n_layers],
+// per layer the 1-indexed rank FROM THE SMALLEST of its threshold score, i.e.
+// numel - num_to_set + 1 with num_to_set = int(numel * (1 - max_sparsity_per_layer)); 0 = the
+// layer protects nothing.  Scores >= that threshold count as finfo.max in the global selection.
+extern "C" int ecoflap_global_threshold_prune_protected(const int64_t* table, int n_layers, int mode,
+                                                        float n_batches, int64_t k,
+                                                        int64_t total_numel,
+                                                        const int64_t* protect_ranks,
+                                                        void* workspace, size_t workspace_bytes,
+                                                        void* stream) {
+    if (mode < 0 || mode > 3) return ECOFLAP_EMODE;
+    if (n_layers <= 0 || k < 1 || k > total_numel) return ECOFLAP_ESIZE;
+    if (total_numel >= (int64_t)0xffffffffLL) return ECOFLAP_ESIZE;
+    if (!table || !workspace || !protect_ranks) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_global_prune_protected_workspace_bytes(n_layers)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    GlobalSelState* st = (GlobalSelState*)workspace;             // [0] global, [1..] per layer
+    uint32_t* keys = (uint32_t*)(st + n_layers + 1);
+    hipError_t e = hipMemsetAsync(st, 0, sizeof(GlobalSelState) * ((size_t)n_layers + 1), s);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long* ranks = (const unsigned long long*)protect_ranks;
+    int rc = gp_run(table, n_layers, mode, n_batches, 0ull, st + 1, ranks, nullptr, false, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gp_layer_keys_kernel, dim3((unsigned)n_layers), dim3(256), 0, s, st + 1, ranks, keys);
     ECO_CHECK_LAUNCH();
-    return 0;
+    return gp_run(table, n_layers, mode, n_batches, (unsigned long long)k, st, nullptr, keys, true, s);
 }
 
 // ---- zeros per layer -------------------------------------------------------------------------

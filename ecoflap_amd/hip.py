@@ -29,7 +29,8 @@ EXPORTS = [
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
     "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
-    "ecoflap_global_threshold_prune", "ecoflap_count_zeros_multi",
+    "ecoflap_global_threshold_prune", "ecoflap_global_prune_protected_workspace_bytes",
+    "ecoflap_global_threshold_prune_protected", "ecoflap_count_zeros_multi",
 ]
 
 
@@ -94,6 +95,9 @@ def load_library():
     lib.ecoflap_grad_accum_multi.argtypes = [vp, ci, vp]
     lib.ecoflap_global_prune_workspace_bytes.restype = sz
     lib.ecoflap_global_threshold_prune.argtypes = [vp, ci, ci, f32, i64, i64, vp, sz, vp]
+    lib.ecoflap_global_prune_protected_workspace_bytes.restype = sz
+    lib.ecoflap_global_prune_protected_workspace_bytes.argtypes = [ci]
+    lib.ecoflap_global_threshold_prune_protected.argtypes = [vp, ci, ci, f32, i64, i64, vp, vp, sz, vp]
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
@@ -369,9 +373,10 @@ class HipKernels:
         _check(self.lib.ecoflap_grad_accum_multi(_ptr(table), len(rows), _stream()),
                "ecoflap_grad_accum_multi")
 
-    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
+    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k, protect_counts=None):
         """One round of get_mask + `W *= mask` over all layers: masks (uint8) and weights are
-        updated in place; k = num_to_zero_out."""
+        updated in place; k = num_to_zero_out.  protect_counts: per layer num_to_set of get_mask's
+        protection step (int(numel * (1 - max_sparsity_per_layer))), None / all 0 = none."""
         if accs is None:             # mode 3: the score is the signed weight itself
             accs = [None] * len(weights)
         rows = [[_gpu(w, "w").data_ptr(), 0 if a is None else _gpu(a, "acc").data_ptr(),
@@ -386,6 +391,16 @@ class HipKernels:
                 f"global threshold over {total} elements: one selection covers at most 2^32 - 2 "
                 "(4 294 967 294) elements (BLIP-2 FlanT5-XL has 3 701 932 032); prune per "
                 "sub-model (prune_per_model) or layer-wise, or split the call")
+        if protect_counts is not None and any(int(c) > 0 for c in protect_counts):
+            ranks = torch.tensor([(r[3] - int(c) + 1) if int(c) > 0 else 0
+                                  for r, c in zip(rows, protect_counts)], dtype=torch.int64, device=dev)
+            nb = self.lib.ecoflap_global_prune_protected_workspace_bytes(len(rows))
+            ws = self.ws.get(nb, dev)
+            _check(self.lib.ecoflap_global_threshold_prune_protected(
+                _ptr(table), len(rows), int(mode), float(n_batches), int(k), int(total),
+                _ptr(ranks), _ptr(ws), ws.numel(), _stream()),
+                "ecoflap_global_threshold_prune_protected")
+            return
         ws = self.ws.get(self.lib.ecoflap_global_prune_workspace_bytes(), dev)
         _check(self.lib.ecoflap_global_threshold_prune(
             _ptr(table), len(rows), int(mode), float(n_batches), int(k), int(total), _ptr(ws),

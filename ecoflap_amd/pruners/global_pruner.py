@@ -65,10 +65,10 @@ class BLIPT5GlobalPruner(LayerWiseBasePruner):
     # ------------------------------------------------------------------ iteration (:162-207)
     def global_iterative_pruning(self, target_sparsity, dict_layers_to_prune, iteratation=1,
                                  max_sparsity_per_layer=1.0):
-        if max_sparsity_per_layer != 1.0:
-            raise NotImplementedError("the reference only passes max_sparsity_per_layer=1.0 (:238), "
-                                      "where get_mask's protection step is a no-op")
         kernels = self._kernels()
+        # get_mask's protection step (:120-127) applies to the global / per-sub-model thresholds,
+        # not to the layer-wise one (get_layerwise_mask, :144-157, has none)
+        layerwise = not getattr(self, "is_global", False)
         names = [k for k, _ in self.model.named_parameters() if k in dict_layers_to_prune]
         params = [v for k, v in self.model.named_parameters() if k in dict_layers_to_prune]
         masks = [torch.ones(p.shape, dtype=torch.uint8, device=p.device) for p in params]
@@ -83,10 +83,13 @@ class BLIPT5GlobalPruner(LayerWiseBasePruner):
                 k = int(p_i * total)                                                   # (:133)
                 if k < 1:
                     raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
+                protect = None
+                if not layerwise and max_sparsity_per_layer != 1.0:
+                    protect = [int(params[j].numel() * (1 - max_sparsity_per_layer)) for j in group]
                 kernels.global_threshold_prune(
                     [params[j].data for j in group],
                     None if accs is None else [accs[j] for j in group],
-                    [masks[j] for j in group], self.score_mode, n_batches, k)
+                    [masks[j] for j in group], self.score_mode, n_batches, k, protect)
             del accs
             print(f"Step {i}, target sparsity: {p_i:.4f}")
         self.stage_stats["global"] = {"seconds": time.time() - t0, "layers": len(names),
@@ -148,9 +151,8 @@ class BLIPT5GlobalMeZoPruner(BLIPT5GlobalPruner):
                                  max_sparsity_per_layer=1.0):
         """One zeroth-order score per matrix (:323-389, the loop of a-3 with eps fixed at 1e-3
         and `self.num_samples`), so get_mask ranks matrices and drops whole ones."""
-        if max_sparsity_per_layer != 1.0:
-            raise NotImplementedError("max_sparsity_per_layer < 1")
         names = [k for k, _ in self.model.named_parameters() if k in dict_layers_to_prune]
+        layerwise = not getattr(self, "is_global", False)
         params = [v for k, v in self.model.named_parameters() if k in dict_layers_to_prune]
         mapping = {k: k for k in names}
         masks = None
@@ -170,6 +172,12 @@ class BLIPT5GlobalMeZoPruner(BLIPT5GlobalPruner):
             masks = {}
             for group in self._threshold_groups(names):
                 sub = {names[j]: scores[names[j]] for j in group}
+                if not layerwise:                      # get_mask's protection step (:120-127) on
+                    for k_, v in sub.items():          # one-element score tensors
+                        num_to_set = int(v.numel() * (1 - max_sparsity_per_layer))
+                        if num_to_set > 0:
+                            thr = torch.topk(v.flatten(), num_to_set, largest=True)[0][-1]
+                            v[torch.where(v >= thr)] = torch.finfo(v.dtype).max
                 all_scores = torch.cat([t.flatten() for t in sub.values()])
                 num_to_zero_out = int(p_i * all_scores.numel())
                 threshold = torch.topk(all_scores, num_to_zero_out, largest=False)[0][-1]

@@ -594,9 +594,6 @@ class LayerSparsity:
         prunable elements -> prune; then the per-parameter zero fractions, weights restored
         (:199-245).  Per-element |g| accumulators (fp32, 14.8 GB for BLIP-2) live in HBM; the
         score is never materialised: the threshold kernels recompute it from (W, acc, mask)."""
-        if max_sparsity_per_layer != 1.0:
-            raise NotImplementedError("the reference only calls this with max_sparsity_per_layer=1.0 "
-                                      "(:324), where get_mask's protection step is a no-op")
         t0 = time.time()
         _, _, world = self._dist()
         names, params = self._select(dict_layers_to_prune)
@@ -609,8 +606,12 @@ class LayerSparsity:
             p_i = target_sparsity ** (iteratation / i)                                # (:213)
             accs, n_batches = self.accumulate_abs_grads(params)    # |g| even for *Square (:452)
             k = int(p_i * total)                                                       # (:173)
+            # get_mask's protection step (:160-167): the top int(numel * (1 - max)) scores of
+            # every layer cannot be pruned (a no-op at the reference's own max = 1.0, :324)
+            protect = [int(p.numel() * (1 - max_sparsity_per_layer)) for p in params]
             self.kernels.global_threshold_prune([p.data for p in params], accs, masks, mode,
-                                                n_batches, k)
+                                                n_batches, k,
+                                                protect if any(c > 0 for c in protect) else None)
             del accs
         model = self.model
         all_names, all_params = [], []

@@ -276,6 +276,15 @@ size_t ecoflap_global_prune_workspace_bytes(void);
 int ecoflap_global_threshold_prune(const int64_t* table, int n_layers, int mode,
                                    float n_batches, int64_t k, int64_t total_numel,
                                    void* workspace, size_t workspace_bytes, void* stream);
+/* The same with get_mask's protection step (:160-167): per layer, scores >= its num_to_set-th
+ * largest (num_to_set = int(numel * (1 - max_sparsity_per_layer))) are raised to finfo.max before
+ * the global threshold is taken.  protect_ranks: device int64[n_layers], the 1-indexed rank from
+ * the smallest of that per-layer threshold (numel - num_to_set + 1; 0 = nothing protected). */
+size_t ecoflap_global_prune_protected_workspace_bytes(int n_layers);
+int ecoflap_global_threshold_prune_protected(const int64_t* table, int n_layers, int mode,
+                                             float n_batches, int64_t k, int64_t total_numel,
+                                             const int64_t* protect_ranks,
+                                             void* workspace, size_t workspace_bytes, void* stream);
 int ecoflap_count_zeros_multi(const int64_t* table, int n_layers, int64_t* out_counts,
                               void* stream);
 

@@ -586,6 +586,49 @@ def golden_real(LayerSparsity, lavis, registry):
     save("g11_real.npz", **out)
 
 
+# --------------------------------------------------------------------------- G14: get_mask protection
+def golden_real_protected(LayerSparsity, lavis):
+    """global_iterative_pruning with max_sparsity_per_layer < 1 (the protection step of get_mask,
+    layer_single_base_pruner.py:160-167, which the reference's own return_sparsity never reaches:
+    it passes 1.0): per-parameter zero fractions."""
+    utils = lavis["utils"]
+    out = {}
+    torch.manual_seed(3)
+    vit = vit_toy().eval()
+    vit_batches = S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5)
+    torch.manual_seed(4)
+    blip = blip2_toy().eval()
+    blip_batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    cases = []
+    for tag, model, batches, loss_fn, prefixes, depth in [
+        ("vit", vit, vit_batches, utils.loss_vision, ["visual"], {"visual": 3}),
+        ("blip2", blip, blip_batches, utils.loss_vision_language,
+         ["t5_model", "visual_encoder"], {"t5_model": 4, "visual_encoder": 3}),
+    ]:
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        for k, v in init.items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        mapping = block_mapping(model, prefixes, depth)
+        out[f"{tag}_names"] = np.array([k for k, _ in model.named_parameters() if k in mapping])
+        all_names = [k for k, _ in model.named_parameters()]
+        out[f"{tag}_all_names"] = np.array(all_names)
+        for method, sparsity, max_sp, iters in [("Real-GradMagAbs_sum", 0.5, 0.7, 3),
+                                                ("Real-GradMagSquare_sum", 0.6, 0.65, 3),
+                                                ("Real-GradOnly_sum", 0.4, 0.9, 2),
+                                                ("Real-GradMagAbs_sum", 0.5, 0.5, 1)]:
+            model.load_state_dict(init)
+            for p in model.parameters():
+                p.requires_grad = True
+            ls = LayerSparsity(model, batches, loss_fn, 8, sparsity, 0.95, method, 1, 1e-3, mapping)
+            sp = ls.global_iterative_pruning(sparsity, mapping, iteratation=iters,
+                                             max_sparsity_per_layer=max_sp)
+            key = f"{tag}|{method}|{sparsity}|{max_sp}|{iters}"
+            cases.append(key)
+            out[key] = np.array([sp[k] for k in all_names], dtype=np.float64)
+    out["cases"] = np.array(cases)
+    save("g14_real_protected.npz", **out)
+
+
 # --------------------------------------------------------------------------- G12: global pruners
 GLOBAL_CASES = {
     # tag: (pruner, is_global, prune_per_model, iteration, keep ratio)
@@ -664,7 +707,8 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # fixed reduction order for the committed vectors
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
-    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global"]
+    only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global",
+                            "protected"]
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:
@@ -685,3 +729,5 @@ if __name__ == "__main__":
         golden_global(registry)
     if "real" in only:
         golden_real(lavis["layer_single_base_pruner"].LayerSparsity, lavis, registry)
+    if "protected" in only:
+        golden_real_protected(lavis["layer_single_base_pruner"].LayerSparsity, lavis)

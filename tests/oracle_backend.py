@@ -88,7 +88,7 @@ class OracleKernels:
         for a, g in zip(accs, grads):
             a += g.detach().float().abs().to(a.device)
 
-    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k):
+    def global_threshold_prune(self, weights, accs, masks, mode, n_batches, k, protect_counts=None):
         scores = []
         if accs is None:
             accs = [None] * len(weights)
@@ -104,6 +104,11 @@ class OracleKernels:
             else:
                 sc = g.abs()
             scores.append(sc * self._host(m).float())
+        if protect_counts is not None:           # get_mask's protection step (:160-167)
+            for sc, num_to_set in zip(scores, protect_counts):
+                if num_to_set > 0:
+                    thr = torch.topk(sc.flatten(), int(num_to_set), largest=True)[0][-1]
+                    sc[torch.where(sc >= thr)] = torch.finfo(sc.dtype).max
         allv = torch.cat([t.flatten() for t in scores])
         thr = torch.topk(allv, k, largest=False)[0][-1]
         for w, m, sc in zip(weights, masks, scores):

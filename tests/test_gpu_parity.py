@@ -884,6 +884,20 @@ def test_real_low_precision_hip_equals_oracle(kern):
     assert 0.2 < sum(vals) / len(vals) < 0.8
 
 
+def test_real_protection_step_hip_equals_reference_golden(kern, golden_dir):
+    """get_mask's protection step (max_sparsity_per_layer < 1) on the HIP kernels: per-layer
+    radix select for the protected set, then the global threshold — zero fractions equal the
+    oracle's (same GPU forward/backward on both sides) exactly, and track the reference's CPU
+    goldens (fp32 batch sums re-associate between CPU and GPU backward passes)."""
+    from oracle_backend import OracleKernels
+    from test_host_parity import protected_cases, run_real_protected
+    for case in protected_cases(golden_dir):
+        got, want = run_real_protected(golden_dir, case, kern, device="cuda")
+        ora, _ = run_real_protected(golden_dir, case, OracleKernels(), device="cuda")
+        assert np.array_equal(got, ora), case
+        assert np.abs(got - want).mean() < 0.01, case
+
+
 def test_real_end_to_end_hip_equals_oracle(kern, golden_dir):
     from oracle_backend import OracleKernels
     from test_host_parity import run_real_e2e

@@ -237,6 +237,39 @@ def test_real_global_iterative_matches_reference(golden_dir, tag, method, sparsi
     assert np.array_equal(got, want)
 
 
+def protected_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g14_real_protected.npz"))
+    return [str(c) for c in g["cases"]]
+
+
+def run_real_protected(golden_dir, case, kernels, device="cpu"):
+    """global_iterative_pruning with max_sparsity_per_layer < 1: get_mask's protection step
+    (layer_single_base_pruner.py:160-167); goldens from the reference's own method."""
+    g = np.load(os.path.join(golden_dir, "g14_real_protected.npz"))
+    tag, method, sparsity, max_sp, iters = case.split("|")
+    model, batches, loss_fn = _setup(tag)
+    load_state(model, g, f"{tag}_init")
+    model.to(device)
+    for p in model.parameters():
+        p.requires_grad = True
+    mapping = {str(n): "g" for n in g[f"{tag}_names"]}
+    ls = LayerSparsity(model, batches, loss_fn, 8, float(sparsity), 0.95, method, 1, 1e-3, mapping,
+                       kernels=kernels)
+    sp = ls.global_iterative_pruning(float(sparsity), mapping, iteratation=int(iters),
+                                     max_sparsity_per_layer=float(max_sp))
+    names = [str(n) for n in g[f"{tag}_all_names"]]
+    return np.array([sp[k] for k in names]), g[case]
+
+
+def test_real_protection_step_matches_reference(golden_dir):
+    for case in protected_cases(golden_dir):
+        got, want = run_real_protected(golden_dir, case, OracleKernels())
+        assert np.array_equal(got, want), case
+        if case.endswith("|0.5|1"):      # max == target: every layer pinned at exactly the target
+            pruned = want[(want > 0) & (want < 1)]
+            assert len(pruned) and np.all(pruned <= 0.5 + 1e-6)
+
+
 def run_real_e2e(golden_dir, kernels, device="cpu"):
     g = np.load(os.path.join(golden_dir, "g11_real.npz"))
     model, batches = build_e2e("vit")
