@@ -362,7 +362,36 @@ def _t5_block_mapping(names, granularity, depth=4):
 
 
 class _StageOneMixin:
+    def _hook_plan(self):
+        """(block ModuleList paths, extra cacheable module paths) for a model without
+        `stage_plan()`: the lists this pruner walks in stage 2, in execution order, plus the
+        model's other direct children (Q-Former, projections, norms ...)."""
+        lists = []
+        for cand in (f"{getattr(self, 'vit_model_prefix', None)}.blocks",
+                     f"{getattr(self, 'model_prefix', None)}.blocks",
+                     f"{getattr(self, 't5_model_prefix', None)}.encoder.block",
+                     f"{getattr(self, 't5_model_prefix', None)}.decoder.block",
+                     f"{getattr(self, 'model_prefix', None)}.encoder.block",
+                     f"{getattr(self, 'model_prefix', None)}.decoder.block"):
+            try:
+                mod = get_module_recursive(self.model, cand)
+            except AttributeError:
+                continue
+            if isinstance(mod, nn.ModuleList) and cand not in lists:
+                lists.append(cand)
+        roots = {p.split(".")[0] for p in lists}
+        extra = [n for n, _ in self.model.named_children() if n not in roots]
+        return lists, extra
+
     def _layer_sparsity(self, loss_func, original_sparsity, mapping, per_model_group=()):
+        if (getattr(self, "prefix_cache", True) and not hasattr(self.model, "stage_plan")
+                and str(self.score_method).startswith("MEZO") and mapping):
+            # un-staged model (the reference's own modules): exact suffix-only re-forward through
+            # forward patches on the block lists (pruners/hooked_prefix.py)
+            lists, extra = self._hook_plan()
+            if lists:
+                from .hooked_prefix import HookedPrefixLoss
+                loss_func = HookedPrefixLoss(self.model, loss_func, lists, extra)
         if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO") and mapping):
             # same losses, bit for bit, from the owning block onwards only

@@ -123,3 +123,79 @@ def test_loss_table_keeps_the_loss_dtype():
             acc = np.float32(acc + np.float32(abs(float(d))))
         want[name] = float(acc)
     assert sbf == want and sbf != s32
+
+
+def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatch):
+    """A model WITHOUT stage_plan() (the reference's own modules swapped in):
+    the hook adapter serves every block-list call before the owning block from its cache and the
+    loss table, sparsity table and drifted weights equal the full-forward run bit for bit —
+    through LayerSparsity directly and through the registered pruner."""
+    import numpy as np
+    import torch
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import Blip2T5, blip2_toy
+
+    plan = Blip2T5.stage_plan
+
+    def forward(self, samples):                      # the same forward ...
+        state = samples
+        for _, _, fn in plan(self):
+            state = fn(state)
+        return state
+
+    monkeypatch.setattr(Blip2T5, "forward", forward)
+    monkeypatch.delattr(Blip2T5, "stage_plan")       # ... on a model with no stage_plan attribute
+
+    def run(hooked):
+        torch.manual_seed(4)
+        model = blip2_toy().eval()
+        assert not hasattr(model, "stage_plan")
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        loss = loss_vision_language
+        if hooked:
+            loss = HookedPrefixLoss(model, loss_vision_language,
+                                    ["visual_encoder.blocks", "t5_model.encoder.block",
+                                     "t5_model.decoder.block"], ["ln_vision", "Qformer", "t5_proj"])
+        np.random.seed(42)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=OracleKernels(), z_source=torch_cpu_normal)
+        sp = ls.return_sparsity()
+        return ls.loss_table, sp, {k: v.clone() for k, v in model.state_dict().items()}, loss
+
+    full = run(False)
+    hooked = run(True)
+    assert np.array_equal(full[0], hooked[0])
+    assert full[1] == hooked[1]
+    for k in full[2]:
+        assert torch.equal(full[2][k], hooked[2][k]), k
+    st = hooked[3].stats
+    assert st["events_served"] > 0.3 * st["events_total"], st      # most block calls came from cache
+
+    def prune(prefix_cache):
+        torch.manual_seed(4)
+        model = blip2_toy().eval()
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+        np.random.seed(42)
+        cfg = dict(t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+                   t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
+                   max_sparsity_per_layer=0.6, num_data_first_stage=8,
+                   sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum",
+                   kernels=OracleKernels(), z_source=torch_cpu_normal)
+        pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg)
+        pruner.prefix_cache = prefix_cache
+        model, table = pruner.prune()
+        return table, {k: v.clone() for k, v in model.state_dict().items()}
+
+    t_full, w_full = prune(False)
+    t_hook, w_hook = prune(True)
+    assert t_full == t_hook
+    for k in w_full:
+        assert torch.equal(w_full[k], w_hook[k]), k
