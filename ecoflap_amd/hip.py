@@ -162,6 +162,7 @@ class HipKernels:
         self.ws = Workspace()
         self.k6_ws = Workspace(zeroed=True)
         self.hess_ws = Workspace()
+        self._pair_tables = {}
 
     # ---- K1 ---------------------------------------------------------------------------
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
@@ -279,11 +280,19 @@ class HipKernels:
                 keep_alive.append(g)
             classes.setdefault((w.dtype, g.dtype), []).append((i, _gpu(w, "w"), _gpu(g, "g")))
         for (dw, dg), items in classes.items():
-            rows = [[w.data_ptr(), g.data_ptr(), w.numel()] for _, w, g in items]
-            table = torch.tensor(rows, dtype=torch.int64, device=out_accum.device)
+            rows = tuple((w.data_ptr(), g.data_ptr(), w.numel()) for _, w, g in items)
+            # the pointer table is the same for every batch when the gradients live in a captured
+            # graph's static buffers: building it afresh is a blocking H2D copy per batch that
+            # stalls the host behind the replay it has just queued
+            cached = self._pair_tables.get((dw, dg))
+            if cached is None or cached[0] != rows or cached[1].device != out_accum.device:
+                cached = (rows,
+                          torch.tensor(rows, dtype=torch.int64, device=out_accum.device),
+                          torch.tensor([i for i, _, _ in items], device=out_accum.device))
+                self._pair_tables[(dw, dg)] = cached
+            _, table, index = cached
             part = torch.zeros(len(items), dtype=torch.float64, device=out_accum.device)
             self.absprod_reduce_multi(table, max(r[2] for r in rows), dw, dg, mode, part)
-            index = torch.tensor([i for i, _, _ in items], device=out_accum.device)
             out_accum.index_add_(0, index, part)
 
     # ---- K6 ---------------------------------------------------------------------------
@@ -368,8 +377,13 @@ class HipKernels:
             if not g.is_contiguous():
                 g = g.contiguous()
                 keep.append(g)
-            rows.append([a.data_ptr(), _gpu(g, "grad").data_ptr(), a.numel(), DTYPE_CODE[g.dtype]])
-        table = torch.tensor(rows, dtype=torch.int64, device=accs[0].device)
+            rows.append((a.data_ptr(), _gpu(g, "grad").data_ptr(), a.numel(), DTYPE_CODE[g.dtype]))
+        rows = tuple(rows)
+        cached = self._pair_tables.get("grad_accum")          # same pointers batch after batch
+        if cached is None or cached[0] != rows or cached[1].device != accs[0].device:
+            cached = (rows, torch.tensor(rows, dtype=torch.int64, device=accs[0].device))
+            self._pair_tables["grad_accum"] = cached
+        table = cached[1]
         _check(self.lib.ecoflap_grad_accum_multi(_ptr(table), len(rows), _stream()),
                "ecoflap_grad_accum_multi")
 
