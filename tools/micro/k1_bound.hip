@@ -7,7 +7,7 @@
 #include <vector>
 
 template <int DT, int MODE>   // 1: VALU only, 2: memory only
-__global__ __launch_bounds__(256) void twin_kernel(void* __restrict__ w, int64_t n, float eps,
+__global__ __launch_bounds__(ECO_K1_THREADS) void twin_kernel(void* __restrict__ w, int64_t n, float eps,
                                                    int n_units, const UnitTable tab, int never) {
     constexpr int N = Vec<DT>::N;
     const int64_t nvec = n / N;
@@ -68,9 +68,9 @@ template <int DT> float run(int mode, void* w, int64_t n, const UnitTable& tab, 
     hipEventCreate(&s); hipEventCreate(&e);
     if (g_heat) hipLaunchKernelGGL(heater, dim3(256 * 8), dim3(256), 0, 0, g_heat_out, g_heat);
     hipEventRecord(s);
-    if (mode == 0) hipLaunchKernelGGL((zo_perturb_units_kernel<DT, false>), dim3(g), dim3(256), 0, 0, w, n, 1e-3f, U, tab);
-    if (mode == 1) hipLaunchKernelGGL((twin_kernel<DT, 1>), dim3(g), dim3(256), 0, 0, w, n, 1e-3f, U, tab, 0);
-    if (mode == 2) hipLaunchKernelGGL((twin_kernel<DT, 2>), dim3(g), dim3(256), 0, 0, w, n, 1e-3f, U, tab, 0);
+    if (mode == 0) hipLaunchKernelGGL((zo_perturb_units_kernel<DT, false>), dim3(g), dim3(ECO_K1_THREADS), 0, 0, w, n, 1e-3f, U, tab);
+    if (mode == 1) hipLaunchKernelGGL((twin_kernel<DT, 1>), dim3(g), dim3(ECO_K1_THREADS), 0, 0, w, n, 1e-3f, U, tab, 0);
+    if (mode == 2) hipLaunchKernelGGL((twin_kernel<DT, 2>), dim3(g), dim3(ECO_K1_THREADS), 0, 0, w, n, 1e-3f, U, tab, 0);
     hipEventRecord(e);
     hipEventSynchronize(e);
     float ms;
@@ -86,7 +86,8 @@ int main(int argc, char** argv) {
     printf("units %d, heater iterations %d\n", U, g_heat);
     const Shape shapes[] = {{"t5_wi_wo bf16", 5120 * 2048, ECOFLAP_BF16}, {"t5_qkvo bf16", 2048 * 2048, ECOFLAP_BF16},
                             {"vit_fc f16", 6144 * 1408, ECOFLAP_F16}, {"vit_qkv f16", 4224 * 1408, ECOFLAP_F16},
-                            {"vit_proj f16", 1408 * 1408, ECOFLAP_F16}};
+                            {"vit_proj f16", 1408 * 1408, ECOFLAP_F16},
+                            {"6144x1408 as bf16", 6144 * 1408, ECOFLAP_BF16}, {"5120x2048 as f16", 5120 * 2048, ECOFLAP_F16}};
     const char* modes[] = {"product", "VALU only", "memory only"};
     for (const Shape& sh : shapes) {
         const size_t bytes = (size_t)sh.n * 2;
