@@ -490,6 +490,18 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
 // per workgroup.  Counts are ballots: v_cmp writes the lane mask, s_bcnt1 counts it on the
 // scalar unit — the bitwise search needs no shuffle, no LDS and no barrier at all.
 // -------------------------------------------------------------------------------------
+// wave-wide sum on the DPP network (row shifts inside the four 16-lane rows, then the two row
+// broadcasts gfx9 has): 6 full-rate adds, no LDS crossbar, result uniform
+static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int DT, int NV>
 __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g) {
     constexpr int N = Vec<DT>::N;
@@ -547,13 +559,15 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
         const int top = mx ? 31 - __builtin_clz(mx) : -1;
         uint32_t prefix = 0;
         for (int bit = top; bit >= 16; --bit) {
+            // per-lane count (compare + add-with-carry, both full-rate VALU), one DPP reduction
+            // per round — instead of a ballot, an s_bcnt1 and an s_add per element
             const uint32_t cand = prefix | (1u << bit);
             uint32_t c = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int i = 0; i < N; ++i) c += (uint32_t)__popcll(__ballot(m[j][i] < cand));
-            if (c < (uint32_t)k) prefix = cand;
+                for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
+            if (wave_sum_dpp(c) < (uint32_t)k) prefix = cand;
         }
         // elements below the 16-bit bucket of the answer, and the bucket's population
         uint32_t less16 = 0, ncand = 0;
