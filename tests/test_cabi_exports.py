@@ -104,3 +104,61 @@ def test_argument_errors_of_the_later_entry_points():
     assert lib.ecoflap_add_layernorm(vp(16), None, vp(16), vp(16), None, vp(16), 4, 12, 1e-6, 1, None) == -3
     assert lib.ecoflap_add_layernorm(vp(16), None, vp(16), vp(16), None, vp(16), 4, 16, 1e-6, 0, None) == -1
     assert lib.ecoflap_add_layernorm(vp(16), vp(16), vp(16), vp(16), None, vp(16), 4, 16, 1e-6, 1, None) == -2
+
+
+def test_argument_errors_of_the_round2_entry_points():
+    """Block-level K7, the MFMA Hessian, the protected global threshold and the timed K1 launch:
+    bad arguments are rejected with the documented codes before anything is launched."""
+    from ecoflap_amd import hip
+    lib = hip.load_library()
+    vp = ctypes.c_void_p
+
+    def items(**kw):
+        arr = (hip.WandaItem * 2)()
+        for a in arr:
+            a.w, a.scaler_row, a.rows, a.cols, a.k, a.mask_out, a.dtype, a.mode = (
+                16, 16, 4, 8, 2, None, 2, hip.WANDA_ROWS)
+        for k, v in kw.items():
+            setattr(arr[1], k, v)
+        return arr
+
+    ok = items()
+    need = lib.ecoflap_wanda_block_workspace_bytes(ctypes.byref(ok), 2)
+    assert need >= 2 * (256 + 3 * 2048 * 4)
+    call = lambda arr, n=2, ws=vp(16), nb=need: lib.ecoflap_wanda_prune_block(   # noqa: E731
+        ctypes.byref(arr) if arr is not None else None, n, ws, nb, None)
+    assert call(ok, n=0) == 0                                                   # empty block
+    assert call(ok, n=hip.WANDA_MAX_ITEMS + 1) == -3
+    assert call(None) == -2
+    assert call(items(dtype=9)) == -1
+    assert call(items(mode=5)) == -4
+    assert call(items(k=-1)) == -3
+    assert call(items(cols=20000)) == -3                                         # rows-mode width limit
+    assert call(items(mode=hip.WANDA_MATRIX, k=32)) == -3                        # sorted[k] out of range
+    assert call(items(w=None)) == -2
+    assert call(ok, ws=None) == -2
+    assert call(ok, nb=64) == -6
+    # MFMA Hessian: 16-bit activations only (fp32 keeps the library GEMM)
+    hws = lib.ecoflap_hessian_workspace_bytes(100, 256)
+    assert hws == 256 * 128 * 2                                                  # Xt [C, 128] 16-bit
+    h = lambda **kw: lib.ecoflap_hessian_accum(                                  # noqa: E731
+        kw.get("H", vp(16)), kw.get("x", vp(16)), kw.get("tokens", 100), 256, kw.get("dt", 2),
+        kw.get("n", 0), kw.get("b", 8), kw.get("ws", vp(16)), kw.get("nb", hws), None)
+    assert h(dt=0) == -1
+    assert h(tokens=0) == -3 and h(b=0) == -3 and h(n=-1) == -3
+    assert h(H=None) == -2 and h(ws=None) == -2
+    assert h(ws=vp(8)) == -5
+    assert h(nb=16) == -6
+    # protected global threshold
+    pws = lib.ecoflap_global_prune_protected_workspace_bytes(3)
+    assert pws >= 4 * 3 * 2048 * 4
+    p = lambda **kw: lib.ecoflap_global_threshold_prune_protected(               # noqa: E731
+        kw.get("table", vp(16)), 3, kw.get("mode", 0), 2.0, kw.get("k", 5), 100,
+        kw.get("ranks", vp(16)), vp(16), kw.get("nb", pws), None)
+    assert p(mode=7) == -4 and p(k=0) == -3 and p(ranks=None) == -2 and p(nb=1024) == -6
+    # timed K1: the event pair is mandatory
+    seeds = (ctypes.c_uint64 * 1)(1)
+    ptrs = (ctypes.c_void_p * 1)(32)
+    assert lib.ecoflap_zo_perturb_units_timed(vp(16), 64, 2, 1e-3, 1, seeds, ptrs, ptrs, None, None,
+                                              None, vp(16)) == -2
+    assert lib.ecoflap_zo_perturb_units(vp(16), 1 << 41, 2, 1e-3, 1, seeds, ptrs, ptrs, None, None) == -3
