@@ -420,10 +420,34 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
     const bool all = (k >= cols);
     uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
     if (!all) {
-        // k-th smallest (1-indexed): largest T with #(m < T) < k
-        uint32_t prefix = 0;
+        // k-th smallest (1-indexed): largest T with #(m < T) < k.  As in the wave form: start at
+        // the row's highest set bit; once the top 16 bits are fixed, compact the elements of that
+        // 16-bit bucket (at most 128) and let ONE wave finish the low 16 bits on them with
+        // ballots — 16 rounds without a block barrier or a pass over the registers.
+        __shared__ uint32_t cand_lds[128];
+        __shared__ uint32_t res3[3];
         int phase = 0;
-        for (int bit = 31; bit >= 0; --bit) {
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (tid + 256 * j < nvec) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) mx = m[j][i] > mx ? m[j][i] : mx;
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        if ((tid & 63) == 0) wave4[tid >> 6] = mx;
+        __syncthreads();
+        mx = wave4[0] > wave4[1] ? wave4[0] : wave4[1];
+        mx = wave4[2] > mx ? wave4[2] : mx;
+        mx = wave4[3] > mx ? wave4[3] : mx;
+        __syncthreads();
+        const int top = mx ? 31 - __builtin_clz(mx) : -1;
+        uint32_t prefix = 0;
+        for (int bit = top; bit >= 16; --bit) {
             const uint32_t cand = prefix | (1u << bit);
             uint32_t c = 0;
 #pragma unroll
@@ -433,18 +457,74 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
             c = block_count_256(c, lds8, phase++);
             if (c < (uint32_t)k) prefix = cand;
         }
-        T = prefix;
-        uint32_t less = 0, eq = 0;
+        // below the bucket / in the bucket, both counts in one reduction (cols < 2^14)
+        uint32_t packed = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                less += (m[j][i] < T) ? 1u : 0u;
-                eq += (m[j][i] == T) ? 1u : 0u;
+                packed += (m[j][i] < prefix) ? 0x10000u : 0u;
+                packed += ((m[j][i] ^ prefix) < 0x10000u) ? 1u : 0u;
             }
-        less = block_count_256(less, lds8, phase++);
-        total_equal = block_count_256(eq, lds8, phase++);
-        take_equal = (uint32_t)k - less;          // >= 1 of the elements equal to T are pruned
+        packed = block_count_256(packed, lds8, phase++);
+        const uint32_t less16 = packed >> 16, ncand = packed & 0xffffu;
+        if (ncand <= 128) {                               // block-uniform
+            uint32_t mine = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) mine += ((m[j][i] ^ prefix) < 0x10000u) ? 1u : 0u;
+            uint32_t total;
+            uint32_t pos = block_scan_256(mine, wave4, total) - mine;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if ((m[j][i] ^ prefix) < 0x10000u) cand_lds[pos++] = m[j][i];
+            __syncthreads();
+            if (tid < 64) {                               // wave 0 finishes the search
+                const bool v0 = (uint32_t)tid < ncand, v1 = (uint32_t)tid + 64 < ncand;
+                const uint32_t c0 = v0 ? cand_lds[tid] : 0u, c1 = v1 ? cand_lds[tid + 64] : 0u;
+                for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
+                    const uint32_t cand = prefix | (1u << bit);
+                    const uint32_t c = less16 + (uint32_t)__popcll(__ballot(v0 && c0 < cand)) +
+                                       (uint32_t)__popcll(__ballot(v1 && c1 < cand));
+                    if (c < (uint32_t)k) prefix = cand;
+                }
+                const uint32_t less = less16 + (uint32_t)__popcll(__ballot(v0 && c0 < prefix)) +
+                                      (uint32_t)__popcll(__ballot(v1 && c1 < prefix));
+                const uint32_t eq = (uint32_t)__popcll(__ballot(v0 && c0 == prefix)) +
+                                    (uint32_t)__popcll(__ballot(v1 && c1 == prefix));
+                if (tid == 0) { res3[0] = prefix; res3[1] = less; res3[2] = eq; }
+            }
+            __syncthreads();
+            T = res3[0];
+            total_equal = res3[2];
+            take_equal = (uint32_t)k - res3[1];           // >= 1 of the elements equal to T are pruned
+        } else {                                          // crowded bucket: all elements, as before
+            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
+                c = block_count_256(c, lds8, phase++);
+                if (c < (uint32_t)k) prefix = cand;
+            }
+            T = prefix;
+            uint32_t less = 0, eq = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    less += (m[j][i] < T) ? 1u : 0u;
+                    eq += (m[j][i] == T) ? 1u : 0u;
+                }
+            less = block_count_256(less, lds8, phase++);
+            total_equal = block_count_256(eq, lds8, phase++);
+            take_equal = (uint32_t)k - less;
+        }
     }
     const bool ordered = !all && (take_equal < total_equal);   // ties cut by column order
     uint32_t running = 0;
