@@ -205,6 +205,22 @@ class TimedKernels:
         return self._timed("single", nbytes, self.inner.zo_perturb, w, scaling_factor, zo_eps,
                            seed, z)
 
+    def event_floor_us(self, n=24):
+        """Median reading of the same event pair around an EMPTY kernel (after the timed
+        region): the part of every K1 reading that is not the kernel."""
+        if self.hip_events is None:
+            return None
+        import statistics
+        pairs = []
+        for _ in range(n):
+            p = self.hip_events.pair()
+            rc = self.inner.lib.ecoflap_null_launch_timed(
+                self.hip_events.ct.c_void_p(torch.cuda.current_stream().cuda_stream), p[0], p[1])
+            assert rc == 0
+            pairs.append(p)
+        torch.cuda.synchronize()
+        return statistics.median(self.hip_events.elapsed_us(a, b) for a, b in pairs)
+
     def summary(self, kind):
         if kind == "units":
             recs = [(self.hip_events.elapsed_us(a, b) * 1e-6, nb, 1) for a, b, nb in self.unit_records]
@@ -488,6 +504,8 @@ def main():
                        "(hipExtLaunchKernelGGL)" if kind == "units" else
                        f"torch event pair behind a '{args.k1_blocker}' blocker"),
             "per_launch": k1["per_launch"],
+            # not subtracted from anything: `achieved` is the raw reading
+            "event_pair_floor_us": kern.event_floor_us() if kind == "units" else None,
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
             "bytes_rule": {
                 "units": "(2*U+2)*s*numel per launch: read W once, write theta+/theta- for each of "

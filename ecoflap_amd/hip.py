@@ -20,7 +20,8 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
-    "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
+    "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed",
+    "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
@@ -72,6 +73,7 @@ def load_library():
     lib.ecoflap_zo_perturb_triple.argtypes = [vp, vp, vp, vp, i64, ci, f32, u64, vp, vp]
     lib.ecoflap_zo_perturb_units.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp]
     lib.ecoflap_zo_perturb_units_timed.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.ecoflap_null_launch_timed.argtypes = [vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz

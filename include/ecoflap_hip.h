@@ -126,6 +126,9 @@ int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, float zo_eps,
                                    const void* const* z, void* stream,
                                    void* start_event, void* stop_event);
 
+/* An empty kernel through the same instrumented launch: the floor of that event pair. */
+int ecoflap_null_launch_timed(void* stream, void* start_event, void* stop_event);
+
 /* Materialise the in-register z stream of K1 for (seed, n, dtype). */
 int ecoflap_zo_fill_normal(void* z_out, int64_t n, int dtype, uint64_t seed,
                            void* stream);
