@@ -45,6 +45,10 @@ def _resolve(model, path):
     return mod
 
 
+class _SequenceChanged(Exception):
+    pass
+
+
 class HookedPrefixLoss:
     """Drop-in `loss_func(model, samples, cuda_enabled) -> (loss, batch_len)` around another
     loss closure; `LayerSparsity` announces the scored matrix through `begin_layer(name)`."""
@@ -65,6 +69,7 @@ class HookedPrefixLoss:
         self.sequence = None                  # [module] in call order (one forward)
         self.cache = {}                       # id(samples) -> [outputs per event]; valid prefix
         self.valid = {}                       # id(samples) -> number of leading events recorded
+        self.disabled = False                 # the model does not call its modules in a fixed order
         self.stats = {"events_total": 0, "events_served": 0, "forwards": 0}
 
     # ---- hooks of LayerSparsity ------------------------------------------------------------
@@ -98,6 +103,23 @@ class HookedPrefixLoss:
 
     def __call__(self, model, samples, cuda_enabled):
         assert model is self.model
+        if self.disabled:
+            return self.loss_func(model, samples, cuda_enabled)
+        try:
+            return self._cached_call(model, samples, cuda_enabled)
+        except _SequenceChanged:
+            # a forward that calls its cacheable modules in another order / number than the
+            # recorded one (data-dependent control flow): the record cannot be trusted — drop it
+            # for good and evaluate this and every later loss with plain full forwards
+            import warnings
+            warnings.warn("HookedPrefixLoss: the model's module call sequence is not fixed; "
+                          "falling back to full forwards")
+            self.disabled = True
+            self.cache.clear()
+            self.valid.clear()
+            return self.loss_func(model, samples, cuda_enabled)
+
+    def _cached_call(self, model, samples, cuda_enabled):
         key = id(samples)
         record_sequence = self.sequence is None
         seen = []
@@ -113,6 +135,8 @@ class HookedPrefixLoss:
                 counter[0] += 1
                 if record_sequence:
                     seen.append(mod)
+                elif i >= len(self.sequence) or self.sequence[i] is not mod:
+                    raise _SequenceChanged()
                 if i < n_valid:
                     self.stats["events_served"] += 1
                     return _map(cached[i], lambda t: t.clone())
@@ -123,9 +147,10 @@ class HookedPrefixLoss:
                     keep = _map(out, lambda t: t.detach().clone())
                     if i < len(cached):
                         cached[i] = keep
-                    else:
-                        assert i == len(cached), "cacheable modules were called in a new order"
+                    elif i == len(cached):
                         cached.append(keep)
+                    else:
+                        raise _SequenceChanged()
                 return out
             return patched
 
@@ -140,9 +165,8 @@ class HookedPrefixLoss:
         if record_sequence:
             self.sequence = seen
             limit = self._limit()
-        else:
-            assert counter[0] == len(self.sequence), \
-                "the model called its cacheable modules a different number of times"
+        elif counter[0] != len(self.sequence):
+            raise _SequenceChanged()
         self.valid[key] = min(max(self.valid.get(key, 0), limit), len(cached))
         del cached[self.valid[key]:]              # nothing recorded at / after the owner survives
         self.stats["events_total"] += counter[0]

@@ -199,3 +199,40 @@ def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatc
     assert t_full == t_hook
     for k in w_full:
         assert torch.equal(w_full[k], w_hook[k]), k
+
+
+def test_hooked_prefix_adapter_falls_back_when_the_call_sequence_changes():
+    """A model whose forward calls its blocks a data-dependent number of times cannot be served
+    from a recorded sequence: the adapter notices, warns once and evaluates plain full forwards
+    (losses stay those of the full forward)."""
+    import warnings
+    import torch
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Odd(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(4, 4) for _ in range(3)])
+
+        def forward(self, batch):
+            x = batch["x"]
+            for i in range(batch["depth"]):          # data-dependent control flow
+                x = self.blocks[i](x)
+            return {"loss": x.pow(2).mean()}
+
+    torch.manual_seed(0)
+    model = Odd().eval()
+    loss = lambda m, b, c: (m(b)["loss"], 2)         # noqa: E731
+    hooked = HookedPrefixLoss(model, loss, ["blocks"])
+    b3 = {"x": torch.randn(2, 4), "depth": 3}
+    b2 = {"x": torch.randn(2, 4), "depth": 2}
+    hooked.begin_layer("blocks.2.weight")
+    with torch.no_grad():
+        assert torch.equal(hooked(model, b3, False)[0], loss(model, b3, False)[0])
+        assert torch.equal(hooked(model, b3, False)[0], loss(model, b3, False)[0])    # served from the record
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert torch.equal(hooked(model, b2, False)[0], loss(model, b2, False)[0])
+        assert hooked.disabled and len(w) == 1
+        assert torch.equal(hooked(model, b3, False)[0], loss(model, b3, False)[0])
+    assert all(m.forward.__func__ is torch.nn.Linear.forward for m in model.blocks)      # patches removed
