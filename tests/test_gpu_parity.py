@@ -949,20 +949,34 @@ def test_upop_task_pruners_hip_equals_oracle(kern, golden_dir, tag):
 @pytest.mark.parametrize("script,stage1", [
     ("ecoflap_compression_vqa.py", "compat"), ("ecoflap_compress_caption.py", "compat"),
     ("ecoflap_compress_nlvr.py", "intended"), ("ecoflap_compression_retrieval_flickr.py", "intended")])
-def test_upop_entrypoints_run(script, stage1):
-    """The four UPop entrypoint names on toy shapes: prune + one masked fine-tune step."""
+def test_upop_entrypoints_run(script, stage1, monkeypatch):
+    """The four UPop entrypoint names on toy shapes: prune + one masked fine-tune step.  As
+    shipped ("compat": uniform table, no random draw anywhere) the whole entrypoint — Wanda
+    statistics, selection, K8 masked step — is run a second time with the oracle standing in for
+    the HIP library and must give the same table and the same weights bit for bit; "intended"
+    (in-register z) is checked for the pruned fraction here and for parity with supplied z in
+    test_upop_task_pruners_hip_equals_oracle."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("upop_entry_" + script[:-3],
                                                   os.path.join(root, "UPop", script))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    model, table = mod.main(["--toy", "--num_data", "8", "--batch_size", "2", "--stage1", stage1,
-                             "--finetune_steps", "1"])
-    blocks = [v for k, v in model.state_dict().items()
+    argv = ["--toy", "--num_data", "8", "--batch_size", "2", "--stage1", stage1, "--finetune_steps", "1"]
+    model, table = mod.main(argv)
+    weights = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    blocks = [v for k, v in weights.items()
               if v.dim() == 2 and (".blocks." in k or ".layer." in k) and not k.split(".")[0].endswith("_m")]
     frac = sum(int((v == 0).sum()) for v in blocks) / sum(v.numel() for v in blocks)
     assert 0.4 < frac < 0.6
+    if stage1 == "compat":
+        from oracle_backend import OracleKernels
+        from ecoflap_amd import hip
+        monkeypatch.setattr(hip, "HipKernels", OracleKernels)       # checker in place of the library
+        model_o, table_o = mod.main(argv)
+        assert (table is None and table_o is None) or table == table_o
+        for k, v in model_o.state_dict().items():
+            assert torch.equal(v.detach().cpu(), weights[k]), k
 
 
 @pytest.mark.parametrize("tag", ["coco", "nlvr"])
