@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-layer", type=int, default=-1)
-    ap.add_argument("--k1-form", default="units", choices=["units", "triple", "single"],
-                    help="units: one K1 launch per layer (default); triple: one fused launch per "
-                         "(layer,batch) unit; single: the reference's three in-place passes")
+    ap.add_argument("--k1-form", default="block", choices=["block", "units", "triple", "single"],
+                    help="block: one K1 launch per transformer block (all its matrices, default); "
+                         "units: one per layer; triple: one fused launch per (layer,batch) unit; "
+                         "single: the reference's three in-place passes")
     ap.add_argument("--full-forward", action="store_true",
                     help="two full forwards per unit like the reference, instead of the exact "
                          "suffix-only re-forward (pruners/prefix_cache.py)")
@@ -149,6 +150,7 @@ class TimedKernels:
         self.spin_cycles = 600000
         self.hip_events = None
         self.unit_records = []   # (start, stop, algorithmic_bytes) raw HIP events
+        self.layers_per_launch = []
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
@@ -200,6 +202,19 @@ class TimedKernels:
             return pair
         return self.inner.zo_perturb_units(w, zo_eps, seeds, w_plus, w_minus, z, events=events)
 
+    def zo_perturb_layers(self, layers, zo_eps):
+        if not self.enabled:
+            return self.inner.zo_perturb_layers(layers, zo_eps)
+        if self.hip_events is None:
+            self.hip_events = HipEvents()
+        # per layer: read W, write theta+/theta- of its owned units, write the drifted W
+        nbytes = sum((2 * sum(1 for t in plus if t is not None) + 2) * w.element_size() * w.numel()
+                     for w, _, _, plus, _ in layers)
+        pair = self.hip_events.pair()
+        self.unit_records.append((pair[0], pair[1], nbytes))
+        self.layers_per_launch.append(len(layers))
+        return self.inner.zo_perturb_layers(layers, zo_eps, events=lambda: pair)
+
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         nbytes = 2 * w.element_size() * w.numel()          # read W, write W
         return self._timed("single", nbytes, self.inner.zo_perturb, w, scaling_factor, zo_eps,
@@ -222,7 +237,7 @@ class TimedKernels:
         return statistics.median(self.hip_events.elapsed_us(a, b) for a, b in pairs)
 
     def summary(self, kind):
-        if kind == "units":
+        if kind in ("units", "block"):
             recs = [(self.hip_events.elapsed_us(a, b) * 1e-6, nb, 1) for a, b, nb in self.unit_records]
         else:
             recs = [(s.elapsed_time(e) * 1e-3, b, n) for s, e, b, k, n in self.records if k == kind]
@@ -490,26 +505,31 @@ def main():
     if k1:
         out["roofline"] = {
             "kernel": {"units": "zo_perturb_units_kernel", "triple": "zo_perturb_triple_kernel",
-                       "single": "zo_perturb_kernel"}[kind],
+                       "single": "zo_perturb_kernel",
+                       "block": "zo_perturb_layers_kernel (+ zo_perturb_units_kernel for a layer "
+                                "that is alone in its block within the sample)"}[kind],
             "bound": "hbm",
             "achieved": k1["gbs"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": k1["gbs"] / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(kind, k1["bytes_per_launch"]),
+            "traffic": load_pmc_traffic("units" if kind == "block" else kind, k1["bytes_per_launch"]),
             "traffic_source": "profiles/k1_pmc_traffic.json (rocprofv3 --pmc, separate passes)",
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
+            "layers_per_launch": kern.layers_per_launch if kind == "block" else None,
             "timing": ("kernel begin/end timestamps in HIP events attached to the launch "
-                       "(hipExtLaunchKernelGGL)" if kind == "units" else
+                       "(hipExtLaunchKernelGGL)" if kind in ("units", "block") else
                        f"torch event pair behind a '{args.k1_blocker}' blocker"),
             "per_launch": k1["per_launch"],
             # not subtracted from anything: `achieved` is the raw reading
-            "event_pair_floor_us": kern.event_floor_us() if kind == "units" else None,
+            "event_pair_floor_us": kern.event_floor_us() if kind in ("units", "block") else None,
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
             "bytes_rule": {
                 "units": "(2*U+2)*s*numel per launch: read W once, write theta+/theta- for each of "
                          "the layer's U units, write the final drifted W",
+                "block": "sum over the launch's layers of (2*U+2)*s*numel: read W once, write "
+                         "theta+/theta- for each of the layer's U units, write the drifted W",
                 "triple": "4*s*numel (read W; write theta+, theta-, restored)",
                 "single": "2*s*numel per pass (read W, write W)"}[kind],
         }

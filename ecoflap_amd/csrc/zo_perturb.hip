@@ -400,6 +400,79 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_units_kernel(void* 
     }
 }
 
+// ---------------------------------------------------------------- block-batched form
+// Every layer of one transformer block (the matrices scored back to back, all re-entering the
+// forward at the same stage) in ONE launch.  K1 of a layer is a function of its original weights
+// and its seeds only, so it can run ahead of the layer's turn — provided the drifted weights are
+// NOT written over the originals yet (the other layers of the block are still evaluated with
+// them): they go to a buffer of their own and the caller copies them in when the layer is done.
+// What it buys is the per-launch cost a 135-285 MB pass pays in the loop (cold instruction and
+// translation caches, dirty L2 lines of the forward that ran before): once per block instead of
+// once per matrix.  Device table, one row of ECO_LAYER_ROW int64 per layer:
+//   [0] w_in  [1] w_final  [2] numel  [3] n_units  [4] first super-row of the layer in the launch
+//   [5 .. 5+U) seeds   [5+U .. 5+2U) theta+ pointers   [5+2U .. 5+3U) theta- pointers   (U = MAX_UNITS)
+#define ECO_LAYER_ROW (5 + 3 * ECOFLAP_MAX_UNITS)
+
+template <int DT>
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_layers_kernel(
+    const int64_t* __restrict__ table, int n_layers, int64_t total_rows, float eps) {
+    constexpr int N = Vec<DT>::N;
+    const int64_t per = (int64_t)(gridDim.x / ECO_XCDS);
+    const int64_t Rg = (int64_t)(blockIdx.x % ECO_XCDS) * per + blockIdx.x / ECO_XCDS;
+    if (Rg >= total_rows) return;
+    int l = 0;                                     // wave-uniform scan: scalar loads
+    while (l + 1 < n_layers && Rg >= table[(int64_t)(l + 1) * ECO_LAYER_ROW + 4]) ++l;
+    const int64_t* __restrict__ row = table + (int64_t)l * ECO_LAYER_ROW;
+    const void* win = (const void*)row[0];
+    void* wout = (void*)row[1];
+    const int64_t n = row[2];
+    const int n_units = (int)row[3];
+    const int64_t R = Rg - row[4];
+    const int64_t nvec = n / N;
+    const LaneVecs L = lane_vecs(R, nvec);
+    u32x4 s0 = ld16_if(L.ok0, win, L.v0), s1 = ld16_if(L.ok1, win, L.v1);
+    for (int u = 0; u < n_units; ++u) {
+        const uint64_t seed = (uint64_t)row[5 + u];
+        float z[2 * N];
+        gen_z_lane<DT>(L.v0, (uint32_t)seed, (uint32_t)(seed >> 32), z);
+        u32x4 p0, m0, p1, m1;
+        unit_update<DT, true>(s0, z, eps, p0, m0);
+        unit_update<DT, true>(s1, z + N, eps, p1, m1);
+        void* dp = (void*)row[5 + ECOFLAP_MAX_UNITS + u];
+        if (dp) {   // wave-uniform: not-owned units only carry the drift
+            void* dm = (void*)row[5 + 2 * ECOFLAP_MAX_UNITS + u];
+            if (L.ok0) {
+                st16_nt(dp, L.v0, p0);
+                st16_nt(dm, L.v0, m0);
+            }
+            if (L.ok1) {
+                st16_nt(dp, L.v1, p1);
+                st16_nt(dm, L.v1, m1);
+            }
+        }
+    }
+    if (L.ok0) st16(wout, L.v0, s0);
+    if (L.ok1) st16(wout, L.v1, s1);
+    const int64_t tail0 = nvec * N;                // ragged tail of this layer: its first wave
+    if (R == 0 && threadIdx.x < (unsigned)(n - tail0)) {
+        const int64_t e = tail0 + threadIdx.x;
+        float a = Vec<DT>::load1(win, e);
+        for (int u = 0; u < n_units; ++u) {
+            const uint64_t seed = (uint64_t)row[5 + u];
+            const float z = gen_z1<DT>(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+            a = k1_step<DT>(a, z, 1.0f, eps);
+            const float b = k1_step<DT>(a, z, -2.0f, eps);
+            void* dp = (void*)row[5 + ECOFLAP_MAX_UNITS + u];
+            if (dp) {
+                Vec<DT>::store1(dp, e, a);
+                Vec<DT>::store1((void*)row[5 + 2 * ECOFLAP_MAX_UNITS + u], e, b);
+            }
+            a = k1_step<DT>(b, z, 1.0f, eps);
+        }
+        Vec<DT>::store1(wout, e, a);
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(ECO_K1_THREADS) void zo_fill_normal_kernel(void* __restrict__ zout, int64_t n,
                                                              uint32_t k0, uint32_t k1) {
@@ -574,6 +647,25 @@ extern "C" int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, flo
     if (!start_event || !stop_event) return ECOFLAP_ENULL;
     return zo_perturb_units_impl(w, n, dtype, zo_eps, n_units, seeds, w_plus, w_minus, z, stream,
                                  (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
+extern "C" int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int64_t total_rows,
+                                         int dtype, float zo_eps, void* stream,
+                                         void* start_event, void* stop_event) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (n_layers < 0 || total_rows < 0 || total_rows > 0x7ffffff0LL) return ECOFLAP_ESIZE;
+    if (n_layers == 0 || total_rows == 0) return 0;
+    if (!table) return ECOFLAP_ENULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return ECOFLAP_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)((total_rows + ECO_XCDS - 1) / ECO_XCDS * ECO_XCDS);
+    DISPATCH_DT(dtype, {
+        hipExtLaunchKernelGGL((zo_perturb_layers_kernel<DT>), dim3(g), dim3(ECO_K1_THREADS), 0, s,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, table, n_layers,
+                              total_rows, zo_eps);
+    });
+    ECO_CHECK_LAUNCH();
+    return 0;
 }
 
 // An empty launch through the same instrumented path: what the event pair of

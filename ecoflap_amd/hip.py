@@ -20,7 +20,7 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
-    "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed",
+    "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
@@ -74,6 +74,7 @@ def load_library():
     lib.ecoflap_zo_perturb_units.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp]
     lib.ecoflap_zo_perturb_units_timed.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.ecoflap_null_launch_timed.argtypes = [vp, vp, vp]
+    lib.ecoflap_zo_perturb_layers.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
@@ -227,6 +228,44 @@ class HipKernels:
             _check(self.lib.ecoflap_zo_perturb_units(
                 _ptr(w), w.numel(), DTYPE_CODE[w.dtype], float(zo_eps), m, seeds_a, plus_a,
                 minus_a, z_a, _stream()), "ecoflap_zo_perturb_units")
+
+    def zo_perturb_layers(self, layers, zo_eps, events=None):
+        """Block-batched K1 (in-register z): layers = [(w_in, w_final, seeds, w_plus, w_minus)],
+        all of one dtype, each with at most MAX_UNITS units (None, None = drift only); one
+        launch for all of them, drifted weights into w_final (w_in is left untouched).
+        events: optional callable -> (start, stop) raw hipEvent_t handles."""
+        U, row_len = self.MAX_UNITS, 5 + 3 * self.MAX_UNITS
+        dt = layers[0][0].dtype
+        rows, total = [], 0
+        for w_in, w_final, seeds, w_plus, w_minus in layers:
+            _gpu(w_in, "w_in")
+            _gpu(w_final, "w_final")
+            n_units = len(seeds)
+            if n_units > U or len(w_plus) != n_units or len(w_minus) != n_units:
+                raise EcoflapHipError("zo_perturb_layers: at most MAX_UNITS units per layer")
+            if w_in.dtype != dt or w_final.dtype != dt or w_final.numel() != w_in.numel():
+                raise EcoflapHipError("zo_perturb_layers: one dtype per launch, w_final like w_in")
+            if w_final.data_ptr() == w_in.data_ptr():
+                raise EcoflapHipError("zo_perturb_layers: w_final must not alias w_in")
+            for t in list(w_plus) + list(w_minus):
+                if t is not None:
+                    _gpu(t, "unit buffer")
+                    if t.dtype != dt or t.numel() != w_in.numel():
+                        raise EcoflapHipError("unit buffers must match w_in in dtype and numel")
+            per_vec = 16 // w_in.element_size()
+            row = [w_in.data_ptr(), w_final.data_ptr(), w_in.numel(), n_units, total]
+            row += [(int(x) & (2 ** 64 - 1)) - (2 ** 64 if (int(x) & (2 ** 63)) else 0) for x in seeds]
+            row += [0] * (U - n_units)
+            row += [t.data_ptr() if t is not None else 0 for t in w_plus] + [0] * (U - n_units)
+            row += [t.data_ptr() if t is not None else 0 for t in w_minus] + [0] * (U - n_units)
+            assert len(row) == row_len
+            rows.append(row)
+            total += max(1, -(-(w_in.numel() // per_vec) // 128))
+        table = torch.tensor(rows, dtype=torch.int64, device=layers[0][0].device)
+        ev = events() if events is not None else (None, None)
+        _check(self.lib.ecoflap_zo_perturb_layers(_ptr(table), len(rows), total, DTYPE_CODE[dt],
+                                                  float(zo_eps), _stream(), ev[0], ev[1]),
+               "ecoflap_zo_perturb_layers")
 
     def zo_fill_normal(self, z_out, seed):
         _gpu(z_out, "z_out")

@@ -4,6 +4,31 @@ layer_single_base_pruner.py:19-117)."""
 import time
 
 
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def capture_graph(graph, **kw):
+    """`torch.cuda.graph(graph, **kw)` with Python's cyclic garbage collector held off for the
+    duration of the capture.  A collection that happens to run inside a capture may finalise
+    objects that own device resources (an older loss closure's HIP graphs, pools, events); their
+    destructors call into HIP on the capturing thread, which is illegal under
+    capture_error_mode="thread_local" and aborts the process (seen once in ~3 runs of the full-size
+    batched-evaluation test).  torch.cuda.graph collects once on entry; nothing may be freed
+    until the capture has ended."""
+    import torch
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def print_time(func):
     """Wall-clock print around a stage, as the reference's decorator (pruners/utils.py:6-18)."""
     def wrapper(*args, **kwargs):

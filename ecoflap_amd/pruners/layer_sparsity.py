@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from .. import hip as _hip
+from .base_pruner import capture_graph
 
 _f32 = np.float32
 
@@ -72,7 +73,7 @@ class LayerSparsity:
         z_source="philox",
         batch_len_fn=None,
         process_group=None,
-        k1_form="units",
+        k1_form="block",
         couple_torch_rng=False,
         grad_graphs=True,
     ):
@@ -85,8 +86,12 @@ class LayerSparsity:
                       or a callable (seed, param) -> z tensor (parity tests).
         process_group torch.distributed group to shard calibration batches over
                       (None = use the default group if initialised, else single process).
-        k1_form       "units"  (default) one launch per layer: every unit's theta+ / theta-
-                               precomputed into scratch, W read once;
+        k1_form       "block"  (default) one launch for ALL layers that re-enter the forward at
+                               one stage (a transformer block): every unit's theta+ / theta-
+                               precomputed into scratch, each W read once, the drifted weights
+                               parked until the layer's turn is over.  Needs in-register z and a
+                               loss closure that knows its stages; otherwise it runs as "units";
+                      "units"  one such launch per layer;
                       "triple" one fused launch per (layer, batch, noise) unit;
                       "single" three in-place launches per unit, the reference's call pattern.
                       All three are bit-identical.
@@ -119,7 +124,7 @@ class LayerSparsity:
         # graph and replayed (the eager loop is launch-bound at batch 1: thousands of tiny kernels)
         self.grad_graphs = grad_graphs
         self.process_group = process_group
-        assert k1_form in ("units", "triple", "single")
+        assert k1_form in ("units", "block", "triple", "single")
         self.k1_form = k1_form
         self.stats = {}          # wall-clock + unit counts of the last run (reference: @print_time)
         self.loss_table = None   # [units, 2] fp32 (host copy) of the last zeroth-order run
@@ -244,35 +249,72 @@ class LayerSparsity:
 
         n_forward = 0
         begin_layer = getattr(self.loss_func, "begin_layer", None)
+        # "block": consecutive layers owned by the same stage of the forward share one K1 launch
+        groups, stash = {}, {}
+        stage_of = getattr(self.loss_func, "stage_of", None)
+        if (self.k1_form == "block" and self.z_source == "philox" and stage_of is not None
+                and hasattr(self.kernels, "zo_perturb_layers")):
+            start = 0
+            for li in range(1, len(names) + 1):
+                if (li == len(names) or stage_of(names[li]) != stage_of(names[start])
+                        or params[li].dtype != params[start].dtype):
+                    if li - start > 1:
+                        groups[start] = list(range(start, li))
+                    start = li
+        max_units = getattr(self.kernels, "MAX_UNITS", 32)
         for li, (name, param) in enumerate(zip(names, params)):
             home = param.data
             layer_units = by_layer.get(li, [])
             if begin_layer is not None:
                 begin_layer(name)     # exact suffix-only re-forward (pruners/prefix_cache.py)
             owned = [(units[u][1] % world) == rank for u in layer_units]
-            if self.k1_form == "units":
+            if li in groups and all(0 < len(by_layer.get(g, [])) <= max_units for g in groups[li]):
+                # K1 of every layer of the block now, each from its ORIGINAL weights; the drifted
+                # weights wait in `final` until the layer's own turn is over
+                batch = []
+                for g in groups[li]:
+                    g_units = by_layer[g]
+                    g_owned = [(units[u][1] % world) == rank for u in g_units]
+                    g_home = params[g].data
+                    scr = torch.empty((2 * max(sum(g_owned), 1),) + tuple(g_home.shape),
+                                      dtype=g_home.dtype, device=g_home.device)
+                    plus, minus, kk = [], [], 0
+                    for mine in g_owned:
+                        plus.append(scr[2 * kk] if mine else None)
+                        minus.append(scr[2 * kk + 1] if mine else None)
+                        kk += int(mine)
+                    fin = torch.empty_like(g_home)
+                    stash[g] = (plus, minus, fin, scr)
+                    batch.append((g_home, fin, [units[u][3] for u in g_units], plus, minus))
+                self.kernels.zo_perturb_layers(batch, zo_eps)
+            if self.k1_form in ("units", "block"):
                 # one launch: theta+/theta- of every owned unit into scratch, final drifted theta
                 # back into the parameter's own storage; then only forwards remain
-                n_owned = sum(owned)
-                scratch = torch.empty((2 * max(n_owned, 1),) + tuple(home.shape), dtype=home.dtype,
-                                      device=home.device)
-                plus, minus, zs, k = [], [], [], 0
-                for u, mine in zip(layer_units, owned):
-                    plus.append(scratch[2 * k] if mine else None)
-                    minus.append(scratch[2 * k + 1] if mine else None)
-                    k += int(mine)
-                    zs.append(self._draw_z(units[u][3], param))
-                if layer_units:
-                    self.kernels.zo_perturb_units(
-                        home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
-                        None if self.z_source == "philox" else zs)
                 static_w = bool(getattr(self.loss_func, "requires_static_weights", False))
                 paired = static_w and bool(getattr(self.loss_func, "supports_pairs", lambda: False)())
                 if paired and self.couple_torch_rng:
                     raise RuntimeError(
                         "couple_torch_rng needs one loss at a time (the torch RNG is re-seeded "
                         "before each loss, :482): use a loss closure without lanes / batching")
-                final = home.clone() if static_w else None   # graphs bake the address of `home`
+                ahead = stash.pop(li, None)
+                if ahead is not None:        # K1 ran with its block: `home` still holds the originals
+                    plus, minus, final, scratch = ahead
+                    zs = []
+                else:
+                    n_owned = sum(owned)
+                    scratch = torch.empty((2 * max(n_owned, 1),) + tuple(home.shape), dtype=home.dtype,
+                                          device=home.device)
+                    plus, minus, zs, k = [], [], [], 0
+                    for u, mine in zip(layer_units, owned):
+                        plus.append(scratch[2 * k] if mine else None)
+                        minus.append(scratch[2 * k + 1] if mine else None)
+                        k += int(mine)
+                        zs.append(self._draw_z(units[u][3], param))
+                    if layer_units:
+                        self.kernels.zo_perturb_units(
+                            home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
+                            None if self.z_source == "philox" else zs)
+                    final = home.clone() if static_w else None   # graphs bake the address of `home`
                 if paired:
                     self.loss_func.begin_layer_weights(name, home)
                 if paired:
@@ -310,12 +352,12 @@ class LayerSparsity:
                     table = self._loss_into(table, u, 1, batches[bi], cuda_enabled, blen,
                                             rng=(units[u][3], param))
                     n_forward += 2
-                if static_w:
+                if static_w or ahead is not None:
                     home.copy_(final)
                 if paired:
                     self.loss_func.end_layer_weights(final)
                 param.data = home               # "recovered" weights, with the reference's drift
-                del scratch, plus, minus, zs
+                del scratch, plus, minus, zs, final, ahead
                 continue
             cur = home
             spare = [torch.empty_like(home), torch.empty_like(home)]
@@ -536,7 +578,7 @@ class LayerSparsity:
             if batch_len != self.batch_len_fn(first):
                 raise RuntimeError("loss_func batch_len differs from batch_len_fn")
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with capture_graph(graph, capture_error_mode="thread_local"):
                 loss, _ = self.loss_func(model, static, cuda_enabled)
                 grads = torch.autograd.grad(loss, params)
             assert len(grads) == len(params)

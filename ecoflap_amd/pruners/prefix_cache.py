@@ -20,6 +20,8 @@ perturbed through the optional `begin_layer(name)` hook.
 """
 import torch
 
+from .base_pruner import capture_graph
+
 
 def _sync_timed(stats):
     """torch.cuda.synchronize(), its wall time added to stats["host_blocked_seconds"]."""
@@ -516,7 +518,7 @@ class PrefixCachedLoss:
                 for i in range(k):      # eager once: library handles, workspaces
                     losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, pool=bchain.pool, capture_error_mode="thread_local"):
+                with capture_graph(graph, pool=bchain.pool, capture_error_mode="thread_local"):
                     for i in range(k):
                         losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
             bundle[1], bundle[2] = graph, losses
@@ -675,7 +677,7 @@ class _StageGraphs:
         if self.stream is not None:
             kw["stream"] = self.stream
         last = (j == len(self.plan) - 1)
-        with torch.no_grad(), torch.cuda.graph(graph, **kw):
+        with torch.no_grad(), capture_graph(graph, **kw):
             out = self.plan[j][2](static_in)
             if last:
                 out = {"__loss__": self.owner.result(out)}

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import hip as _hip
 from ..registry import registry
-from .base_pruner import LayerWiseBasePruner, print_time
+from .base_pruner import LayerWiseBasePruner, capture_graph, print_time
 from .layer_sparsity import LayerSparsity, _default_batch_len
 from .losses import loss_language, loss_vision, loss_vision_language
 
@@ -242,7 +242,7 @@ class _BlockwiseWanda:
             for w_ in (wrapped or {}).values():
                 w_.n_dev = torch.tensor([w_.nsamples], dtype=torch.int64, device=static_x.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
                 with autocast():
                     y = block(static_x, **static_kw)
                 y = y[0] if take_first else y

@@ -126,6 +126,20 @@ int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, float zo_eps,
                                    const void* const* z, void* stream,
                                    void* start_event, void* stop_event);
 
+/* Block-batched form: the layer-batched pass for SEVERAL matrices (the layers of one transformer
+ * block, scored back to back) in one launch, in-register z only.  Per layer the drifted weights
+ * go to w_final (NOT over w_in: the block's other layers are still evaluated with the original
+ * weights; the caller copies w_final in when the layer's turn is over).  table: DEVICE int64
+ * [n_layers][5 + 3*ECOFLAP_MAX_UNITS], row = {w_in, w_final, numel, n_units, first_super_row,
+ * seeds[MAX_UNITS], w_plus[MAX_UNITS], w_minus[MAX_UNITS]} (super-row = 128 16-byte vectors:
+ * rows_l = ceil(numel_l / (128 * 16 / s)); first_super_row = sum of the earlier layers' rows);
+ * total_rows = the sum over all layers.  One dtype per launch.  start_event / stop_event: both
+ * NULL, or a hipEvent_t pair that receives the kernel's begin / end (as the _timed form).
+ * Bit-identical to one ecoflap_zo_perturb_units call per layer. */
+int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int64_t total_rows,
+                              int dtype, float zo_eps, void* stream,
+                              void* start_event, void* stop_event);
+
 /* An empty kernel through the same instrumented launch: the floor of that event pair. */
 int ecoflap_null_launch_timed(void* stream, void* start_event, void* stop_event);
 

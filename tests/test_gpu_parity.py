@@ -91,6 +91,70 @@ def test_k1_in_register_z_equals_materialised_stream(kern, oracle, dt, n):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_k1_block_batched_equals_per_layer_launches(kern, dt):
+    """ecoflap_zo_perturb_layers (all matrices of a block in one launch, drifted weights to a
+    separate buffer) == one ecoflap_zo_perturb_units per matrix, bit for bit: theta+ / theta- of
+    every owned unit, the drifted weights, and the inputs left untouched; ragged sizes, partial
+    super-rows, drift-only units, different unit counts per layer."""
+    torch.manual_seed(17)
+    sizes = [(2048 * 2048, 16), (5, 3), (4099, 7), (128 * 8 * 3 + 11, 16), (1408 * 96, 5), (1023, 32)]
+    layers, refs = [], []
+    for li, (n, n_units) in enumerate(sizes):
+        w0 = (torch.randn(n, device="cuda") * 0.05).to(dt)
+        seeds = [100003 * li + 17 * u + (2 ** 40 if u == 1 else 0) for u in range(n_units)]
+        owned = [(u + li) % 3 != 1 for u in range(n_units)]
+        mk = lambda: [torch.empty(n, dtype=dt, device="cuda") if o else None for o in owned]   # noqa: E731
+        plus, minus, fin = mk(), mk(), torch.empty_like(w0)
+        layers.append((w0, fin, seeds, plus, minus))
+        w_ref = w0.clone()
+        rp, rm = mk(), mk()
+        kern.zo_perturb_units(w_ref, 1e-3, seeds, rp, rm)
+        refs.append((w0.clone(), w_ref, rp, rm, owned))
+    kern.zo_perturb_layers(layers, 1e-3)
+    for (w_in, fin, _, plus, minus), (w_orig, w_ref, rp, rm, owned) in zip(layers, refs):
+        assert torch.equal(w_in, w_orig)                       # originals untouched
+        assert torch.equal(fin, w_ref)
+        for u, o in enumerate(owned):
+            if o:
+                assert torch.equal(plus[u], rp[u]) and torch.equal(minus[u], rm[u]), u
+
+
+def test_stage1_block_batched_k1_equals_per_layer(kern):
+    """k1_form="block" (one K1 launch per transformer block, drifted weights parked until each
+    layer's turn is over) == "units": loss table, sparsity table, drifted weights — through the
+    graph-replayed prefix cache with lanes and batched evaluation, and through plain full
+    forwards (where it runs as "units")."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.losses import loss_vision_language
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+
+    def run(form, cached):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        loss = (PrefixCachedLoss(model, use_graphs=True, n_lanes=2, eval_batch=4, verify_batched="all")
+                if cached else loss_vision_language)
+        np.random.seed(3)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=kern, z_source="philox", k1_form=form)
+        sp = ls.return_sparsity()
+        return ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    for cached in (True, False):
+        a, b = run("units", cached), run("block", cached)
+        assert np.array_equal(a[0], b[0])
+        assert a[1] == b[1]
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_k1_million_elements_vs_oracle(kern, oracle, dt):
     """Rounding ties (~1e-4 of elements) only show up at scale: f32 product first, then the
     storage rounding — never a single rounding of the exact product."""

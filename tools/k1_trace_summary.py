@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--units", type=int, default=16)
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--bench-json", default=None,
+                    help="the JSON line bench.py printed in the same run: its roofline.per_launch "
+                         "bytes are matched to the K1 dispatches in order (needed for the "
+                         "block-batched kernel, whose grid does not name one matrix)")
     args = ap.parse_args()
     by_grid = {}
     for numel, name in SHAPES.items():
@@ -32,7 +36,7 @@ def main():
         rd = csv.DictReader(f)
         fields = rd.fieldnames
         for r in rd:
-            if "zo_perturb_units_kernel" in r["Kernel_Name"]:
+            if "zo_perturb_units_kernel" in r["Kernel_Name"] or "zo_perturb_layers_kernel" in r["Kernel_Name"]:
                 rows.append(r)
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[args.skip:]
@@ -41,12 +45,21 @@ def main():
             w = csv.DictWriter(f, fieldnames=fields, quoting=csv.QUOTE_NONNUMERIC)
             w.writeheader()
             w.writerows(rows)
+    per_launch = None
+    if args.bench_json:
+        line = [ln for ln in open(args.bench_json).read().splitlines() if ln.startswith("{")][-1]
+        per_launch = json.loads(line)["roofline"]["per_launch"]
+        rows = rows[len(rows) - len(per_launch):]          # the timed region's launches
     agg, tot_b, tot_t = {}, 0.0, 0.0
-    for r in rows:
+    for i, r in enumerate(rows):
         g = int(r["Grid_Size_X"])
         name, numel = by_grid.get(g, (f"grid {g}", None))
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         b = (2 * args.units + 2) * 2 * numel if numel else 0
+        if per_launch is not None:
+            b = per_launch[i]["bytes"]
+            if numel is None:
+                name = f"block launch, {b / 1e6:.0f} MB"
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += us
