@@ -513,7 +513,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": k1["gbs"] / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic("units" if kind == "block" else kind, k1["bytes_per_launch"]),
+            "traffic": load_pmc_traffic(kind, k1["bytes_per_launch"]),
             "traffic_source": "profiles/k1_pmc_traffic.json (rocprofv3 --pmc, separate passes)",
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
@@ -564,7 +564,8 @@ def load_pmc_traffic(kind, algorithmic_bytes_per_launch=None):
     if not os.path.exists(path) or algorithmic_bytes_per_launch is None:
         return None
     try:
-        ratio = json.load(open(path)).get(kind, {}).get("traffic_over_algorithmic")
+        doc = json.load(open(path))
+        ratio = (doc.get(kind) or doc.get("units", {})).get("traffic_over_algorithmic")
         return None if ratio is None else ratio * algorithmic_bytes_per_launch
     except Exception:
         return None

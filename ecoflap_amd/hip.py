@@ -261,7 +261,11 @@ class HipKernels:
             assert len(row) == row_len
             rows.append(row)
             total += max(1, -(-(w_in.numel() // per_vec) // 128))
-        table = torch.tensor(rows, dtype=torch.int64, device=layers[0][0].device)
+        # pinned staging + asynchronous copy: a pageable host-to-device copy would make the host
+        # wait here for everything queued on the stream before it (the caching host allocator
+        # keeps the pinned block alive until the copy has run)
+        table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(layers[0][0].device,
+                                                                      non_blocking=True)
         ev = events() if events is not None else (None, None)
         _check(self.lib.ecoflap_zo_perturb_layers(_ptr(table), len(rows), total, DTYPE_CODE[dt],
                                                   float(zo_eps), _stream(), ev[0], ev[1]),

@@ -15,11 +15,11 @@ def capture_graph(graph, **kw):
     objects that own device resources (an older loss closure's HIP graphs, pools, events); their
     destructors call into HIP on the capturing thread, which is illegal under
     capture_error_mode="thread_local" and aborts the process (seen once in ~3 runs of the full-size
-    batched-evaluation test).  torch.cuda.graph collects once on entry; nothing may be freed
+    batched-evaluation test).  No collection is forced here (a full one costs ~85 ms on the
+    BLIP-2 object graph and a stage-1 run captures hundreds of graphs): garbage simply waits
     until the capture has ended."""
     import torch
     was_enabled = gc.isenabled()
-    gc.collect()
     gc.disable()
     try:
         with torch.cuda.graph(graph, **kw):

@@ -162,3 +162,12 @@ def test_argument_errors_of_the_round2_entry_points():
     assert lib.ecoflap_zo_perturb_units_timed(vp(16), 64, 2, 1e-3, 1, seeds, ptrs, ptrs, None, None,
                                               None, vp(16)) == -2
     assert lib.ecoflap_zo_perturb_units(vp(16), 1 << 41, 2, 1e-3, 1, seeds, ptrs, ptrs, None, None) == -3
+    # block-batched K1: table of layers in device memory
+    lay = lambda **kw: lib.ecoflap_zo_perturb_layers(                            # noqa: E731
+        kw.get("table", vp(16)), kw.get("n", 2), kw.get("rows", 64), kw.get("dt", 2), 1e-3, None,
+        kw.get("ev0", None), kw.get("ev1", None))
+    assert lay(n=0) == 0 and lay(rows=0) == 0                                    # empty block
+    assert lay(dt=9) == -1
+    assert lay(n=-1) == -3 and lay(rows=-4) == -3 and lay(rows=1 << 31) == -3
+    assert lay(table=None) == -2
+    assert lay(ev0=vp(16)) == -2                                                 # half an event pair

@@ -23,14 +23,50 @@ SHAPES = [("t5_wi_wo", 5120 * 2048, torch.bfloat16), ("t5_qkvo", 2048 * 2048, to
           ("vit_proj", 1408 * 1408, torch.float16)]
 
 
+BLOCKS = [("t5_block", [2048 * 2048] * 4 + [5120 * 2048] * 3, torch.bfloat16),
+          ("vit_block", [4224 * 1408, 1408 * 1408, 6144 * 1408, 6144 * 1408], torch.float16)]
+
+
+def block_form(kern, U, reps):
+    """One launch per transformer block: every matrix of the block with its U units (the
+    default form of the stage-1 loop).  Two buffer sets per block shape, > 1 GiB each."""
+    plan = []
+    for name, numels, dt in BLOCKS:
+        sets = []
+        for _ in range(2):
+            ws = [torch.randn(n, device="cuda").mul_(0.02).to(dt) for n in numels]
+            fin = [torch.empty_like(w) for w in ws]
+            scr = [torch.empty(2 * U, n, device="cuda", dtype=dt) for n in numels]
+            sets.append((ws, fin, scr))
+        plan.append((name, numels, dt, sets))
+    torch.cuda.synchronize()
+    launches = []
+    for rep in range(reps):
+        for name, numels, dt, sets in plan:
+            for k, (ws, fin, scr) in enumerate(sets):
+                layers = [(w, f, [1000 * rep + 100 * k + 16 * i + u for u in range(U)],
+                           [s[2 * u] for u in range(U)], [s[2 * u + 1] for u in range(U)])
+                          for i, (w, f, s) in enumerate(zip(ws, fin, scr))]
+                kern.zo_perturb_layers(layers, 1e-3)
+                launches.append({"shape": name, "numel": sum(numels), "dtype": str(dt),
+                                 "algorithmic_bytes": (2 * U + 2) * 2 * sum(numels)})
+    torch.cuda.synchronize()
+    print(json.dumps({"units": U, "form": "block", "launches": launches}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--units", type=int, default=16)
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--form", choices=["units", "block"], default="units",
+                    help="block: one zo_perturb_layers launch per transformer block (all of its "
+                         "matrices), as the stage-1 loop issues it by default")
     args = ap.parse_args()
     kern = hip.HipKernels()
     U = args.units
+    if args.form == "block":
+        return block_form(kern, U, args.reps)
     plan = []
     for name, n, dt in SHAPES:
         if args.only and args.only != name:

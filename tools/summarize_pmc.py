@@ -4,7 +4,7 @@ HBM bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md §HBM:
 FETCH_SIZE reports exactly half the bytes of a wide (16 B/lane) coalesced read stream ->
 doubled; WRITE_SIZE is exact for 16 B/lane streaming stores; both are in KiB units.
 
-    python3 tools/summarize_pmc.py <fetch_csv> <write_csv> <launches_json> > profiles/k1_pmc_traffic.json
+    python3 tools/summarize_pmc.py <fetch_csv> <write_csv> <launches_json> [<existing summary to merge into>] > out.json
 """
 import csv
 import json
@@ -21,9 +21,12 @@ def per_kernel(path, counter, kernel_substr):
 
 def main():
     fetch_csv, write_csv, launches_json = sys.argv[1:4]
-    launches = json.load(open(launches_json))["launches"]
-    f = per_kernel(fetch_csv, "FETCH_SIZE", "zo_perturb_units_kernel")
-    w = per_kernel(write_csv, "WRITE_SIZE", "zo_perturb_units_kernel")
+    doc = json.load(open(launches_json))
+    launches = doc["launches"]
+    form = doc.get("form", "units")
+    kernel = {"units": "zo_perturb_units_kernel", "block": "zo_perturb_layers_kernel"}[form]
+    f = per_kernel(fetch_csv, "FETCH_SIZE", kernel)
+    w = per_kernel(write_csv, "WRITE_SIZE", kernel)
     n = min(len(f), len(w), len(launches))
     by_shape = {}
     for i in range(n):
@@ -46,7 +49,12 @@ def main():
                             "traffic_over_algorithmic": traffic / d["algorithmic_bytes"]}
         tot_t += traffic * d["launches"]
         tot_a += d["algorithmic_bytes"] * d["launches"]
-    out["units"] = {"traffic_over_algorithmic": tot_t / tot_a}
+    out[form] = {"traffic_over_algorithmic": tot_t / tot_a}
+    if len(sys.argv) > 4:          # merge into an existing summary (other kernel forms are kept)
+        old = json.load(open(sys.argv[4]))
+        old.setdefault("shapes", {}).update(out["shapes"])
+        old[form] = out[form]
+        out = old
     print(json.dumps(out, indent=1))
 
 
