@@ -383,14 +383,124 @@ struct RowsGroup {
     uint8_t* mask[WMAX];
 };
 
+// ---- helpers shared by the two register forms of the rows mode ----------------------------
+// wave-wide sum on the DPP network (row shifts inside the four 16-lane rows, then the two row
+// broadcasts gfx9 has): 6 full-rate adds, no LDS crossbar, result uniform
+static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// pruned elements -> +0 on the stored bits themselves (kept elements are not re-encoded), and the
+// row's uint8 mask bytes
+template <int DT>
+static __device__ __forceinline__ void zero_pruned(u32x4& wv, const bool* prune) {
+    if (Vec<DT>::N == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = prune[i] ? 0u : wv[i];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            wv[q] &= (prune[2 * q] ? 0u : 0xffffu) | (prune[2 * q + 1] ? 0u : 0xffff0000u);
+    }
+}
+template <int N>
+static __device__ __forceinline__ void store_mask_bytes(uint8_t* mrow, const bool* prune) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i < 4) lo |= (prune[i] ? 1u : 0u) << (8 * i);
+        else hi |= (prune[i] ? 1u : 0u) << (8 * (i - 4));
+    }
+    *(uint32_t*)mrow = lo;
+    if (N == 8) *(uint32_t*)(mrow + 4) = hi;
+}
+
+// count of row elements below cand: per-lane compare + add-with-carry, one DPP reduction
+template <int NV, int N>
+static __device__ __forceinline__ uint32_t wave_count_less(const uint32_t (&m)[NV][N], uint32_t cand) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
+    return wave_sum_dpp(c);
+}
+
+// The rounds on bits 31..16 only look at the HIGH HALVES of the metrics (cand has no low bits
+// there), two elements per register: hi16(x) >= c for both halves of a word with ONE subtraction,
+//   d = (x | 0x80008000) - (c & 0x7fff) * 0x10001   (no borrow leaves a half; bit 15 / 31 of d is
+//   set iff low15(x) >= low15(c));   c < 0x8000: x >= c <=> bit15(x | d);  else bit15(x & d),
+// counted with v_bcnt: 3 instructions per two elements instead of 4 (compare + add-with-carry each,
+// and the v_cmp -> carry-in hazard of this ISA costs a wait state per compare on top).
+template <int NV, int N>
+static __device__ __forceinline__ void gather_hi16(const uint32_t (&m)[NV][N], uint32_t (&x)[NV * N / 2]) {
+#pragma unroll
+    for (int w = 0; w < NV * N / 2; ++w) {
+        const int e = 2 * w;
+        // bytes [b.3 b.2 a.3 a.2]: element e in the low half, e+1 in the high half
+        x[w] = __builtin_amdgcn_perm(m[(e + 1) / N][(e + 1) % N], m[e / N][e % N], 0x07060302u);
+    }
+}
+template <int W, bool KEEP>
+static __device__ __forceinline__ uint32_t wave_count_hi16_ge(const uint32_t (&x)[W], const uint32_t (&xg)[KEEP ? W : 1],
+                                                              uint32_t c) {
+    const uint32_t cl = (c & 0x7fffu) * 0x10001u;
+    const uint32_t K = 0x80008000u;
+    uint32_t cnt = 0;
+    if (c & 0x8000u) {         // wave-uniform
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t d = (KEEP ? xg[KEEP ? w : 0] : (x[w] | K)) - cl;
+            const uint32_t f = __builtin_amdgcn_bitop3_b32(d, x[w], K, 0x80);      // d & x & K
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(f));
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t d = (KEEP ? xg[KEEP ? w : 0] : (x[w] | K)) - cl;
+            const uint32_t f = __builtin_amdgcn_bitop3_b32(d, x[w], K, 0xa8);      // (d | x) & K
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(f));
+        }
+    }
+    return wave_sum_dpp(cnt);
+}
+
+// sum (or max) of one wave-uniform value per wave over the workgroup's four waves, result uniform:
+// lane 0 of each wave writes its value, one barrier (double-buffered by call parity), four reads
+static __device__ __forceinline__ uint32_t block_sum4(uint32_t wave_value, uint32_t* lds8, int phase,
+                                                      int wave, int lane) {
+    uint32_t* buf = lds8 + 4 * (phase & 1);
+    if (lane == 0) buf[wave] = wave_value;
+    __syncthreads();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(buf[0] + buf[1] + buf[2] + buf[3]));
+}
+static __device__ __forceinline__ uint32_t block_max4(uint32_t wave_value, uint32_t* lds8, int phase,
+                                                      int wave, int lane) {
+    uint32_t* buf = lds8 + 4 * (phase & 1);
+    if (lane == 0) buf[wave] = wave_value;
+    __syncthreads();
+    const uint32_t a = buf[0] > buf[1] ? buf[0] : buf[1], b = buf[2] > buf[3] ? buf[2] : buf[3];
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(a > b ? a : b));
+}
+
+// One 256-thread workgroup per row (rows beyond the wave form's reach, and the long rows of a
+// block whose short rows run in the wave form): the same search — bisection over the packed high
+// halves, then the compacted bucket — with the per-probe count summed over the four waves through
+// LDS (one barrier per probe).
 template <int DT, int NV>
-__global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) {
+static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t grow, uint32_t* lds8,
+                                                     uint32_t* wave4, uint32_t* cand_lds, uint32_t* res3) {
     constexpr int N = Vec<DT>::N;
-    __shared__ uint32_t lds8[8];
-    __shared__ uint32_t wave4[4];
-    const int tid = threadIdx.x;
-    const int it = group_item(g, blockIdx.x);
-    const int64_t row = blockIdx.x - g.start[it];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int it = group_item(g, grow);
+    const int64_t row = grow - g.start[it];
     const int64_t cols = g.cols[it], k = g.k[it];
     const float* __restrict__ sq = g.sq[it];
     uint8_t* mask_out = g.mask[it];
@@ -399,10 +509,12 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
     u32x4 wv[NV];
     uint32_t m[NV][N];
 #pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (tid + 256 * j < nvec) wv[j] = ld16(wrow, tid + 256 * j);
+#pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = tid + 256 * j;
         if (v < nvec) {
-            wv[j] = ld16(wrow, v);
             float f[N];
             Vec<DT>::unpack(wv[j], f);
 #pragma unroll
@@ -419,14 +531,8 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
     }
     const bool all = (k >= cols);
     uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
+    int phase = 0;
     if (!all) {
-        // k-th smallest (1-indexed): largest T with #(m < T) < k.  As in the wave form: start at
-        // the row's highest set bit; once the top 16 bits are fixed, compact the elements of that
-        // 16-bit bucket (at most 128) and let ONE wave finish the low 16 bits on them with
-        // ballots — 16 rounds without a block barrier or a pass over the registers.
-        __shared__ uint32_t cand_lds[128];
-        __shared__ uint32_t res3[3];
-        int phase = 0;
         uint32_t mx = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -439,36 +545,31 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
             const uint32_t o = __shfl_xor(mx, off, 64);
             mx = o > mx ? o : mx;
         }
-        if ((tid & 63) == 0) wave4[tid >> 6] = mx;
-        __syncthreads();
-        mx = wave4[0] > wave4[1] ? wave4[0] : wave4[1];
-        mx = wave4[2] > mx ? wave4[2] : mx;
-        mx = wave4[3] > mx ? wave4[3] : mx;
-        __syncthreads();
+        mx = block_max4((uint32_t)__builtin_amdgcn_readfirstlane((int)mx), lds8, phase++, wave, lane);
         const int top = mx ? 31 - __builtin_clz(mx) : -1;
-        uint32_t prefix = 0;
-        for (int bit = top; bit >= 16; --bit) {
-            const uint32_t cand = prefix | (1u << bit);
-            uint32_t c = 0;
+        uint32_t prefix, less16, ncand;
+        {
+            constexpr int WH = NV * N / 2;
+            constexpr uint32_t ALL = 256 * NV * N;
+            uint32_t xh[WH], xg[WH];
+            gather_hi16(m, xh);
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
-#pragma unroll
-                for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
-            c = block_count_256(c, lds8, phase++);
-            if (c < (uint32_t)k) prefix = cand;
-        }
-        // below the bucket / in the bucket, both counts in one reduction (cols < 2^14)
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                packed += (m[j][i] < prefix) ? 0x10000u : 0u;
-                packed += ((m[j][i] ^ prefix) < 0x10000u) ? 1u : 0u;
+            for (int w = 0; w < WH; ++w) xg[w] = xh[w] | 0x80008000u;
+            const uint32_t mx16 = mx >> 16;
+            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t fm = ALL - block_sum4(wave_count_hi16_ge<WH, true>(xh, xg, mid), lds8, phase++, wave, lane);
+                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
             }
-        packed = block_count_256(packed, lds8, phase++);
-        const uint32_t less16 = packed >> 16, ncand = packed & 0xffffu;
+            prefix = lo << 16;
+            less16 = flo;
+            ncand = fhi - flo;
+        }
         if (ncand <= 128) {                               // block-uniform
+            // compact the bucket's elements; ONE wave finishes the low 16 bits on them with
+            // ballots — 16 rounds without a block barrier or a pass over the registers
             uint32_t mine = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -476,15 +577,17 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
                 for (int i = 0; i < N; ++i) mine += ((m[j][i] ^ prefix) < 0x10000u) ? 1u : 0u;
             uint32_t total;
             uint32_t pos = block_scan_256(mine, wave4, total) - mine;
+            if (mine) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
+                for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    if ((m[j][i] ^ prefix) < 0x10000u) cand_lds[pos++] = m[j][i];
+                    for (int i = 0; i < N; ++i)
+                        if ((m[j][i] ^ prefix) < 0x10000u) cand_lds[pos++] = m[j][i];
+            }
             __syncthreads();
-            if (tid < 64) {                               // wave 0 finishes the search
-                const bool v0 = (uint32_t)tid < ncand, v1 = (uint32_t)tid + 64 < ncand;
-                const uint32_t c0 = v0 ? cand_lds[tid] : 0u, c1 = v1 ? cand_lds[tid + 64] : 0u;
+            if (wave == 0) {
+                const bool v0 = (uint32_t)lane < ncand, v1 = (uint32_t)lane + 64 < ncand;
+                const uint32_t c0 = v0 ? cand_lds[lane] : 0u, c1 = v1 ? cand_lds[lane + 64] : 0u;
                 for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
                     const uint32_t cand = prefix | (1u << bit);
                     const uint32_t c = less16 + (uint32_t)__popcll(__ballot(v0 && c0 < cand)) +
@@ -495,98 +598,101 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
                                       (uint32_t)__popcll(__ballot(v1 && c1 < prefix));
                 const uint32_t eq = (uint32_t)__popcll(__ballot(v0 && c0 == prefix)) +
                                     (uint32_t)__popcll(__ballot(v1 && c1 == prefix));
-                if (tid == 0) { res3[0] = prefix; res3[1] = less; res3[2] = eq; }
+                if (lane == 0) { res3[0] = prefix; res3[1] = less; res3[2] = eq; }
             }
             __syncthreads();
-            T = res3[0];
-            total_equal = res3[2];
-            take_equal = (uint32_t)k - res3[1];           // >= 1 of the elements equal to T are pruned
-        } else {                                          // crowded bucket: all elements, as before
+            T = (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[0]);
+            total_equal = (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[2]);
+            take_equal = (uint32_t)k - (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[1]);
+        } else {                                          // crowded bucket: all elements, bit by bit
+            uint32_t less = less16;
             for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
                 const uint32_t cand = prefix | (1u << bit);
-                uint32_t c = 0;
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-#pragma unroll
-                    for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
-                c = block_count_256(c, lds8, phase++);
-                if (c < (uint32_t)k) prefix = cand;
+                const uint32_t c = block_sum4(wave_count_less(m, cand), lds8, phase++, wave, lane);
+                if (c < (uint32_t)k) { prefix = cand; less = c; }
             }
             T = prefix;
-            uint32_t less = 0, eq = 0;
+            uint32_t eq = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    less += (m[j][i] < T) ? 1u : 0u;
-                    eq += (m[j][i] == T) ? 1u : 0u;
-                }
-            less = block_count_256(less, lds8, phase++);
-            total_equal = block_count_256(eq, lds8, phase++);
+                for (int i = 0; i < N; ++i) eq += (m[j][i] == T) ? 1u : 0u;
+            total_equal = block_sum4(wave_sum_dpp(eq), lds8, phase++, wave, lane);
             take_equal = (uint32_t)k - less;
         }
     }
     const bool ordered = !all && (take_equal < total_equal);   // ties cut by column order
+    if (!ordered) {
+        const uint32_t Tq = all ? 0xffffffffu : T;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t v = tid + 256 * j;
+            if (v < nvec) {
+                bool prune[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) prune[i] = m[j][i] <= Tq;
+                zero_pruned<DT>(wv[j], prune);
+                st16(wrow, v, wv[j]);
+                if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
+            }
+        }
+        return;
+    }
     uint32_t running = 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = tid + 256 * j;
-        uint32_t rank0 = 0;
-        if (ordered) {     // block-uniform: equal-to-T elements in lower columns come first
-            uint32_t mine = 0;
+        // block-uniform branch: equal-to-T elements in lower columns come first
+        uint32_t mine = 0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
-            uint32_t total;
-            const uint32_t incl = block_scan_256(mine, wave4, total);
-            rank0 = running + incl - mine;
-            running += total;
-        }
+        for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t incl = block_scan_256(mine, wave4, total);
+        const uint32_t rank0 = running + incl - mine;
+        running += total;
         if (v < nvec) {
-            float f[N];
-            Vec<DT>::unpack(wv[j], f);
-            uint32_t bytes_lo = 0, bytes_hi = 0;
+            bool prune[N];
             uint32_t seen = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const bool eqT = (m[j][i] == T);
-                bool prune = all || (m[j][i] < T) || (eqT && (!ordered || (rank0 + seen) < take_equal));
+                prune[i] = (m[j][i] < T) || (eqT && (rank0 + seen) < take_equal);
                 seen += eqT ? 1u : 0u;
-                if (prune) f[i] = 0.0f;
-                if (i < 4) bytes_lo |= (prune ? 1u : 0u) << (8 * i);
-                else bytes_hi |= (prune ? 1u : 0u) << (8 * (i - 4));
             }
-            st16(wrow, v, Vec<DT>::pack(f));
-            if (mask_out) {
-                uint8_t* mrow = mask_out + row * cols + v * N;
-                *(uint32_t*)mrow = bytes_lo;
-                if (N == 8) *(uint32_t*)(mrow + 4) = bytes_hi;
-            }
+            zero_pruned<DT>(wv[j], prune);
+            st16(wrow, v, wv[j]);
+            if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
         }
     }
 }
 
-// -------------------------------------------------------------------------------------
-// K7 rows mode, wave form (rows of up to 64*12 vectors): ONE 64-lane wave per row, four rows
-// per workgroup.  Counts are ballots: v_cmp writes the lane mask, s_bcnt1 counts it on the
-// scalar unit — the bitwise search needs no shuffle, no LDS and no barrier at all.
-// -------------------------------------------------------------------------------------
-// wave-wide sum on the DPP network (row shifts inside the four 16-lane rows, then the two row
-// broadcasts gfx9 has): 6 full-rate adds, no LDS crossbar, result uniform
-static __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+template <int DT, int NV>
+__global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) {
+    __shared__ uint32_t lds8[8];
+    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t cand_lds[128];
+    __shared__ uint32_t res3[3];
+    rows_reg_body<DT, NV>(g, blockIdx.x, lds8, wave4, cand_lds, res3);
 }
 
+// -------------------------------------------------------------------------------------
+// K7 rows mode, wave form (rows of up to 64*12 vectors): ONE 64-lane wave per row, four rows
+// per workgroup — the search needs no LDS traffic and no barrier at all.
+// -------------------------------------------------------------------------------------
+// One 64-lane wave per row, four rows per workgroup.  (Tried and measured slower on MI355X: a
+// persistent wave walking a run of rows with the next row's loads in flight during the search —
+// all waves then load, search and store in phase and the memory and VALU phases stop overlapping
+// across waves; seeding the search from the previous row's threshold through a word in the
+// workspace — loads of many waves from one address serialise like atomics, ~30 ns each.)
 template <int DT, int NV>
-__global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g) {
+static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_t first_row,
+                                                      uint32_t (*cand_lds_all)[64 * 2]) {
     constexpr int N = Vec<DT>::N;
     const int lane = threadIdx.x & 63;
-    const int64_t grow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (the wave index is uniform, which the compiler cannot see through threadIdx: without the
+    // readfirstlane every per-row scalar — item, k, cols, the search bounds — lives in VGPRs)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t grow = first_row + wave;
     if (grow >= g.start[g.n]) return;          // whole wave leaves together
     const int it = group_item(g, grow);
     const int64_t row = grow - g.start[it];
@@ -595,13 +701,16 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
     uint8_t* mask_out = g.mask[it];
     const int64_t nvec = cols / N;
     void* wrow = (char*)g.w[it] + row * cols * Vec<DT>::BYTES;
+    uint32_t* cand_lds = cand_lds_all[wave];
     u32x4 wv[NV];
     uint32_t m[NV][N];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < nvec) wv[j] = ld16(wrow, lane + 64 * j);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = lane + 64 * j;
         if (v < nvec) {
-            wv[j] = ld16(wrow, v);
             float f[N];
             Vec<DT>::unpack(wv[j], f);
 #pragma unroll
@@ -619,11 +728,11 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
     const bool all = (k >= cols);
     uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
     if (!all) {
-        // k-th smallest (1-indexed) = largest T with #(m < T) < k, found bit by bit.  Two things
-        // keep the search short: it starts at the highest bit set anywhere in the row, and after
-        // the top 16 bits are fixed only the elements that share them (typically ~1 % of a row:
-        // sign + exponent + 7 mantissa bits) can still change a count — they are compacted to
-        // at most two per lane, and the 16 low rounds then cost 2 compares instead of N*NV.
+        // k-th smallest (1-indexed) = largest T with #(m < T) < k.  Its high 16 bits come from a
+        // bisection over the packed high halves; then only the elements that share them
+        // (typically ~1 % of a row: sign + exponent + 7 mantissa bits) can still change a count —
+        // they are compacted to at most two per lane, and the 16 low bits are found bit by bit
+        // with 2 ballots per round instead of a pass over the row.
         uint32_t mx = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -636,32 +745,35 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
             const uint32_t o = __shfl_xor(mx, off, 64);
             mx = o > mx ? o : mx;
         }
+        mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);      // uniform: scalar loop control
         const int top = mx ? 31 - __builtin_clz(mx) : -1;
-        uint32_t prefix = 0;
-        for (int bit = top; bit >= 16; --bit) {
-            // per-lane count (compare + add-with-carry, both full-rate VALU), one DPP reduction
-            // per round — instead of a ballot, an s_bcnt1 and an s_add per element
-            const uint32_t cand = prefix | (1u << bit);
-            uint32_t c = 0;
+        uint32_t prefix, less16, ncand;        // less16 = #(m < prefix), ncand = population of the 16-bit bucket
+        {
+            constexpr int WH = NV * N / 2;
+            constexpr bool KEEPG = NV <= 4;
+            constexpr uint32_t ALL = 64 * NV * N;              // padding (0xffff....) is never "less"
+            uint32_t xh[WH], xg[KEEPG ? WH : 1];
+            gather_hi16(m, xh);
+            if (KEEPG) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
-#pragma unroll
-                for (int i = 0; i < N; ++i) c += (m[j][i] < cand) ? 1u : 0u;
-            if (wave_sum_dpp(c) < (uint32_t)k) prefix = cand;
-        }
-        // elements below the 16-bit bucket of the answer, and the bucket's population
-        uint32_t less16 = 0, ncand = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                less16 += (uint32_t)__popcll(__ballot(m[j][i] < prefix));
-                ncand += (uint32_t)__popcll(__ballot((m[j][i] ^ prefix) < 0x10000u));
+                for (int w = 0; w < WH; ++w) xg[KEEPG ? w : 0] = xh[w] | 0x80008000u;
             }
-        constexpr uint32_t CMAX = 2;                 // candidates per lane
-        __shared__ uint32_t cand_lds[4][64 * CMAX];
-        if (ncand <= 64 * CMAX) {                    // wave-uniform
-            uint32_t* mine = cand_lds[threadIdx.x >> 6];
+            // f(c) = #(hi16(m) < c) is monotone; wanted: p16 = max{c : f(c) < k}.  Bisection on
+            // [lo, hi] with f(lo) < k <= f(hi); the last two values give the bucket's population
+            const uint32_t mx16 = mx >> 16;
+            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }   // every real element is below
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t fm = ALL - wave_count_hi16_ge<WH, KEEPG>(xh, xg, mid);
+                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+            }
+            prefix = lo << 16;
+            less16 = flo;
+            ncand = fhi - flo;
+        }
+        constexpr uint32_t CMAX = 2;             // candidates per lane
+        if (ncand <= 64 * CMAX) {                // wave-uniform
             uint32_t pos = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -669,18 +781,20 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
                 for (int i = 0; i < N; ++i) {
                     const bool hit = (m[j][i] ^ prefix) < 0x10000u;
                     const uint64_t mask = __ballot(hit);
-                    if (hit) mine[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = m[j][i];
-                    pos += (uint32_t)__popcll(mask);
+                    if (mask) {                  // wave-uniform: most element slots have no candidate
+                        if (hit) cand_lds[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = m[j][i];
+                        pos += (uint32_t)__popcll(mask);
+                    }
                 }
             // (same wave wrote and reads: program order, no barrier needed on one SIMD)
-            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): LDS writes done
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes done
             uint32_t cr[CMAX];
             bool cv[CMAX];
 #pragma unroll
             for (uint32_t c = 0; c < CMAX; ++c) {
                 cv[c] = lane + 64 * c < ncand;
-                cr[c] = cv[c] ? mine[lane + 64 * c] : 0u;
+                cr[c] = cv[c] ? cand_lds[lane + 64 * c] : 0u;
             }
             for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
                 const uint32_t cand = prefix | (1u << bit);
@@ -697,71 +811,97 @@ __global__ __launch_bounds__(256) void wanda_rows_wave_kernel(const RowsGroup g)
                 total_equal += (uint32_t)__popcll(__ballot(cv[q] && cr[q] == T));
             }
             take_equal = (uint32_t)k - less;
-        } else {                                     // crowded bucket (few distinct values): all elements
+        } else {                                 // crowded bucket (few distinct values): all elements
+            uint32_t less = less16;
             for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
                 const uint32_t cand = prefix | (1u << bit);
-                uint32_t c = 0;
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-#pragma unroll
-                    for (int i = 0; i < N; ++i) c += (uint32_t)__popcll(__ballot(m[j][i] < cand));
-                if (c < (uint32_t)k) prefix = cand;
+                const uint32_t c = wave_count_less(m, cand);
+                if (c < (uint32_t)k) { prefix = cand; less = c; }
             }
             T = prefix;
-            uint32_t less = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    less += (uint32_t)__popcll(__ballot(m[j][i] < T));
+                for (int i = 0; i < N; ++i)
                     total_equal += (uint32_t)__popcll(__ballot(m[j][i] == T));
-                }
             take_equal = (uint32_t)k - less;
         }
     }
     const bool ordered = !all && (take_equal < total_equal);
-    uint32_t running = 0;
+    if (!ordered) {
+        // every element equal to T goes (or, with k >= cols, every element): prune = m <= T
+        const uint32_t Tq = all ? 0xffffffffu : T;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t v = lane + 64 * j;
+            if (v < nvec) {
+                bool prune[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) prune[i] = m[j][i] <= Tq;
+                zero_pruned<DT>(wv[j], prune);
+                st16(wrow, v, wv[j]);
+                if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
+            }
+        }
+        return;
+    }
+    uint32_t running = 0;                      // ties cut by column order
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = lane + 64 * j;
-        uint32_t rank0 = 0;
-        if (ordered) {      // wave-uniform
-            uint32_t mine = 0;
+        uint32_t mine = 0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
-            uint32_t x = mine;
+        for (int i = 0; i < N; ++i) mine += (m[j][i] == T) ? 1u : 0u;
+        uint32_t x = mine;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t y = __shfl_up(x, off, 64);
-                if (lane >= off) x += y;
-            }
-            rank0 = running + x - mine;
-            running += __shfl(x, 63, 64);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
         }
+        const uint32_t rank0 = running + x - mine;
+        running += __shfl(x, 63, 64);
         if (v < nvec) {
-            float f[N];
-            Vec<DT>::unpack(wv[j], f);
-            uint32_t bytes_lo = 0, bytes_hi = 0, seen = 0;
+            bool prune[N];
+            uint32_t seen = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const bool eqT = (m[j][i] == T);
-                const bool prune = all || (m[j][i] < T) ||
-                                   (eqT && (!ordered || (rank0 + seen) < take_equal));
+                prune[i] = (m[j][i] < T) || (eqT && (rank0 + seen) < take_equal);
                 seen += eqT ? 1u : 0u;
-                if (prune) f[i] = 0.0f;
-                if (i < 4) bytes_lo |= (prune ? 1u : 0u) << (8 * i);
-                else bytes_hi |= (prune ? 1u : 0u) << (8 * (i - 4));
             }
-            st16(wrow, v, Vec<DT>::pack(f));
-            if (mask_out) {
-                uint8_t* mrow = mask_out + row * cols + v * N;
-                *(uint32_t*)mrow = bytes_lo;
-                if (N == 8) *(uint32_t*)(mrow + 4) = bytes_hi;
-            }
+            zero_pruned<DT>(wv[j], prune);
+            st16(wrow, v, wv[j]);
+            if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
         }
     }
 }
 
+template <int DT, int NV>
+__global__ __launch_bounds__(256, 4) void wanda_rows_wave_kernel(const RowsGroup g) {
+    __shared__ uint32_t cand_lds_all[4][64 * 2];
+    rows_wave_body<DT, NV>(g, (int64_t)blockIdx.x * 4, cand_lds_all);
+}
+
+// A block's short rows (wave form) and long rows (workgroup form) in ONE grid: the long rows of a
+// T5 block (2048 rows of 5120 columns) are too few to fill the chip in a launch of their own
+// (measured: 33 us for 22 % of the block's bytes, after the 58 us of the other 78 %), and launches
+// on one stream do not overlap; side streams joined by events cost more than they gave.  The
+// long-row workgroups come first in the grid so that they are not the tail.
+template <int DT, int NVW, int NVR>
+__global__ __launch_bounds__(256, 4) void wanda_rows_fused_kernel(const RowsGroup gw, const RowsGroup gr) {
+    __shared__ uint32_t cand_lds_all[4][64 * 2];      // wave form: 2 candidates per lane and wave
+    __shared__ uint32_t lds8[8];
+    __shared__ uint32_t wave4[4];
+    __shared__ uint32_t res3[3];
+    const int64_t n_long = gr.start[gr.n];
+    if ((int64_t)blockIdx.x < n_long)
+        rows_reg_body<DT, NVR>(gr, blockIdx.x, lds8, wave4, &cand_lds_all[0][0], res3);
+    else
+        rows_wave_body<DT, NVW>(gw, ((int64_t)blockIdx.x - n_long) * 4, cand_lds_all);
+}
+
+#define ROWS_WAVE_MAX_NVEC 256                           // 4 vectors per lane (2048 bf16 columns)
+#define ROWS_FUSE_MAX_NVEC 1024                          // workgroup-form rows that may share a grid: 4 vectors per thread
 static inline int rows_wave_class(int64_t nvec) {       // vectors per lane, one wave per row
     const int nv = (int)((nvec + 63) / 64);
     return nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
@@ -780,6 +920,20 @@ static void launch_rows_wave(const RowsGroup& g, int nv, hipStream_t s) {
     if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1>), grid, blk, 0, s, g);
     else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2>), grid, blk, 0, s, g);
     else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4>), grid, blk, 0, s, g);
+}
+
+template <int DT>
+static void launch_rows_fused(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
+    const dim3 grid((unsigned)(gr.start[gr.n] + (gw.start[gw.n] + 3) / 4)), blk(256);
+#define FUSED(W_, R_) hipLaunchKernelGGL((wanda_rows_fused_kernel<DT, W_, R_>), grid, blk, 0, s, gw, gr)
+#define FUSED_R(W_)                                                          \
+    do {                                                                     \
+        if (nvr == 1) FUSED(W_, 1); else if (nvr == 2) FUSED(W_, 2);         \
+        else if (nvr == 3) FUSED(W_, 3); else FUSED(W_, 4);                  \
+    } while (0)
+    if (nvw == 1) FUSED_R(1); else if (nvw == 2) FUSED_R(2); else FUSED_R(4);
+#undef FUSED_R
+#undef FUSED
 }
 
 template <int DT>
@@ -1141,6 +1295,11 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     for (int i = 0; i < n_items; ++i) done[i] = false;
 
     // ---- rows mode -------------------------------------------------------------------------
+    // Groups of one (dtype, form, register class) each; a wave-form group and a workgroup-form
+    // group of the same dtype share one grid when the long rows fit 4 vectors per thread.
+    struct Pending { RowsGroup g; int dtype, cls; bool wave, used; };
+    static thread_local Pending pend[8];
+    int n_pend = 0;
     for (int i = 0; i < n_items; ++i) {
         if (done[i] || items[i].mode != ECOFLAP_WANDA_ROWS) continue;
         const ecoflap_wanda_item& a = items[i];
@@ -1154,12 +1313,23 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             done[i] = true;
             continue;
         }
-        // measured on MI355X: the wave form wins up to 256 vectors per row (2048 bf16 columns),
-        // the workgroup form beyond
+        // measured on MI355X: the wave form wins up to 256 vectors per row (2048 bf16 columns)
         const int64_t nvec = a.cols / nve;
-        const bool wave = nvec <= 256;
+        const bool wave = nvec <= ROWS_WAVE_MAX_NVEC;
         const int cls = wave ? rows_wave_class(nvec) : rows_reg_class(nvec);
-        RowsGroup g;
+        if (n_pend == 8) {                   // more classes than slots: flush what is pending
+            for (int q = 0; q < n_pend; ++q) {
+                Pending& P = pend[q];
+#define ROWS_GO(DT_) do { if (P.wave) launch_rows_wave<DT_>(P.g, P.cls, s); else launch_rows_reg<DT_>(P.g, P.cls, s); } while (0)
+                DT_SWITCH(P.dtype, ROWS_GO);
+#undef ROWS_GO
+                ECO_CHECK_LAUNCH();
+            }
+            n_pend = 0;
+        }
+        Pending& P = pend[n_pend++];
+        P.dtype = a.dtype; P.cls = cls; P.wave = wave; P.used = false;
+        RowsGroup& g = P.g;
         g.n = 0;
         g.start[0] = 0;
         for (int j = i; j < n_items; ++j) {
@@ -1167,17 +1337,38 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             if (done[j] || b.mode != ECOFLAP_WANDA_ROWS || b.dtype != a.dtype || !item_vector_ok(b, sq[j]))
                 continue;
             const int64_t nvb = b.cols / nve;
-            const bool wb = nvb <= 256;
+            const bool wb = nvb <= ROWS_WAVE_MAX_NVEC;
             if (wb != wave || (wb ? rows_wave_class(nvb) : rows_reg_class(nvb)) != cls) continue;
-            if ((int64_t)g.start[g.n] + b.rows > 0x7fffffffLL) continue;   // next group
+            if ((int64_t)g.start[g.n] + b.rows > 0x3fffffffLL) continue;   // next group
             g.w[g.n] = b.w; g.sq[g.n] = sq[j]; g.cols[g.n] = b.cols; g.k[g.n] = b.k; g.mask[g.n] = b.mask_out;
             g.start[g.n + 1] = g.start[g.n] + (int32_t)b.rows;
             ++g.n;
             done[j] = true;
         }
-#define ROWS_GO(DT_) do { if (wave) launch_rows_wave<DT_>(g, cls, s); else launch_rows_reg<DT_>(g, cls, s); } while (0)
-        DT_SWITCH(a.dtype, ROWS_GO);
+    }
+    for (int q = 0; q < n_pend; ++q) {
+        Pending& P = pend[q];
+        if (P.used) continue;
+        P.used = true;
+        Pending* mate = nullptr;             // the other form, same dtype, long rows of <= 4 vectors per thread
+        for (int r = q + 1; r < n_pend && !mate; ++r) {
+            Pending& Q = pend[r];
+            if (Q.used || Q.dtype != P.dtype || Q.wave == P.wave) continue;
+            const Pending& longer = P.wave ? Q : P;
+            if (longer.cls <= 4) mate = &Q;
+        }
+        if (mate) {
+            mate->used = true;
+            const Pending& W = P.wave ? P : *mate;
+            const Pending& L = P.wave ? *mate : P;
+#define FUSED_GO(DT_) launch_rows_fused<DT_>(W.g, W.cls, L.g, L.cls, s)
+            DT_SWITCH(P.dtype, FUSED_GO);
+#undef FUSED_GO
+        } else {
+#define ROWS_GO(DT_) do { if (P.wave) launch_rows_wave<DT_>(P.g, P.cls, s); else launch_rows_reg<DT_>(P.g, P.cls, s); } while (0)
+            DT_SWITCH(P.dtype, ROWS_GO);
 #undef ROWS_GO
+        }
         ECO_CHECK_LAUNCH();
     }
 

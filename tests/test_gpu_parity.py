@@ -524,6 +524,40 @@ def test_wanda_block_call_equals_oracle_per_matrix(kern, oracle):
             assert torch.equal(mask.cpu(), mref), (mode, tuple(wg.shape))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("short_vec,long_vec,levels", [
+    (64, 300, None), (128, 600, 3), (256, 1000, None), (200, 257, 40), (33, 640, None)])
+def test_wanda_block_short_and_long_rows_share_one_grid(kern, oracle, dt, short_vec, long_vec, levels):
+    """Rows-mode items of the wave form (<= 256 vectors per row) and of the workgroup form
+    (257..1024 vectors) in one block call take the fused grid: every register-class pairing, ties
+    (few distinct values: the crowded-bucket path and the column-order cut), k = 0 and k = cols,
+    with and without masks == the oracle matrix by matrix, bit for bit."""
+    torch.manual_seed(short_vec * 7 + long_vec)
+    n = 4 if dt == torch.float32 else 8
+    spec = [(9, short_vec * n, 0.5, True), (6, long_vec * n, 0.5, True), (5, short_vec * n, 0.31, False),
+            (3, long_vec * n, 0.77, True), (4, short_vec * n, 0.0, True), (2, long_vec * n, 1.0, True)]
+    items, refs = [], []
+    for rows, cols, frac, want_mask in spec:
+        w = torch.randn(rows, cols) * 0.05
+        if levels:
+            w = _ties(w, levels)
+        w = w.to(dt)
+        sr = torch.rand(cols) + 0.1
+        if levels:
+            sr = torch.round(sr * 2) / 2 + 0.5
+        k = int(cols * frac)
+        mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda") if want_mask else None
+        wg = gpu(w.clone())
+        items.append((wg, gpu(sr), "rows", k, mask))
+        wr = w.clone()
+        refs.append((wr, oracle.wanda_prune_rows(wr, sr, k)))
+    kern.wanda_prune_block(items)
+    for (wg, _, _, k, mask), (wr, mref) in zip(items, refs):
+        assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8)), tuple(wg.shape)
+        if mask is not None:
+            assert torch.equal(mask.cpu(), mref), tuple(wg.shape)
+
+
 def test_wanda_block_full_size_blocks_equal_single_calls(kern):
     """A ViT-g block (4 fp16 matrices, matrix mode) and a FlanT5-XL decoder block (11 bf16
     matrices, rows mode) at BASELINE size: block call == one call per matrix, bit for bit."""

@@ -31,6 +31,11 @@ def timed(fn, n_sets, reps=3, fresh=False):
 
 
 def main():
+    # --only k6,rows,matrix,syrk: sections to run (default all)
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    want = lambda tag: only is None or tag in only          # noqa: E731
     kern = hip.HipKernels()
     res = []
     # K6: hooked Linear inputs of one calibration batch (bs 8)
@@ -38,6 +43,8 @@ def main():
                                    ("vit fc2 input", 8 * 257, 6144, torch.float16),
                                    ("t5 enc q/k/v/wi input", 8 * 48, 2048, torch.bfloat16),
                                    ("t5 enc wo input", 8 * 48, 5120, torch.bfloat16)]:
+        if not want("k6"):
+            break
         nbytes = tokens * cols * torch.empty(0, dtype=dt).element_size()
         sets = max(2, int(6e8 // nbytes))
         xs = [torch.randn(tokens, cols, device="cuda").to(dt) for _ in range(sets)]
@@ -51,6 +58,8 @@ def main():
                                        ("vit fc1 6144x1408", 6144, 1408, torch.float16, "matrix"),
                                        ("vit qkv 4224x1408", 4224, 1408, torch.float16, "matrix"),
                                        ("vit proj 1408x1408", 1408, 1408, torch.float16, "matrix")]:
+        if not want(mode):
+            continue
         es = torch.empty(0, dtype=dt).element_size()
         nbytes = 2 * es * rows * cols + 4 * cols
         sets = max(3, int(6e8 // (rows * cols * es)))
@@ -71,6 +80,8 @@ def main():
               ("t5 decoder block (11 bf16)", "rows", torch.bfloat16,
                [(2048, 2048)] * 8 + [(5120, 2048)] * 2 + [(2048, 5120)])]
     for name, mode, dt, shapes in blocks:
+        if not want(mode):
+            continue
         es = 2
         nbytes = sum(2 * es * r * c + 4 * c for r, c in shapes)
         sets = max(3, int(8e8 // (nbytes // 2)))
@@ -88,6 +99,8 @@ def main():
     for name, tokens, cols, dt in [("vit fc2 input [2056, 6144] fp16", 8 * 257, 6144, torch.float16),
                                    ("vit qkv input [2056, 1408] fp16", 8 * 257, 1408, torch.float16),
                                    ("t5 wo input [384, 5120] bf16", 384, 5120, torch.bfloat16)]:
+        if not want("syrk"):
+            break
         xs = [torch.randn(tokens, cols, device="cuda").to(dt) for _ in range(3)]
         H = torch.zeros(cols, cols, device="cuda")
         med, mn = timed(lambda i: kern.hessian_accum(H, xs[i], 8 * i, 8), 3)
