@@ -255,11 +255,16 @@ struct SqrtGroup {
     const float* src[WMAX];
     float* dst[WMAX];
     int64_t cols[WMAX];
+    uint32_t* zero[WMAX];         // matrix mode: the item's selection state, cleared here (no memset launch)
+    int zero_words;
 };
 __global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
     const int it = group_item(g, blockIdx.x);
-    const int64_t c = (int64_t)(blockIdx.x - g.start[it]) * 256 + threadIdx.x;
+    const int lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    const int64_t c = (int64_t)lb * 256 + threadIdx.x;
     if (c < g.cols[it]) g.dst[it][c] = __builtin_sqrtf(g.src[it][c]);
+    if (g.zero[it])
+        for (int i = lb * 256 + threadIdx.x; i < g.zero_words; i += nb * 256) g.zero[it][i] = 0u;
 }
 
 template <int DT>
@@ -959,15 +964,21 @@ static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
 // =====================================================================================
 struct MatrixSelState {
     uint32_t hist[3][2048];
+    uint32_t resolved[3][2];      // (prefix, remaining rank) after pass 1, 2, 3
+    uint32_t pad[58];
 };
 
-// Matrix mode runs FEW, LARGE workgroups (1024 threads, at most 64 per matrix): every workgroup
-// merges its LDS histogram into the matrix's global one with one atomic per non-empty bin, and
-// those atomics all meet at the memory side — with 1024 workgroups per matrix that merge, not
-// the read of W, was the whole cost of a pass (measured: 74 us for a 50 MB ViT-g block).
+// Matrix mode runs FEW, LARGE workgroups (1024 threads, 256 over the launch, shared out by size):
+// every workgroup merges its LDS histogram into the matrix's global one with one atomic per
+// non-empty bin, and those atomics all meet at the memory side — with 1024 workgroups per matrix
+// that merge, not the read of W, was the whole cost of a pass (measured: 74 us for a 50 MB ViT-g
+// block).  What a pass costs today is mostly fixed: a matrix of 2 M elements takes ~10 us per
+// pass like one of 8 M (launch, zeroing + staging LDS, resolving the earlier passes from the
+// global histograms, the merge); the streaming itself runs at > 5 TB/s.
 #define WM_THREADS 1024
 #define WM_WAVES (WM_THREADS / 64)
-#define WM_MAX_WGS 64
+#define WM_TOTAL_WGS 256     // one workgroup per CU over the whole launch (measured: 128 and 512 both slower)
+#define WM_SUB0 4            // interleaved counters per bin in the first pass
 #define WM_UNROLL 4
 #define WM_SQ_LDS 16384      // columns whose sqrt table is staged in LDS (64 KiB of the CU's 160)
 
@@ -1008,47 +1019,50 @@ static __device__ __forceinline__ uint32_t block_scan_wm(uint32_t v, uint32_t* l
     return x + base;
 }
 
-// Every workgroup resolves the previous passes itself from the global histograms (8 KB each,
-// L2-resident): bin = first bin whose inclusive count reaches `remaining`.  Identical in every
-// workgroup, so no separate "pick" launch and no inter-workgroup hand-off is needed.
+// Every workgroup resolves the LATEST pass itself from its global histogram (8 KB, L2-resident):
+// bin = first bin whose inclusive count reaches `remaining`.  Identical in every workgroup, so no
+// separate "pick" launch and no inter-workgroup hand-off is needed; the result (prefix, remaining)
+// is left in the state by the matrix's first workgroup, so the next pass starts from it instead
+// of resolving all earlier passes again.  Two adjacent bins per thread: one block scan per pick.
 static __device__ __forceinline__ void pick_bin(const uint32_t* __restrict__ hist, int bins,
                                                 uint32_t remaining, uint32_t* lds_waves,
                                                 uint32_t* out2 /* LDS: bin, new remaining */) {
-    uint32_t carry = 0;
-    for (int base = 0; base < bins; base += WM_THREADS) {
-        const uint32_t cnt = hist[base + threadIdx.x];
-        uint32_t total;
-        const uint32_t incl = block_scan_wm(cnt, lds_waves, total) + carry;
-        const uint32_t excl = incl - cnt;
-        if (excl < remaining && remaining <= incl) {
-            out2[0] = (uint32_t)(base + threadIdx.x);
-            out2[1] = remaining - excl;
-        }
-        carry += total;
+    const int b0 = 2 * (int)threadIdx.x;
+    uint32_t c0 = 0, c1 = 0;
+    if (b0 < bins) {
+        const uint2 two = *(const uint2*)(hist + b0);
+        c0 = two.x; c1 = two.y;
+    }
+    uint32_t total;
+    const uint32_t incl = block_scan_wm(c0 + c1, lds_waves, total);
+    const uint32_t excl = incl - (c0 + c1);
+    if (excl < remaining && remaining <= incl) {
+        const bool second = remaining > excl + c0;
+        out2[0] = (uint32_t)(b0 + (second ? 1 : 0));
+        out2[1] = remaining - excl - (second ? c0 : 0u);
     }
     __syncthreads();
 }
 
 // prefix (selected high bits) and remaining rank after `upto` resolved passes
-static __device__ __forceinline__ void resolve(const MatrixSelState* st, int upto, uint32_t rank0,
+static __device__ __forceinline__ void resolve(MatrixSelState* st, int upto, uint32_t rank0, bool writer,
                                                uint32_t* wave4, uint32_t* out2, uint32_t& prefix,
                                                uint32_t& remaining) {
     prefix = 0;
     remaining = rank0;
-    if (upto >= 1) {
-        pick_bin(st->hist[0], 2048, remaining, wave4, out2);
-        prefix |= out2[0] << 21; remaining = out2[1];
-        __syncthreads();
-    }
+    if (upto == 0) return;
     if (upto >= 2) {
-        pick_bin(st->hist[1], 2048, remaining, wave4, out2);
-        prefix |= out2[0] << 10; remaining = out2[1];
-        __syncthreads();
+        prefix = st->resolved[upto - 2][0];
+        remaining = st->resolved[upto - 2][1];
     }
-    if (upto >= 3) {
-        pick_bin(st->hist[2], 1024, remaining, wave4, out2);
-        prefix |= out2[0]; remaining = out2[1];
-        __syncthreads();
+    const int shift = upto == 1 ? 21 : (upto == 2 ? 10 : 0);
+    pick_bin(st->hist[upto - 1], upto == 3 ? 1024 : 2048, remaining, wave4, out2);
+    prefix |= out2[0] << shift;
+    remaining = out2[1];
+    __syncthreads();
+    if (writer && threadIdx.x == 0) {
+        st->resolved[upto - 1][0] = prefix;
+        st->resolved[upto - 1][1] = remaining;
     }
 }
 
@@ -1064,7 +1078,7 @@ struct MatGroup {
     uint8_t* mask[WMAX];
 };
 
-template <int DT, int PASS, bool VECTOR>
+template <int DT, int PASS, bool VECTOR, int SUB = 1>
 __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const MatGroup g) {
     const int it = group_item(g, blockIdx.x);
     const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
@@ -1077,12 +1091,15 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const Mat
     constexpr int BITS = PASS == 2 ? 10 : 11;
     constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
     constexpr int N = Vec<DT>::N;
-    __shared__ uint32_t h[2048];
+    // SUB > 1: SUB interleaved counters per bin, chosen by the lane — the top digit has few
+    // distinct values, and lanes of one LDS atomic that meet at one address are served one by one
+    __shared__ uint32_t h[2048 * SUB];
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
-    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) h[i] = 0;
+    for (int i = threadIdx.x; i < 2048 * SUB; i += WM_THREADS) h[i] = 0;
+    const uint32_t sub = SUB > 1 ? (threadIdx.x & (SUB - 1)) : 0u;
     uint32_t prefix, remaining;
-    resolve(st, PASS, rank0, wave4, out2, prefix, remaining);
+    resolve(st, PASS, rank0, lb == 0, wave4, out2, prefix, remaining);
     __syncthreads();
     __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
     if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
@@ -1116,7 +1133,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const Mat
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
-                        if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+                        if ((b & HI_MASK) == prefix) atomicAdd(&h[((b >> SHIFT) & ((1u << BITS) - 1u)) * SUB + sub], 1u);
                     }
                 }
             }
@@ -1125,12 +1142,16 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const Mat
         for (int64_t r = lb; r < rows; r += nb)
             for (int64_t c = threadIdx.x; c < cols; c += WM_THREADS) {
                 const uint32_t b = metric_bits<DT>(w, r * cols + c, sq[c]);
-                if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & ((1u << BITS) - 1u)], 1u);
+                if ((b & HI_MASK) == prefix) atomicAdd(&h[((b >> SHIFT) & ((1u << BITS) - 1u)) * SUB + sub], 1u);
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (1 << BITS); i += WM_THREADS)
-        if (h[i]) atomicAdd(&st->hist[PASS][i], h[i]);
+    for (int i = threadIdx.x; i < (1 << BITS); i += WM_THREADS) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < SUB; ++q) c += h[i * SUB + q];
+        if (c) atomicAdd(&st->hist[PASS][i], c);
+    }
 }
 
 template <int DT, bool VECTOR>
@@ -1141,13 +1162,13 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
     const float* sq = g.sq[it];
     const int64_t rows = g.rows[it], cols = g.cols[it];
     const uint32_t rank0 = g.rank0[it];
-    const MatrixSelState* st = g.st[it];
+    MatrixSelState* st = g.st[it];
     uint8_t* mask_out = g.mask[it];
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
     uint32_t thres_bits, remaining;
-    resolve(st, 3, rank0, wave4, out2, thres_bits, remaining);
+    resolve(st, 3, rank0, false, wave4, out2, thres_bits, remaining);
     const float thres = __uint_as_float(thres_bits);
     __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
     if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
@@ -1275,16 +1296,15 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         p += sizeof(MatrixSelState);
         any_matrix = any_matrix || items[i].mode == ECOFLAP_WANDA_MATRIX;
     }
-    if (any_matrix) {
-        hipError_t e = hipMemsetAsync(st[0], 0, sizeof(MatrixSelState) * (size_t)n_items, s);
-        if (e != hipSuccess) return (int)e;
-    }
+    (void)any_matrix;
     {
         SqrtGroup g;
         g.n = n_items;
+        g.zero_words = (int)(sizeof(MatrixSelState) / sizeof(uint32_t));
         g.start[0] = 0;
         for (int i = 0; i < n_items; ++i) {
             g.src[i] = items[i].scaler_row; g.dst[i] = sq[i]; g.cols[i] = items[i].cols;
+            g.zero[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)st[i] : nullptr;
             g.start[i + 1] = g.start[i] + (int32_t)((items[i].cols + 255) / 256);
         }
         hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)g.start[n_items]), dim3(256), 0, s, g);
@@ -1380,27 +1400,37 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         MatGroup g;
         g.n = 0;
         g.start[0] = 0;
+        // the group's workgroups are shared out in proportion to the matrices' sizes (equal work
+        // per workgroup: a ViT-g block's matrices differ 4x), WM_TOTAL_WGS over the launch
+        int members[WMAX];
+        int64_t total_elems = 0;
         for (int j = i; j < n_items; ++j) {
             const ecoflap_wanda_item& b = items[j];
             if (done[j] || b.dtype != a.dtype || item_vector_ok(b, sq[j]) != vec) continue;
-            const int64_t n = b.rows * b.cols;
-            // >= 4 vectors per thread and pass; at most WM_MAX_WGS histogram merges per matrix
-            int64_t nb = vec ? (n / (b.dtype == ECOFLAP_F32 ? 4 : 8) + 4 * WM_THREADS - 1) / (4 * WM_THREADS)
-                             : (b.rows + 3) / 4;
-            if (nb < 1) nb = 1;
-            if (nb > WM_MAX_WGS) nb = WM_MAX_WGS;
-            g.w[g.n] = b.w; g.sq[g.n] = sq[j]; g.rows[g.n] = b.rows; g.cols[g.n] = b.cols;
-            g.rank0[g.n] = (uint32_t)(b.k + 1);     // sorted[k], 0-indexed -> (k+1)-th smallest
-            g.st[g.n] = st[j]; g.mask[g.n] = b.mask_out;
-            g.start[g.n + 1] = g.start[g.n] + (int32_t)nb;
-            ++g.n;
+            members[g.n++] = j;
+            total_elems += b.rows * b.cols;
             done[j] = true;
+        }
+        const int budget = WM_TOTAL_WGS;
+        for (int q = 0; q < g.n; ++q) {
+            const ecoflap_wanda_item& b = items[members[q]];
+            const int64_t n = b.rows * b.cols;
+            // >= 4 vectors per thread and pass
+            int64_t cap = vec ? (n / (b.dtype == ECOFLAP_F32 ? 4 : 8) + 4 * WM_THREADS - 1) / (4 * WM_THREADS)
+                              : (b.rows + 3) / 4;
+            int64_t nb = (int64_t)((double)budget * (double)n / (double)total_elems + 0.5);
+            if (nb > cap) nb = cap;
+            if (nb < 1) nb = 1;
+            g.w[q] = b.w; g.sq[q] = sq[members[q]]; g.rows[q] = b.rows; g.cols[q] = b.cols;
+            g.rank0[q] = (uint32_t)(b.k + 1);     // sorted[k], 0-indexed -> (k+1)-th smallest
+            g.st[q] = st[members[q]]; g.mask[q] = b.mask_out;
+            g.start[q + 1] = g.start[q] + (int32_t)nb;
         }
         const dim3 grid((unsigned)g.start[g.n]), blk(WM_THREADS);
 #define MATRIX_GO(DT_)                                                                              \
     do {                                                                                            \
         if (vec) {                                                                                  \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, true>), grid, blk, 0, s, g);       \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, true, WM_SUB0>), grid, blk, 0, s, g); \
             hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, true>), grid, blk, 0, s, g);       \
             hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, true>), grid, blk, 0, s, g);       \
             hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, true>), grid, blk, 0, s, g);         \
