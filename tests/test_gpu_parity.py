@@ -558,6 +558,42 @@ def test_wanda_block_short_and_long_rows_share_one_grid(kern, oracle, dt, short_
             assert torch.equal(mask.cpu(), mref), tuple(wg.shape)
 
 
+def test_wanda_rows_random_shapes_vs_oracle(kern, oracle):
+    """Rows mode over random widths (every wave / workgroup register class, vector and odd
+    widths), dtypes, k and tie densities, several matrices per block call == oracle, bit for bit."""
+    import random
+    rng = random.Random(1234)
+    for case in range(12):
+        torch.manual_seed(1000 + case)
+        items, refs = [], []
+        for _ in range(rng.randint(2, 5)):
+            dt = rng.choice(DTYPES)
+            n = 4 if dt == torch.float32 else 8
+            cols = rng.choice([rng.randint(1, 60) * n, rng.randint(60, 300) * n, rng.randint(300, 1100) * n,
+                               rng.randint(1100, 1900) * n, rng.randint(3, 4000)])
+            cols = min(cols, 15360)
+            rows = rng.randint(1, 7)
+            w = torch.randn(rows, cols) * 0.05
+            levels = rng.choice([None, None, 3, 50])
+            if levels:
+                w = _ties(w, levels)
+            w = w.to(dt)
+            sr = torch.rand(cols) + 0.1
+            if levels:
+                sr = torch.round(sr * 2) / 2 + 0.5
+            k = rng.choice([0, cols, cols // 2, rng.randint(0, cols)])
+            mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda") if rng.random() < 0.7 else None
+            wg = gpu(w.clone())
+            items.append((wg, gpu(sr), "rows", k, mask))
+            wr = w.clone()
+            refs.append((wr, oracle.wanda_prune_rows(wr, sr, k)))
+        kern.wanda_prune_block(items)
+        for (wg, _, _, k, mask), (wr, mref) in zip(items, refs):
+            assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8)), (case, tuple(wg.shape), k)
+            if mask is not None:
+                assert torch.equal(mask.cpu(), mref), (case, tuple(wg.shape), k)
+
+
 def test_wanda_block_full_size_blocks_equal_single_calls(kern):
     """A ViT-g block (4 fp16 matrices, matrix mode) and a FlanT5-XL decoder block (11 bf16
     matrices, rows mode) at BASELINE size: block call == one call per matrix, bit for bit."""
