@@ -1024,39 +1024,43 @@ static __device__ __forceinline__ uint32_t block_scan_wm(uint32_t v, uint32_t* l
 // separate "pick" launch and no inter-workgroup hand-off is needed; the result (prefix, remaining)
 // is left in the state by the matrix's first workgroup, so the next pass starts from it instead
 // of resolving all earlier passes again.  Two adjacent bins per thread: one block scan per pick.
-static __device__ __forceinline__ void pick_bin(const uint32_t* __restrict__ hist, int bins,
-                                                uint32_t remaining, uint32_t* lds_waves,
-                                                uint32_t* out2 /* LDS: bin, new remaining */) {
+struct PickLoad {                // the pick's global loads, issued before anything that can wait on memory
+    uint32_t c0, c1, prefix, remaining;
+};
+static __device__ __forceinline__ PickLoad pick_load(const MatrixSelState* st, int upto, uint32_t rank0) {
+    PickLoad p;
+    p.c0 = p.c1 = 0; p.prefix = 0; p.remaining = rank0;
+    if (upto == 0) return p;
+    const int bins = upto == 3 ? 1024 : 2048;
     const int b0 = 2 * (int)threadIdx.x;
-    uint32_t c0 = 0, c1 = 0;
     if (b0 < bins) {
-        const uint2 two = *(const uint2*)(hist + b0);
-        c0 = two.x; c1 = two.y;
+        const uint2 two = *(const uint2*)(st->hist[upto - 1] + b0);
+        p.c0 = two.x; p.c1 = two.y;
     }
-    uint32_t total;
-    const uint32_t incl = block_scan_wm(c0 + c1, lds_waves, total);
-    const uint32_t excl = incl - (c0 + c1);
-    if (excl < remaining && remaining <= incl) {
-        const bool second = remaining > excl + c0;
-        out2[0] = (uint32_t)(b0 + (second ? 1 : 0));
-        out2[1] = remaining - excl - (second ? c0 : 0u);
+    if (upto >= 2) {
+        p.prefix = st->resolved[upto - 2][0];
+        p.remaining = st->resolved[upto - 2][1];
     }
-    __syncthreads();
+    return p;
 }
 
 // prefix (selected high bits) and remaining rank after `upto` resolved passes
-static __device__ __forceinline__ void resolve(MatrixSelState* st, int upto, uint32_t rank0, bool writer,
+static __device__ __forceinline__ void resolve(MatrixSelState* st, int upto, const PickLoad& p, bool writer,
                                                uint32_t* wave4, uint32_t* out2, uint32_t& prefix,
                                                uint32_t& remaining) {
-    prefix = 0;
-    remaining = rank0;
+    prefix = p.prefix;
+    remaining = p.remaining;
     if (upto == 0) return;
-    if (upto >= 2) {
-        prefix = st->resolved[upto - 2][0];
-        remaining = st->resolved[upto - 2][1];
+    uint32_t total;
+    const uint32_t incl = block_scan_wm(p.c0 + p.c1, wave4, total);
+    const uint32_t excl = incl - (p.c0 + p.c1);
+    if (excl < remaining && remaining <= incl) {
+        const bool second = remaining > excl + p.c0;
+        out2[0] = (uint32_t)(2 * threadIdx.x + (second ? 1 : 0));
+        out2[1] = remaining - excl - (second ? p.c0 : 0u);
     }
+    __syncthreads();
     const int shift = upto == 1 ? 21 : (upto == 2 ? 10 : 0);
-    pick_bin(st->hist[upto - 1], upto == 3 ? 1024 : 2048, remaining, wave4, out2);
     prefix |= out2[0] << shift;
     remaining = out2[1];
     __syncthreads();
@@ -1096,13 +1100,14 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_hist_kernel(const Mat
     __shared__ uint32_t h[2048 * SUB];
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
+    const PickLoad pl = pick_load(st, PASS, rank0);   // in flight while the LDS is set up
     for (int i = threadIdx.x; i < 2048 * SUB; i += WM_THREADS) h[i] = 0;
     const uint32_t sub = SUB > 1 ? (threadIdx.x & (SUB - 1)) : 0u;
-    uint32_t prefix, remaining;
-    resolve(st, PASS, rank0, lb == 0, wave4, out2, prefix, remaining);
-    __syncthreads();
     __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
     if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
+    uint32_t prefix, remaining;
+    resolve(st, PASS, pl, lb == 0, wave4, out2, prefix, remaining);
+    __syncthreads();
     if (VECTOR) {
         const int64_t vpr = cols / N;                 // vectors per row
         const int64_t nvec = rows * vpr;
@@ -1167,11 +1172,12 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
-    uint32_t thres_bits, remaining;
-    resolve(st, 3, rank0, false, wave4, out2, thres_bits, remaining);
-    const float thres = __uint_as_float(thres_bits);
+    const PickLoad pl = pick_load(st, 3, rank0);
     __shared__ __attribute__((aligned(16))) float sq_lds[VECTOR ? WM_SQ_LDS : 4];
     if (VECTOR) sq = stage_sq(sq, cols, sq_lds);
+    uint32_t thres_bits, remaining;
+    resolve(st, 3, pl, false, wave4, out2, thres_bits, remaining);
+    const float thres = __uint_as_float(thres_bits);
     if (VECTOR) {
         const int64_t vpr = cols / N;
         const int64_t nvec = rows * vpr;
