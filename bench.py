@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--num-data", type=int, default=128, help="calibration pairs per rank")
     ap.add_argument("--batch-size", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", default=None,
+                    help="analysis only: comma-separated matrix indices to time instead of the strided "
+                         "sample (--steps is set to their count; not the headline workload)")
     ap.add_argument("--cpu-baseline-layer", type=int, default=-1)
     ap.add_argument("--k1-form", default="block", choices=["block", "units", "triple", "single"],
                     help="block: one K1 launch per transformer block (all its matrices, default); "
@@ -421,6 +424,9 @@ def main():
 
     # ---- timed region: exactly K steps -----------------------------------------------------
     layer_ids = strided(n_total, args.steps)
+    if args.layers:
+        layer_ids = [int(x) for x in args.layers.split(",")]
+        args.steps = len(layer_ids)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if args.profile_host:

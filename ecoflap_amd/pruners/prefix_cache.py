@@ -147,7 +147,7 @@ class PrefixCachedLoss:
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
                  two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries",
-                 group_batch=4, assume_not_invariant=()):
+                 group_batch=4, assume_not_invariant=(), pad_slots=2):
         self.model = model
         self.use_graphs = bool(use_graphs)
         # eval_batch = k > 1 (graphs only): k evaluations of a layer (theta+/theta- of k/2 units)
@@ -168,6 +168,12 @@ class PrefixCachedLoss:
         # it only moves work from the shared pass to the per-evaluation / per-group part; the
         # tests use it to drive the group path on toy shapes, where everything is invariant)
         self.assume_not_invariant = tuple(assume_not_invariant)
+        # pad_slots = p: a stage that is not batch invariant at k concatenated evaluations may be
+        # so in its first k slots when p more slots follow them (measured: the fp32 Q-Former's
+        # library GEMMs treat the last rows of a problem differently — only the last slot differs
+        # at k = 4..24, the last two at 17, none at 18): the shared pass then runs at width k + p
+        # from that stage on, the p extra slots carry a copy of some evaluation and are never read
+        self.pad_slots = int(pad_slots) if (self.use_graphs and pad_slots and self.eval_batch > 1) else 0
         self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
         self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
         self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
@@ -394,6 +400,13 @@ class PrefixCachedLoss:
                 if self.plan[j][0].startswith(self.assume_not_invariant or ("\0",)):
                     same = False
                 self.invariant[(self._fam, k, j)] = same
+                if self.pad_slots:       # the first k slots of a state of k + p
+                    wide = self.plan[j][2](_cat_states(ins + [ins[-1]] * self.pad_slots, B))
+                    same_p = slots_equal(wide, outs, k + self.pad_slots)[0]
+                    if self.plan[j][0].startswith(self.assume_not_invariant or ("\0",)):
+                        same_p = False
+                    self.invariant[(self._fam, k + self.pad_slots, j)] = same_p
+                    del wide
                 if g:        # the same question for groups of g (first and last group of the chunk)
                     ok_g = all(slots_equal(self.plan[j][2](_cat_states(ins[a:a + g], B)),
                                            outs[a:a + g], g)[0] for a in (0, k - g))
@@ -408,20 +421,36 @@ class PrefixCachedLoss:
         self.stats["stages_not_batch_invariant"] = sorted(
             {self.plan[j][0] for (_, kk, j), ok in self.invariant.items()
              if not ok and kk == self.eval_batch})
+        if self.pad_slots:
+            self.stats["stages_shared_with_padding"] = sorted(
+                {self.plan[j][0] for (_, kk, j), ok in self.invariant.items()
+                 if ok and kk == self.eval_batch + self.pad_slots
+                 and not self.invariant.get((self._fam, self.eval_batch, j), False)})
         self.stats["stages_invariant_in_groups"] = len(
             {j for (_, kk, j), ok in self.invariant.items() if ok and kk == self.group_batch
              and not self.invariant.get((self._fam, self.eval_batch, j), False)})
 
     def _batch_from(self, entry, evals, states, B):
-        """First stage S > entry such that S..n-2 are all batch invariant (None: nothing to share)."""
+        """(S, width): first stage S > entry such that S..n-2 are all batch invariant in the
+        first k slots of a state of `width` slots (k, or k + pad_slots when that starts the
+        shared pass earlier); (None, k): nothing to share."""
         n = len(self.plan)
         fam, k = self._fam, self.eval_batch
         if any((fam, k, j) not in self.invariant for j in range(entry + 1, n - 1)):
             self._probe_invariance(entry, evals, states, B)      # every new family is probed
-        S = n - 1
-        while S - 1 > entry and self.invariant.get((fam, k, S - 1), False):
-            S -= 1
-        return S if S <= n - 2 else None
+
+        def first_shared(width):
+            S = n - 1
+            while S - 1 > entry and self.invariant.get((fam, width, S - 1), False):
+                S -= 1
+            return S if S <= n - 2 else None
+
+        S_k = first_shared(k)
+        if self.pad_slots:
+            S_p = first_shared(k + self.pad_slots)
+            if S_p is not None and (S_k is None or S_p < S_k):
+                return S_p, k + self.pad_slots
+        return S_k, k
 
     def _batched(self, model, evals, cuda_enabled):
         """losses of `evals` = [(samples, theta)] (all for the layer announced by begin_layer).
@@ -450,13 +479,15 @@ class PrefixCachedLoss:
         if len(fams) != 1 or not all(idx == entry and _on_gpu(st) for idx, st in states):
             return None
         B = self._batch_len(evals[0][0])
-        S = self._batch_from(entry, evals, states, B)
+        S, width = self._batch_from(entry, evals, states, B)
         if S is None:
             return None
-        bundle = self.bchains.get((self._fam, k))
+        if width > k:
+            self.stats["padded_shared_evals"] = self.stats.get("padded_shared_evals", 0) + len(evals)
+        bundle = self.bchains.get((self._fam, width))
         if bundle is None:
             bundle = [_StageGraphs(self, self.plan, stream=None), None, None]
-            self.bchains[(self._fam, k)] = bundle
+            self.bchains[(self._fam, width)] = bundle
         bchain = bundle[0]
         captured = S in bchain.graphs
         # 1. the per-evaluation part: owning stage (its theta in the parameter's storage), then
@@ -504,7 +535,7 @@ class PrefixCachedLoss:
         for lane in lanes:
             main.wait_stream(lane.stream)
         if not captured:
-            while len(outs) < k:
+            while len(outs) < width:
                 outs.append(outs[-1])
             cat = _cat_states(outs, B)
             bchain.ensure(S, cat, stop=n - 1)
@@ -516,16 +547,16 @@ class PrefixCachedLoss:
             losses = torch.zeros(k, dtype=torch.float32, device=self._pair_home.device)
             with torch.no_grad():
                 for i in range(k):      # eager once: library handles, workspaces
-                    losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
+                    losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, width))))
                 graph = torch.cuda.CUDAGraph()
                 with capture_graph(graph, pool=bchain.pool, capture_error_mode="thread_local"):
                     for i in range(k):
-                        losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, k))))
+                        losses[i].copy_(self.result(self.plan[n - 1][2](_slice_state(mid, i, B, width))))
             bundle[1], bundle[2] = graph, losses
             self.stats["graph_captures"] += 1
         bundle[1].replay()
         for _ in evals:
-            self.stats["stage_calls"] += (S - entry) + (n - S) / k
+            self.stats["stage_calls"] += (S - entry) + (n - S) * (width / k) / k
             self.stats["stage_calls_full"] += n
         self.stats["batched_evals"] = self.stats.get("batched_evals", 0) + len(evals)
         losses = [bundle[2][i].clone() for i in range(len(evals))]
@@ -558,6 +589,12 @@ class PrefixCachedLoss:
                     self.stats["grouping_disabled_at"] = self.plan[entry][0]
                     self.group_batch = 0
                     self._verified.discard((self._fam, entry, S))     # re-check without groups
+                    return self._sequential(model, evals, cuda_enabled)
+                if width > k:
+                    # then the padded width: stages shared only thanks to the extra slots
+                    self.stats["padding_disabled_at"] = self.plan[entry][0]
+                    self.pad_slots = 0
+                    self._verified.discard((self._fam, entry, S))
                     return self._sequential(model, evals, cuda_enabled)
                 self.stats["batched_disabled_at"] = self.plan[entry][0]
                 self.eval_batch = 1

@@ -1179,6 +1179,13 @@ def test_batched_suffix_is_exact_at_full_size(kern, k_evals, lanes):
             # the two ViT matrices' evaluations ran grouped
             assert loss.stats.get("grouped_evals", 0) >= k_evals, loss.stats
             assert "grouping_disabled_at" not in loss.stats, loss.stats
+            # the fp32 Q-Former bridge differs in its LAST slot at 8 / 16 concatenated evaluations;
+            # with two padding slots behind them the first k are exact, so the ViT matrices'
+            # shared pass starts at the bridge (whatever the probe decided, the guard stayed quiet)
+            assert "padding_disabled_at" not in loss.stats, loss.stats
+            if "bridge" in bad:
+                assert loss.stats.get("stages_shared_with_padding") == ["bridge"], loss.stats
+                assert loss.stats.get("padded_shared_evals", 0) >= k_evals, loss.stats
     assert np.array_equal(tables["sequential"], tables["batched"])
 
 
