@@ -1291,18 +1291,15 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     if (workspace_bytes < ecoflap_wanda_block_workspace_bytes(items, n_items)) return ECOFLAP_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
 
-    // workspace: sqrt tables, then the selection states (contiguous: one memset)
+    // workspace: sqrt tables, then the selection states
     float* sq[WMAX];
     MatrixSelState* st[WMAX];
     char* p = (char*)workspace;
     for (int i = 0; i < n_items; ++i) { sq[i] = (float*)p; p += sq_bytes(items[i].cols); }
-    bool any_matrix = false;
     for (int i = 0; i < n_items; ++i) {
-        st[i] = (MatrixSelState*)p;
+        st[i] = (MatrixSelState*)p;      // cleared by the sqrt kernel below (matrix-mode items)
         p += sizeof(MatrixSelState);
-        any_matrix = any_matrix || items[i].mode == ECOFLAP_WANDA_MATRIX;
     }
-    (void)any_matrix;
     {
         SqrtGroup g;
         g.n = n_items;

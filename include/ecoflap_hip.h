@@ -222,8 +222,11 @@ int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
 /* Block-level form: every Linear of one transformer block in ONE call (the reference prunes
  * them one after another inside its per-block loop, wanda_pruner.py:253-283 / :534-562; the
  * selections are independent).  Same results as n_items single calls, bit for bit; the launches
- * are shared: one sqrt launch, one selection launch per (dtype, register class) of the rows-mode
- * items, three histogram launches + one apply launch for all matrix-mode items of a dtype. */
+ * are shared: one sqrt launch (it also clears the matrix-mode selection state: the workspace
+ * need not be zeroed), ONE selection grid for the rows-mode items of a dtype when their rows are
+ * at most 8192 (fp16 / bf16) or 4096 (fp32) columns wide (rows of up to 256 16-byte vectors one
+ * wave each, longer rows one workgroup each), three histogram launches + one apply launch for
+ * all matrix-mode items of a dtype. */
 #define ECOFLAP_WANDA_MAX_ITEMS 16
 #define ECOFLAP_WANDA_ROWS   0
 #define ECOFLAP_WANDA_MATRIX 1
