@@ -88,16 +88,21 @@ def parse():
     return ap.parse_args()
 
 
-def strided(n_total, k, offset=0, run=6):
+def strided(n_total, k, offset=0, run=6, block_starts=None):
     """k layer indices as runs of `run` consecutive matrices at evenly strided positions.
     A real pass visits the 588 matrices in order, ~6.6 per block, so per-block costs
-    (prefix-cache advance, graph capture) amortise over consecutive matrices; runs of 6
-    keep that structure in a k-matrix sample."""
+    (prefix-cache advance, graph capture, the block's K1 launch) amortise over consecutive
+    matrices; runs of 6 keep that structure in a k-matrix sample.  With `block_starts` a run
+    begins at the first matrix of a transformer block, as every block of the real pass does (its
+    K1 launch then covers the block's matrices of the run instead of the tail of one block and
+    the head of the next)."""
     n_runs = max(1, (k + run - 1) // run)
     out = []
     for i in range(n_runs):
         start = int((i + 0.5) * n_total / n_runs) + offset
         start -= start % run
+        if block_starts:
+            start = max(b for b in block_starts if b <= start) + offset
         for j in range(run):
             if len(out) < k:
                 out.append(min(n_total - 1, start + j))
@@ -373,6 +378,8 @@ def main():
     group_of = lambda k: ".".join(k.split(".")[:4 if k.startswith("t5_model") else 3])  # noqa: E731
     full_mapping = {k: group_of(k) for k in prunable}
     n_total = len(prunable)
+    block_starts = [i for i, k in enumerate(prunable)
+                    if i == 0 or group_of(k) != group_of(prunable[i - 1])]
     params_by_name = dict(model.named_parameters())
     numel_total = sum(params_by_name[k].numel() for k in prunable)
     build_s = time.time() - t_build
@@ -416,14 +423,14 @@ def main():
     if args.warmup > 0:
         # the first matrix of the model (every later stage gets captured / probed once) plus
         # matrices next to the strided sample
-        run(sorted(set([0] + strided(n_total, args.warmup - 1, offset=1)))
+        run(sorted(set([0] + strided(n_total, args.warmup - 1, offset=1, block_starts=block_starts)))
             if args.warmup > 1 else [0], timed=False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
 
     # ---- timed region: exactly K steps -----------------------------------------------------
-    layer_ids = strided(n_total, args.steps)
+    layer_ids = strided(n_total, args.steps, block_starts=block_starts)
     if args.layers:
         layer_ids = [int(x) for x in args.layers.split(",")]
         args.steps = len(layer_ids)
