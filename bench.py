@@ -244,6 +244,24 @@ class TimedKernels:
         torch.cuda.synchronize()
         return statistics.median(self.hip_events.elapsed_us(a, b) for a, b in pairs)
 
+    @staticmethod
+    def box_write_gbs(nbytes=1 << 30, reps=5):
+        """What THIS box writes at, measured after the timed region: a plain single-stream fill of
+        1 GiB (torch events on the current stream).  K1's traffic is 32 parts write to 1 part read;
+        boxes of the pool differ by +-10 % in this figure and K1's in-situ rate moves with it."""
+        import statistics
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        buf.fill_(0)
+        torch.cuda.synchronize()
+        out = []
+        for i in range(reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); buf.fill_(i + 1); e.record()
+            torch.cuda.synchronize()
+            out.append(nbytes / (s.elapsed_time(e) * 1e-3) / 1e9)
+        del buf
+        return statistics.median(out)
+
     def summary(self, kind):
         if kind in ("units", "block"):
             recs = [(self.hip_events.elapsed_us(a, b) * 1e-6, nb, 1) for a, b, nb in self.unit_records]
@@ -537,6 +555,8 @@ def main():
             "per_launch": k1["per_launch"],
             # not subtracted from anything: `achieved` is the raw reading
             "event_pair_floor_us": kern.event_floor_us() if kind in ("units", "block") else None,
+            # context, not a peak: the same box's single-stream fill rate right after the run
+            "box_fill_gbs": kern.box_write_gbs(),
             "algorithmic_bytes_per_launch": k1["bytes_per_launch"],
             "bytes_rule": {
                 "units": "(2*U+2)*s*numel per launch: read W once, write theta+/theta- for each of "
