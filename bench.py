@@ -424,7 +424,7 @@ def main():
             loss_fn.reset()
             for key in ("stage_calls", "stage_calls_full", "advance_calls", "graph_captures",
                         "graph_replays", "capture_seconds", "batched_evals", "batched_checks",
-                        "host_blocked_seconds"):
+                        "host_blocked_seconds", "guard_gpu_seconds"):
                 if key in loss_fn.stats:
                     loss_fn.stats[key] = 0
         run.loss_fns.append(loss_fn)
@@ -526,6 +526,11 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * max(0.0, ls.stats.get("host_enqueue_seconds", 0.0)
                                                   - _blocked(run.loss_fns[-1])) / args.steps,
             "host_blocked_on_device_ms_per_step": 1e3 * _blocked(run.loss_fns[-1]) / args.steps,
+            # inside the timed region and inside `value`: the bitwise guard's own sequential
+            # re-evaluations, one-off per entry stage (this sample: one per ~2.5 matrices; a whole
+            # 588-matrix run: one per ~9)
+            "guard_gpu_ms_per_step": (1e3 * getattr(run.loss_fns[-1], "stats", {}).get(
+                "guard_gpu_seconds", 0.0) / args.steps),
             "cpu_model": _cpu_model_name(),
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,

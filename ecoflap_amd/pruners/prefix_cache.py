@@ -573,10 +573,17 @@ class PrefixCachedLoss:
                 sel = [i for i in (p0, p0 + 1) if i < len(evals)]
             else:
                 sel = list(range(len(evals)))
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
             want = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
+            ev1.record()
             import time
             t_chk = time.time()
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))   # one sync
+            # device time of the guard's own sequential evaluations (one-off per entry stage:
+            # ~65 of them in a 588-matrix run)
+            self.stats["guard_gpu_seconds"] = (self.stats.get("guard_gpu_seconds", 0.0)
+                                               + ev0.elapsed_time(ev1) * 1e-3)
             self.stats["host_blocked_seconds"] = (self.stats.get("host_blocked_seconds", 0.0)
                                                   + time.time() - t_chk)
             self.stats["batched_checks"] = self.stats.get("batched_checks", 0) + 1
