@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--eval-batch", type=int, default=16,
                     help="evaluations of a layer whose shared suffix runs once on their "
                          "concatenated states (exact; see pruners/prefix_cache.py)")
+    ap.add_argument("--no-batched-advance", action="store_true",
+                    help="A/B: move the prefix cache one batch at a time")
     ap.add_argument("--toy", action="store_true", help="tiny shapes (plumbing check only)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL) in production; 'gloo' + --same-device only to exercise "
@@ -414,7 +416,8 @@ def main():
     # layers), so the warm-up steps absorb them; the prefix cache itself is reset in between
     shared_loss = (loss_vision_language if args.full_forward
                    else PrefixCachedLoss(model, use_graphs=not args.no_graphs,
-                                        n_lanes=args.lanes, eval_batch=args.eval_batch))
+                                        n_lanes=args.lanes, eval_batch=args.eval_batch,
+                                        batched_advance=not args.no_batched_advance))
 
     def run(layer_ids, timed):
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}

@@ -147,7 +147,7 @@ class PrefixCachedLoss:
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
                  two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries",
-                 group_batch=4, assume_not_invariant=(), pad_slots=2):
+                 group_batch=4, assume_not_invariant=(), pad_slots=2, batched_advance=True):
         self.model = model
         self.use_graphs = bool(use_graphs)
         # eval_batch = k > 1 (graphs only): k evaluations of a layer (theta+/theta- of k/2 units)
@@ -174,6 +174,10 @@ class PrefixCachedLoss:
         # at k = 4..24, the last two at 17, none at 18): the shared pass then runs at width k + p
         # from that stage on, the p extra slots carry a copy of some evaluation and are never read
         self.pad_slots = int(pad_slots) if (self.use_graphs and pad_slots and self.eval_batch > 1) else 0
+        self.batched_advance = bool(batched_advance) and self.use_graphs and self.eval_batch > 1
+        self._fam_B = {}            # family -> batch length (learnt in `_batched`)
+        self._adv_bad = set()       # (family, stage) whose batched advance once differed
+        self._adv_pending = []      # queued bitwise checks of the batched advance
         self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
         self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
         self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
@@ -203,7 +207,105 @@ class PrefixCachedLoss:
 
     # ---- hook called by LayerSparsity before the units of a layer --------------------------
     def begin_layer(self, name):
-        self.entry = self.stage_of(name)
+        entry = self.stage_of(name)
+        if entry > self.entry and self.batched_advance:
+            self._advance_all(entry)
+        self.entry = entry
+
+    # ---- the cached prefix states of all batches, moved to a later stage together ----------
+    def _advance_all(self, target):
+        """Every cached batch state waits at the same stage; moving them to `target` one batch at
+        a time is (batches x stages) latency-bound launches at batch B.  The stages on the way
+        have already run as part of a shared pass — at width k (+ padding) or in groups of g — and
+        were measured batch invariant there, so their captured graphs advance k (or g) batches
+        per replay: slot i of the concatenated state carries exactly the bits batch i gets alone.
+        One rotating slot per stage is also advanced alone and compared bit for bit; a stage
+        without a usable graph, or one that ever differs, falls back to the per-batch path."""
+        if not (self.use_graphs and self.eval_batch > 1 and self._warmed):
+            return
+        todo = {}
+        for key, (idx, st) in self.cache.items():
+            fam = self.families.get(key)
+            B = self._fam_B.get(fam)
+            if fam is None or B is None or not (0 < idx < target) or not _on_gpu(st):
+                continue
+            todo.setdefault((fam, idx, B), []).append(key)
+        for (fam, idx, B), keys in todo.items():
+            if len(keys) < 2:
+                continue
+            chain1 = self.chains.get(fam)
+            states = [self.cache[k][1] for k in keys]
+            reached = idx
+            with torch.no_grad():
+                for j in range(idx, target):
+                    nxt = self._advance_stage(fam, j, states, B, chain1)
+                    if nxt is None:
+                        break
+                    states, reached = nxt, j + 1
+            if reached > idx:
+                for k_, st in zip(keys, states):
+                    self.cache[k_] = (reached, st)
+                self.stats["advance_calls"] += (reached - idx) * len(keys)
+
+    def _advance_stage(self, fam, j, states, B, chain1):
+        k, p, g = self.eval_batch, self.pad_slots, self.group_batch
+        if (fam, j) in self._adv_bad:
+            return None
+        plans = []        # (graphs, width, slots used)
+        b = self.bchains.get((fam, k))
+        if self.invariant.get((fam, k, j), False) and b and j in b[0].graphs:
+            plans.append((b[0], k, k))
+        b = self.bchains.get((fam, k + p)) if p else None
+        if not plans and p and self.invariant.get((fam, k + p, j), False) and b and j in b[0].graphs:
+            plans.append((b[0], k + p, k))
+        gch = self.gchains.get((fam, g)) if g else None
+        if not plans and g and self.invariant.get((fam, g, j), False) and gch and j in gch.graphs:
+            plans.append((gch, g, g))
+        if not plans:
+            return None
+        ch, width, used = plans[0]
+        graph, static_in, static_out = ch.graphs[j]
+        outs = []
+        for a in range(0, len(states), used):
+            chunk = states[a:a + used]
+            for i, st in enumerate(chunk):
+                _copy_slot(static_in, st, i, B)
+            if j in ch.bridges:      # this stage's input is normally fed by a copy: we wrote it directly
+                pass
+            graph.replay()
+            for i in range(len(chunk)):
+                outs.append(_map_tensors(_slice_state(static_out, i, B, width), lambda t: t.clone()))
+        self.stats["advance_batched_replays"] = (self.stats.get("advance_batched_replays", 0)
+                                                 + (len(states) + used - 1) // used)
+        # the check: one batch of this stage alone (captured chain if it has the stage, else eager)
+        pick = self.stats.get("advance_checks", 0) % len(states)
+        if chain1 is not None and j in chain1.graphs:
+            alone = chain1.advance(j, j + 1, states[pick])
+        else:
+            alone = self.plan[j][2](states[pick])
+        fa, fb = [], []
+        _map_tensors(alone, lambda t: fa.append(t) or t)
+        _map_tensors(outs[pick], lambda t: fb.append(t) or t)
+        self.stats["advance_checks"] = self.stats.get("advance_checks", 0) + 1
+        self._adv_pending.append((fam, j, fa, fb))
+        return outs
+
+    def _settle_advance_checks(self):
+        """Compare what `_advance_stage` queued (one host sync for all of them); called before the
+        advanced states are first used."""
+        pending, self._adv_pending = self._adv_pending, []
+        bad = False
+        for fam, j, fa, fb in pending:
+            same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
+                                              for x, y in zip(fa, fb))
+            if not same:
+                self._adv_bad.add((fam, j))
+                self.stats["advance_mismatch_at"] = self.plan[j][0]
+                bad = True
+        if bad:
+            # exactness first: throw the advanced states away, the per-batch path rebuilds them
+            self.cache.clear()
+            self.batched_advance = False
 
     def stage_of(self, name):
         for i, (_, prefixes, _) in enumerate(self.plan):
@@ -219,6 +321,8 @@ class PrefixCachedLoss:
 
     # ---- the loss closure ----------------------------------------------------------------------
     def _ensure_cached(self, key, samples):
+        if self._adv_pending:
+            self._settle_advance_checks()
         idx, state = self.cache.get(key, (0, samples))
         if idx > self.entry:        # asked for an earlier stage than cached: start over
             idx, state = 0, samples
@@ -479,6 +583,7 @@ class PrefixCachedLoss:
         if len(fams) != 1 or not all(idx == entry and _on_gpu(st) for idx, st in states):
             return None
         B = self._batch_len(evals[0][0])
+        self._fam_B[self._fam] = B
         S, width = self._batch_from(entry, evals, states, B)
         if S is None:
             return None

@@ -1183,6 +1183,11 @@ def test_batched_suffix_is_exact_at_full_size(kern, k_evals, lanes):
             # with two padding slots behind them the first k are exact, so the ViT matrices'
             # shared pass starts at the bridge (whatever the probe decided, the guard stayed quiet)
             assert "padding_disabled_at" not in loss.stats, loss.stats
+            # between the ViT-g matrices and the FlanT5 ones the cached prefix states of all
+            # batches moved through ~60 stages together (captured shared / group graphs), one
+            # rotating batch per stage re-done alone and compared bit for bit
+            assert loss.stats.get("advance_batched_replays", 0) > 0, loss.stats
+            assert loss.stats.get("advance_checks", 0) > 0 and "advance_mismatch_at" not in loss.stats
             if "bridge" in bad:
                 assert loss.stats.get("stages_shared_with_padding") == ["bridge"], loss.stats
                 assert loss.stats.get("padded_shared_evals", 0) >= k_evals, loss.stats
