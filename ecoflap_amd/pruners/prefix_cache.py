@@ -174,6 +174,9 @@ class PrefixCachedLoss:
         # at k = 4..24, the last two at 17, none at 18): the shared pass then runs at width k + p
         # from that stage on, the p extra slots carry a copy of some evaluation and are never read
         self.pad_slots = int(pad_slots) if (self.use_graphs and pad_slots and self.eval_batch > 1) else 0
+        import os
+        if os.environ.get("ECOFLAP_BATCHED_ADVANCE") == "0":       # A/B and end-to-end checks
+            batched_advance = False
         self.batched_advance = bool(batched_advance) and self.use_graphs and self.eval_batch > 1
         self._fam_B = {}            # family -> batch length (learnt in `_batched`)
         self._adv_bad = set()       # (family, stage) whose batched advance once differed

@@ -53,10 +53,17 @@ def main():
     zeros = sum(int((v == 0).sum()) for v in blocks.values())
     total = sum(v.numel() for v in blocks.values())
     vals = sorted(set(round(v, 6) for v in table.values())) if isinstance(table, dict) else []
+    import hashlib
+    table_sha = (hashlib.sha256(repr(sorted(table.items())).encode()).hexdigest()
+                 if isinstance(table, dict) else None)
+    weights_sha = hashlib.sha256()
+    for k in sorted(blocks):
+        weights_sha.update(blocks[k].detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
     print(json.dumps({
         "config": which, "wall_seconds": wall, "prunable_matrices": len(blocks),
         "prunable_elements": total, "pruned_fraction": zeros / total,
         "table_entries": len(table) if isinstance(table, dict) else 0,
+        "table_sha256": table_sha, "pruned_weights_sha256": weights_sha.hexdigest(),
         "distinct_sparsities": len(vals), "min_sparsity": vals[0] if vals else None,
         "max_sparsity": vals[-1] if vals else None,
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
