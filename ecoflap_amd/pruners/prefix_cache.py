@@ -298,6 +298,8 @@ class PrefixCachedLoss:
         advanced states are first used."""
         pending, self._adv_pending = self._adv_pending, []
         bad = False
+        import time
+        t0 = time.time()
         for fam, j, fa, fb in pending:
             same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
                                               for x, y in zip(fa, fb))
@@ -305,6 +307,9 @@ class PrefixCachedLoss:
                 self._adv_bad.add((fam, j))
                 self.stats["advance_mismatch_at"] = self.plan[j][0]
                 bad = True
+        # (the first comparison waits for everything queued before it: host time blocked on the device)
+        self.stats["host_blocked_seconds"] = (self.stats.get("host_blocked_seconds", 0.0)
+                                              + time.time() - t0)
         if bad:
             # exactness first: throw the advanced states away, the per-batch path rebuilds them
             self.cache.clear()
