@@ -109,6 +109,23 @@ def _slice_state(state, i, B, k):
     return state
 
 
+def _first_slots(state, k, B, width):
+    """The first k of `width` slots of a concatenated state (views)."""
+    if torch.is_tensor(state):
+        if state.dim() > 0 and state.shape[0] == width * B:
+            return state[:k * B]
+        return state
+    if isinstance(state, dict):
+        return {a: _first_slots(b, k, B, width) for a, b in state.items()}
+    if isinstance(state, (list, tuple)):
+        return type(state)(_first_slots(b, k, B, width) for b in state)
+    return state
+
+
+def _copy_first_slots(dst, src, k, B, width):
+    _copy_tensors(dst, _first_slots(src, k, B, width))
+
+
 def _family(samples):
     """Shape signature of a calibration batch: batches of one family replay the same graphs
     (BLIP-VQA batches differ in their number of answers: one chain of graphs per family)."""
@@ -173,6 +190,9 @@ class PrefixCachedLoss:
         # library GEMMs treat the last rows of a problem differently — only the last slot differs
         # at k = 4..24, the last two at 17, none at 18): the shared pass then runs at width k + p
         # from that stage on, the p extra slots carry a copy of some evaluation and are never read
+        import os
+        if os.environ.get("ECOFLAP_PAD_SLOTS") is not None:         # A/B and end-to-end checks
+            pad_slots = int(os.environ["ECOFLAP_PAD_SLOTS"])
         self.pad_slots = int(pad_slots) if (self.use_graphs and pad_slots and self.eval_batch > 1) else 0
         import os
         if os.environ.get("ECOFLAP_BATCHED_ADVANCE") == "0":       # A/B and end-to-end checks
@@ -181,6 +201,8 @@ class PrefixCachedLoss:
         self._fam_B = {}            # family -> batch length (learnt in `_batched`)
         self._adv_bad = set()       # (family, stage) whose batched advance once differed
         self._adv_pending = []      # queued bitwise checks of the batched advance
+        self._rechecking = False    # inside the guard's second look at a mismatch
+        self._inject_mismatch_once = False
         self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
         self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
         self.bchains = {}           # k -> (_StageGraphs at batch k*B, tail graph, losses)
@@ -543,9 +565,10 @@ class PrefixCachedLoss:
              and not self.invariant.get((self._fam, self.eval_batch, j), False)})
 
     def _batch_from(self, entry, evals, states, B):
-        """(S, width): first stage S > entry such that S..n-2 are all batch invariant in the
-        first k slots of a state of `width` slots (k, or k + pad_slots when that starts the
-        shared pass earlier); (None, k): nothing to share."""
+        """(S, width, S_narrow): the shared pass starts at stage S > entry at `width` slots and
+        continues from S_narrow at k slots: S_narrow..n-2 are batch invariant at k; S..S_narrow-1
+        (possibly none: width == k, S == S_narrow) are so in the first k slots of k + pad_slots.
+        (None, k, None): nothing to share."""
         n = len(self.plan)
         fam, k = self._fam, self.eval_batch
         if any((fam, k, j) not in self.invariant for j in range(entry + 1, n - 1)):
@@ -558,11 +581,15 @@ class PrefixCachedLoss:
             return S if S <= n - 2 else None
 
         S_k = first_shared(k)
-        if self.pad_slots:
-            S_p = first_shared(k + self.pad_slots)
-            if S_p is not None and (S_k is None or S_p < S_k):
-                return S_p, k + self.pad_slots
-        return S_k, k
+        if self.pad_slots and S_k is not None:
+            # stages in front of the width-k part that are exact in the first k slots of k + p:
+            # the pass starts there at width k + p and narrows to k slots at S_k
+            S_p = S_k
+            while S_p - 1 > entry and self.invariant.get((fam, k + self.pad_slots, S_p - 1), False):
+                S_p -= 1
+            if S_p < S_k:
+                return S_p, k + self.pad_slots, S_k
+        return S_k, k, S_k
 
     def _batched(self, model, evals, cuda_enabled):
         """losses of `evals` = [(samples, theta)] (all for the layer announced by begin_layer).
@@ -592,7 +619,7 @@ class PrefixCachedLoss:
             return None
         B = self._batch_len(evals[0][0])
         self._fam_B[self._fam] = B
-        S, width = self._batch_from(entry, evals, states, B)
+        S, width, S_n = self._batch_from(entry, evals, states, B)
         if S is None:
             return None
         if width > k:
@@ -651,10 +678,24 @@ class PrefixCachedLoss:
             while len(outs) < width:
                 outs.append(outs[-1])
             cat = _cat_states(outs, B)
-            bchain.ensure(S, cat, stop=n - 1)
+            bchain.ensure(S, cat, stop=S_n if width > k else n - 1)
             _copy_tensors(bchain.graphs[S][1], cat)
-        # 2. shared suffix, once, on batch k*B
-        mid = bchain.replay(S, None, stop=n - 1)
+        # 2. shared suffix, once: the padded stages at k + p slots, everything after them at k
+        padded = width > k
+        if padded:
+            wide_out = bchain.replay(S, None, stop=S_n)
+            bundle = self.bchains.get((self._fam, k))
+            if bundle is None:
+                bundle = [_StageGraphs(self, self.plan, stream=None), None, None]
+                self.bchains[(self._fam, k)] = bundle
+            narrow = bundle[0]
+            if S_n not in narrow.graphs:
+                narrow.ensure(S_n, _first_slots(wide_out, k, B, width), stop=n - 1)
+            _copy_first_slots(narrow.graphs[S_n][1], wide_out, k, B, width)
+            mid = narrow.replay(S_n, None, stop=n - 1)
+            bchain, width = narrow, k
+        else:
+            mid = bchain.replay(S, None, stop=n - 1)
         # 3. loss head per slot (one graph for all slots)
         if bundle[1] is None:
             losses = torch.zeros(k, dtype=torch.float32, device=self._pair_home.device)
@@ -669,12 +710,13 @@ class PrefixCachedLoss:
             self.stats["graph_captures"] += 1
         bundle[1].replay()
         for _ in evals:
-            self.stats["stage_calls"] += (S - entry) + (n - S) * (width / k) / k
+            self.stats["stage_calls"] += (S - entry) + (n - S) / k
             self.stats["stage_calls_full"] += n
         self.stats["batched_evals"] = self.stats.get("batched_evals", 0) + len(evals)
         losses = [bundle[2][i].clone() for i in range(len(evals))]
         import os
-        check = (self.verify_batched == "all" or bool(os.environ.get("ECOFLAP_VERIFY_BATCHED"))
+        check = not self._rechecking and (
+                 self.verify_batched == "all" or bool(os.environ.get("ECOFLAP_VERIFY_BATCHED"))
                  or ((self._fam, entry, S) not in self._verified
                      and (self.verify_batched == "entries" or len(self._verified) < 4)))
         if check:
@@ -690,6 +732,9 @@ class PrefixCachedLoss:
             ev0.record()
             want = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
             ev1.record()
+            if self._inject_mismatch_once:       # tests: one loss of this check is off, once
+                self._inject_mismatch_once = False
+                losses[sel[0]] = losses[sel[0]] + 1.0
             import time
             t_chk = time.time()
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))   # one sync
@@ -702,15 +747,42 @@ class PrefixCachedLoss:
             self.stats["batched_checks"] = self.stats.get("batched_checks", 0) + 1
             if not same:
                 if os.environ.get("ECOFLAP_DEBUG_BATCHED"):
-                    print("batched mismatch at", self.plan[entry][0], "S", S,
+                    print("batched mismatch at", self.plan[entry][0], self._pair_name, "S", S,
                           [float(losses[i]) for i in sel], [float(x) for x in want], flush=True)
+                # Does it repeat?  Every-chunk verification of the whole BLIP-2 config (21 runs,
+                # ~24 000 checked chunks) shows, in about one run in four, ONE slot of ONE chunk
+                # off by ~7e-3 in the loss: ViT-g matrices only, either lane, any position of a
+                # group, theta loaded by memcpy or by a kernel alike, every other chunk of the run
+                # clean and the final table identical.  The library GEMMs are bit-reproducible call
+                # to call (tools/diag/gemm_determinism.py); what is left as a suspect sits below
+                # this file (graph replays of the fp16 ViT-g block on two streams).  A one-off is
+                # not a property of the batched path: only a mismatch that REPEATS switches a
+                # feature off; the chunk's losses are the sequential ones either way.
+                want2 = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
+                seq_stable = all(torch.equal(a, b_) for a, b_ in zip(want, want2))
+                again = None
+                if seq_stable:
+                    self._rechecking = True
+                    try:
+                        again = self._batched(model, evals, cuda_enabled)
+                    finally:
+                        self._rechecking = False
+                repeats = again is not None and not all(torch.equal(again[i], w)
+                                                        for i, w in zip(sel, want))
+                if not repeats:
+                    self.stats.setdefault("transient_mismatches", []).append(
+                        {"entry": self.plan[entry][0], "layer": self._pair_name,
+                         "side": "sequential" if not seq_stable else "batched"})
+                    if len(sel) == len(evals):
+                        return want2
+                    return self._sequential(model, evals, cuda_enabled)
                 if used_groups:
                     # the group path first: the shared pass has its own record of clean checks
                     self.stats["grouping_disabled_at"] = self.plan[entry][0]
                     self.group_batch = 0
                     self._verified.discard((self._fam, entry, S))     # re-check without groups
                     return self._sequential(model, evals, cuda_enabled)
-                if width > k:
+                if padded:
                     # then the padded width: stages shared only thanks to the extra slots
                     self.stats["padding_disabled_at"] = self.plan[entry][0]
                     self.pad_slots = 0

@@ -805,6 +805,42 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
             assert torch.equal(res[0][2][k], other[2][k]), k
 
 
+def test_guard_tells_a_transient_mismatch_from_a_repeating_one(kern):
+    """One loss of one check differs ONCE (injected): the guard re-does both sides, finds them
+    equal the second time, records a transient event and keeps batching, groups and padding on;
+    the table is the sequential one bit for bit."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+    tables = {}
+    for mode in ("sequential", "batched"):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        loss = PrefixCachedLoss(model, use_graphs=True, eval_batch=8 if mode == "batched" else 1,
+                                n_lanes=2 if mode == "batched" else 1, verify_batched="all")
+        if mode == "batched":
+            loss._inject_mismatch_once = True
+        np.random.seed(3)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=kern, z_source="philox")
+        ls.return_sparsity()
+        tables[mode] = ls.loss_table.copy()
+        if mode == "batched":
+            ev = loss.stats.get("transient_mismatches", [])
+            assert len(ev) == 1 and ev[0]["side"] == "batched", loss.stats
+            # batching went on after the injected event (a later, REPEATING mismatch may still
+            # switch it off on these toy tensors, where the probe can be lucky)
+            assert loss.stats.get("batched_evals", 0) > 16, loss.stats
+            assert loss.stats.get("batched_disabled_at") != ev[0]["entry"], loss.stats
+    assert np.array_equal(tables["sequential"], tables["batched"])
+
+
 @pytest.mark.parametrize("mode", ["compat", "intended"])
 def test_upop_vqa_hip_equals_oracle(kern, golden_dir, mode):
     """BASELINE configs[4] shape (toy size): ViT matrix-mode + BERT rows-mode Wanda and, in
