@@ -772,7 +772,11 @@ class PrefixCachedLoss:
                 if not repeats:
                     self.stats.setdefault("transient_mismatches", []).append(
                         {"entry": self.plan[entry][0], "layer": self._pair_name,
-                         "side": "sequential" if not seq_stable else "batched"})
+                         "side": "sequential" if not seq_stable else "batched",
+                         "slots": [[i, float(losses[i]), float(w), float(w2)]
+                                   for i, w, w2 in zip(sel, want, want2)
+                                   if not (torch.equal(losses[i], w) and torch.equal(w, w2))],
+                         "grouped": bool(used_groups), "lanes": len(lanes) + 1})
                     if len(sel) == len(evals):
                         return want2
                     return self._sequential(model, evals, cuda_enabled)
