@@ -202,6 +202,10 @@ class PrefixCachedLoss:
         self._adv_bad = set()       # (family, stage) whose batched advance once differed
         self._adv_pending = []      # queued bitwise checks of the batched advance
         self._rechecking = False    # inside the guard's second look at a mismatch
+        # diagnostics (tools/diag/transient_hunt.py): a dict here receives clones of every stage
+        # output of the batched path (per group / per evaluation / shared pass), keyed by where
+        # they came from; None in production
+        self.trace = None
         self._inject_mismatch_once = False
         self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
         self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
@@ -662,12 +666,16 @@ class PrefixCachedLoss:
             if lane is not None:
                 out = lane.run_prefix(entry, S, st, self._pair_name, theta)
                 with torch.cuda.stream(lane.stream):
+                    if self.trace is not None:
+                        self.trace[("pre", i)] = _map_tensors(out, lambda t: t.clone())
                     _copy_slot(bchain.graphs[S][1], out, i, B)
                 continue
             self._pair_home.copy_(theta)
             out = self.chain.run_stage(entry, st)
             if S > entry + 1:
                 out = self.chain.replay(entry + 1, out, stop=S)
+            if self.trace is not None:
+                self.trace[("pre", i)] = _map_tensors(out, lambda t: t.clone())
             if captured:
                 _copy_slot(bchain.graphs[S][1], out, i, B)
             else:
@@ -684,6 +692,10 @@ class PrefixCachedLoss:
         padded = width > k
         if padded:
             wide_out = bchain.replay(S, None, stop=S_n)
+            if self.trace is not None:
+                self.trace[("wide", width)] = {
+                    j: _map_tensors(bchain.graphs[j][2], lambda t: t.clone())
+                    for j in range(S, S_n)}
             bundle = self.bchains.get((self._fam, k))
             if bundle is None:
                 bundle = [_StageGraphs(self, self.plan, stream=None), None, None]
@@ -709,6 +721,11 @@ class PrefixCachedLoss:
             bundle[1], bundle[2] = graph, losses
             self.stats["graph_captures"] += 1
         bundle[1].replay()
+        if self.trace is not None:
+            self.trace[("shared", width)] = {
+                j: _map_tensors(bchain.graphs[j][2], lambda t: t.clone())
+                for j in range(S_n if padded else S, n - 1) if j in bchain.graphs}
+            self.trace["losses"] = bundle[2].clone()
         for _ in evals:
             self.stats["stage_calls"] += (S - entry) + (n - S) / k
             self.stats["stage_calls_full"] += n
@@ -835,14 +852,26 @@ class PrefixCachedLoss:
                     for j in range(entry + 1, R):
                         x = plan[j][2](x)
                 gch.ensure(entry + 1, cat, stop=R)
-            for pos, (_, theta, st) in enumerate(items):
+            tr = self.trace
+            for pos, (slot, theta, st) in enumerate(items):
                 home.copy_(theta)
-                _copy_slot(gch.graphs[entry + 1][1], chain.run_stage(entry, st), pos, B)
+                own = chain.run_stage(entry, st)
+                if tr is not None:
+                    tr[("own", slot)] = _map_tensors(own, lambda t: t.clone())
+                _copy_slot(gch.graphs[entry + 1][1], own, pos, B)
             mid = gch.replay(entry + 1, None, stop=R)
+            if tr is not None:
+                tr[("group", items[0][0])] = {
+                    j: _map_tensors(gch.graphs[j][2], lambda t: t.clone())
+                    for j in range(entry + 1, R)}
+                tr.setdefault("_meta", {})[("group", items[0][0])] = (
+                    gch, stream, entry, R, [slot for slot, _, _ in items])
             for pos, (slot, _, _) in enumerate(items):
                 x = _slice_state(mid, pos, B, g)
                 if S > R:
                     x = chain.replay(R, x, stop=S)
+                if tr is not None:
+                    tr[("pre", slot)] = _map_tensors(x, lambda t: t.clone())
                 _copy_slot(slot_in, x, slot, B)
 
         if ready:

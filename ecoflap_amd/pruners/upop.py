@@ -136,6 +136,10 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
             return _UniformSparsity(original_sparsity)          # as shipped
         device = next(iter(self.model.parameters())).device
         loss_func = lambda m, batch, cuda_enabled: task_forward(self.task, m, batch, device)  # noqa: E731
+        # stage 1's calibration prefix is a LOCAL: stage 2 (`prune` -> _vit_prune / _bert_prune)
+        # keeps reading `self.data_loader` for its own `num_samples` samples, as the reference
+        # does (the shipped entrypoints use num_data_first_stage=32, num_samples=128)
+        stage1_batches = self.data_loader
         if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO")):
             # same losses, bit for bit, re-entering at the block that owns the scored matrix
@@ -149,16 +153,18 @@ class BLIPBertLayerWandaPruner(_BertWandaMixin, LayerWiseBasePruner):
                                   original_sparsity, self.max_sparsity_per_layer, self.score_method,
                                   self.num_noise, self.noise_eps, {}, kernels=self.kernels,
                                   batch_len_fn=lambda b: b[0].shape[0])
-            self.data_loader = probe.calibration_prefix()     # fixed list: same batches downstream
-            families = len({_shape_signature(b) for b in self.data_loader})
+            stage1_batches = probe.calibration_prefix()       # fixed list: same batches per layer
+            families = len({_shape_signature(b) for b in stage1_batches})
             graphs = (families <= 8 and device.type == "cuda"
                       and bool(getattr(self, "use_graphs", True))
                       and bool(getattr(self.model, "stages_capturable", True)))
             loss_func = PrefixCachedLoss(self.model, kind="vision_language",
                                          batch_len_fn=lambda b: b[0].shape[0], use_graphs=graphs,
                                          n_lanes=int(getattr(self, "n_lanes", 2)) if graphs else 1)
+        self.stage_stats["stage1_batches"] = (len(stage1_batches)
+                                              if isinstance(stage1_batches, (list, tuple)) else None)
         ls = LayerSparsity(
-            self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
+            self.model, stage1_batches, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,
             self._mapping(sparsity_ratio_granularity), kernels=self.kernels,
             z_source=self.z_source, process_group=self.process_group,

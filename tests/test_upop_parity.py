@@ -69,6 +69,42 @@ def test_intended_mode_allocates_non_uniform_table(golden_dir):
     assert 0.45 < frac < 0.56
 
 
+class _CountingLoader:
+    """re-iterable loader that records how many batches each pass over it consumed"""
+
+    def __init__(self, batches):
+        self.batches, self.passes = batches, []
+
+    def __iter__(self):
+        self.passes.append(0)
+        slot = len(self.passes) - 1
+        for b in self.batches:
+            self.passes[slot] += 1
+            yield b
+
+
+def test_stage2_reads_its_own_samples_not_the_stage1_prefix(golden_dir):
+    """The shipped UPop entrypoints score on fewer samples (num_data_first_stage=32) than they
+    calibrate Wanda on (num_samples=128): stage 1's bounded prefix must not replace the loader
+    stage 2 iterates (UPop/pruners/wanda_pruner.py:769-812 pass `self.data_loader` to both)."""
+    _, model, batches = _model(golden_dir)
+    loader = _CountingLoader(batches)                 # 4 batches of 2
+    np.random.seed(42)
+    pruner = BLIPBertLayerWandaPruner(
+        model, loader, bert_prune_spec="0-0.5-1.0-1.0", vit_prune_spec="0-0.5-1.0-1.0",
+        num_samples=4, bert_model_prefix="text_decoder", vit_model_prefix="visual_encoder",
+        sparsity_ratio_granularity="block", max_sparsity_per_layer=0.6,
+        score_method="MEZO-GradOnly_sum", num_data_first_stage=2, task="vqa",
+        stage1_mode="intended", kernels=OracleKernels(), z_source=torch_cpu_normal)
+    pruner.prune()
+    assert pruner.data_loader is loader
+    assert pruner.stage_stats["stage1_batches"] == 1          # 2 samples = one batch of 2
+    # stage 1 took one batch (and looked at the next); each of the three stage-2 captures (ViT,
+    # question encoder, answer decoder) then walked the loader ITSELF for its own 4 samples =
+    # two batches (+ the one it fetched before seeing the count reached)
+    assert loader.passes == [2, 3, 3, 3], loader.passes
+
+
 def test_masked_finetune_step(golden_dir):
     """grad *= mask (UPop/ecoflap_compression_vqa.py:124-129) keeps pruned weights at zero."""
     _, model, batches = _model(golden_dir)

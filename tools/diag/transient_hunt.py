@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Hunt for the one-off loss mismatch of the batched evaluation path (VERDICT r2 "weak" #1).
+
+Every chunk of evaluations of every selected matrix runs TWICE through the production batched
+path (groups of 4 on two lanes, padded bridge, shared FlanT5 pass), with `PrefixCachedLoss.trace`
+collecting a clone of every stage output of both runs; the two traces are compared on the device
+stage by stage.  The path is deterministic, so any difference is the transient event; the first
+differing stage, the lane it ran on and the pattern of the differing elements are printed, and
+that stage's graph is replayed again from the recorded input to see which of the two outputs is
+the reproducible one.  One process runs many passes over the ViT matrices (where every recorded
+event happened), which exposes ~2 runs' worth of group replays per pass at a third of the cost
+of `ECOFLAP_VERIFY_BATCHED=1 tools/run_config.py 3`.
+
+    python3 tools/diag/transient_hunt.py --passes 10 --lanes 2 --group 4 [--layers 0-155]
+"""
+import argparse
+import json
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def box_id():
+    out = {"host": socket.gethostname()}
+    try:
+        import glob
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(f):
+                if line.startswith("unique_id") and line.split()[1] != "0":
+                    out.setdefault("gpu_unique_id", []).append(line.split()[1])
+    except Exception as e:       # noqa: BLE001
+        out["err"] = repr(e)
+    return out
+
+
+def flat(obj, out):
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for k in sorted(obj, key=str):
+            flat(obj[k], out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            flat(v, out)
+    return out
+
+
+class DoubleRun:
+    """loss closure wrapper: every `multi` call runs twice, traces compared."""
+
+    def __init__(self, inner, log):
+        self.inner = inner
+        self.log = log
+        self.events = []
+        self.chunks = 0
+        self.compared_tensors = 0
+        self.layer = None
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def begin_layer(self, name):
+        self.layer = name
+        return self.inner.begin_layer(name)
+
+    def __call__(self, *a, **kw):
+        return self.inner(*a, **kw)
+
+    def multi(self, model, items, cuda_enabled):
+        inner = self.inner
+        inner.trace = A = {}
+        r1 = inner.multi(model, items, cuda_enabled)
+        inner.join()
+        r1 = [(a.clone(), b.clone(), n) for a, b, n in r1]
+        inner.trace = B = {}
+        r2 = inner.multi(model, items, cuda_enabled)
+        inner.join()
+        inner.trace = None
+        self.chunks += 1
+        metaA = A.pop("_meta", {})
+        B.pop("_meta", None)
+        keys = [k for k in A if k in B]
+        pairs, where = [], []
+        for k in keys:
+            if isinstance(A[k], dict) and all(isinstance(j, int) for j in A[k]):
+                for j in sorted(A[k]):
+                    fa, fb = flat(A[k][j], []), flat(B[k][j], [])
+                    for t, (x, y) in enumerate(zip(fa, fb)):
+                        pairs.append((x, y))
+                        where.append((k, j, t))
+            else:
+                fa, fb = flat(A[k], []), flat(B[k], [])
+                for t, (x, y) in enumerate(zip(fa, fb)):
+                    pairs.append((x, y))
+                    where.append((k, None, t))
+        for i, ((a1, b1, _), (a2, b2, _)) in enumerate(zip(r1, r2)):
+            pairs += [(a1, a2), (b1, b2)]
+            where += [(("loss", 2 * i), None, 0), (("loss", 2 * i + 1), None, 0)]
+        if pairs:
+            ne = torch.stack([(x != y).any() if x.shape == y.shape else torch.ones((), dtype=torch.bool, device=x.device)
+                              for x, y in pairs]).cpu().numpy()
+        else:
+            ne = np.zeros(0, bool)
+        self.compared_tensors += len(pairs)
+        if ne.any():
+            self.report(A, B, metaA, pairs, where, ne, r1, r2)
+        return r1
+
+    def report(self, A, B, meta, pairs, where, ne, r1, r2):
+        inner = self.inner
+        plan = inner.plan
+        bad = [(w, p) for w, p, f in zip(where, pairs, ne) if f]
+        ev = {"layer": self.layer, "chunk": self.chunks, "n_bad_tensors": len(bad),
+              "bad": [], "time": time.time()}
+        for (k, j, t), (x, y) in bad[:40]:
+            d = (x != y)
+            idx = d.nonzero()
+            info = {"key": repr(k), "stage": None if j is None else plan[j][0], "tensor": t,
+                    "shape": list(x.shape), "n_diff": int(d.sum())}
+            if idx.numel():
+                info["min_idx"] = idx.min(0).values.tolist()
+                info["max_idx"] = idx.max(0).values.tolist()
+                if x.dim() >= 2:
+                    info["distinct_dim0"] = int(idx[:, 0].unique().numel())
+                    info["distinct_dim1"] = int(idx[:, 1].unique().numel())
+                    if x.dim() >= 3:
+                        info["distinct_dim2"] = int(idx[:, 2].unique().numel())
+                xf, yf = x[d].float(), y[d].float()
+                info["max_abs_diff"] = float((xf - yf).abs().max())
+                info["first_vals"] = [xf[:4].tolist(), yf[:4].tolist()]
+            ev["bad"].append(info)
+        ev["losses_run1"] = [float(v) for a, b, _ in r1 for v in (a, b)]
+        ev["losses_run2"] = [float(v) for a, b, _ in r2 for v in (a, b)]
+        # the first differing group stage: replay it again from the recorded input
+        firsts = [(k, j) for (k, j, t), _ in bad if isinstance(k, tuple) and k[0] == "group"]
+        if firsts:
+            k, j = min(firsts, key=lambda kj: kj[1])
+            gch, stream, entry, R, slots = meta[k]
+            ev["first_group_stage"] = {"key": repr(k), "stage": plan[j][0], "lane":
+                                       "main" if stream is None else "replica", "slots": slots}
+            try:
+                graph, static_in, static_out = gch.graphs[j]
+                # input of stage j in run 1: previous group stage's output, or the owning-stage outputs
+                if j - 1 in A[k]:
+                    src_a, src_b = A[k][j - 1], B[k][j - 1]
+                    ev["first_group_stage"]["inputs_equal"] = bool(all(
+                        torch.equal(x, y) for x, y in zip(flat(src_a, []), flat(src_b, []))))
+                    from ecoflap_amd.pruners.prefix_cache import _copy_tensors
+                    ctx = torch.cuda.stream(stream) if stream is not None else _null()
+                    oa, ob = flat(A[k][j], []), flat(B[k][j], [])
+                    n_a = n_b = n_other = 0
+                    with ctx:
+                        for _ in range(40):
+                            _copy_tensors(static_in, src_a)
+                            graph.replay()
+                            oo = flat(static_out, [])
+                            ea = all(torch.equal(x, y) for x, y in zip(oo, oa))
+                            eb = all(torch.equal(x, y) for x, y in zip(oo, ob))
+                            n_a += ea
+                            n_b += eb
+                            n_other += (not ea and not eb)
+                    ev["first_group_stage"]["replays_equal_run1_run2_neither"] = [n_a, n_b, n_other]
+            except Exception as e:       # noqa: BLE001
+                ev["first_group_stage"]["probe_error"] = repr(e)
+        self.events.append(ev)
+        print("EVENT " + json.dumps(ev), flush=True)
+        self.log.write(json.dumps(ev) + "\n")
+        self.log.flush()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def parse_layers(spec, n):
+    out = []
+    for part in spec.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return [i for i in out if i < n]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--passes", type=int, default=4)
+    ap.add_argument("--layers", default="0-155", help="matrix indices (ViT-g = 0-155)")
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--group", type=int, default=4)
+    ap.add_argument("--eval-batch", type=int, default=16)
+    ap.add_argument("--pad-slots", type=int, default=2)
+    ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = all passes)")
+    ap.add_argument("--out", default="gpurun_out/transient_hunt.jsonl")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+
+    from ecoflap_amd import hip
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_flant5xl
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = blip2_flant5xl().eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    batches = S.image_text_batches(128, 8, img_size=224, vocab=32128, in_len=16, out_len=16,
+                                   seed=42, device=dev)
+    prunable = [k for k, v in model.named_parameters()
+                if v.dim() == 2 and ".block" in k and "relative_attention_bias.weight" not in k
+                and (k.startswith("t5_model") or k.startswith("visual_encoder"))]
+    group_of = lambda k: ".".join(k.split(".")[:4 if k.startswith("t5_model") else 3])  # noqa: E731
+    layer_ids = parse_layers(args.layers, len(prunable))
+    mapping = {prunable[i]: group_of(prunable[i]) for i in layer_ids}
+
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    log = open(args.out, "a")
+    head = {"tag": args.tag, "args": vars(args), "box": box_id(), "env": {
+        k: v for k, v in os.environ.items() if k.startswith(("ECOFLAP", "TORCH_BLAS", "TENSILE", "HIPBLASLT", "ROCBLAS"))}}
+    print("HEAD " + json.dumps(head), flush=True)
+    log.write(json.dumps(head) + "\n")
+    log.flush()
+
+    inner = PrefixCachedLoss(model, use_graphs=True, n_lanes=args.lanes, eval_batch=args.eval_batch,
+                             group_batch=args.group, pad_slots=args.pad_slots)
+    loss = DoubleRun(inner, log)
+    kern = hip.HipKernels()
+    t0 = time.time()
+    done = 0
+    for p_ in range(args.passes):
+        np.random.seed(42 + p_)
+        inner.reset()
+        ls = LayerSparsity(model, batches, loss, 128, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3,
+                           mapping, kernels=kern, z_source="philox", k1_form="block")
+        ls.return_sparsity()
+        torch.cuda.synchronize()
+        done += 1
+        st = inner.stats
+        line = {"pass": p_, "elapsed_s": round(time.time() - t0, 1), "chunks": loss.chunks,
+                "compared_tensors": loss.compared_tensors, "events": len(loss.events),
+                "grouped_evals": st.get("grouped_evals"), "batched_evals": st.get("batched_evals"),
+                "transient_by_guard": len(st.get("transient_mismatches", [])),
+                "grouping_disabled_at": st.get("grouping_disabled_at"),
+                "padding_disabled_at": st.get("padding_disabled_at"),
+                "batched_disabled_at": st.get("batched_disabled_at"),
+                "advance_mismatch_at": st.get("advance_mismatch_at")}
+        print("PASS " + json.dumps(line), flush=True)
+        log.write(json.dumps(line) + "\n")
+        log.flush()
+        if args.minutes and (time.time() - t0) / 60 > args.minutes:
+            break
+    summary = {"tag": args.tag, "passes": done, "events": len(loss.events), "chunks": loss.chunks,
+               "compared_tensors": loss.compared_tensors, "seconds": round(time.time() - t0, 1),
+               "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}
+    print("SUMMARY " + json.dumps(summary), flush=True)
+    log.write(json.dumps(summary) + "\n")
+    log.close()
+
+
+if __name__ == "__main__":
+    main()
