@@ -47,6 +47,9 @@ def run(task, argv=None):
     ap.add_argument("--toy", action="store_true")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--save", default="")
+    ap.add_argument("--z_source", default="philox", choices=["philox", "torch"],
+                    help="torch: draw z as the reference does (torch.manual_seed + torch.normal "
+                         "on the parameter's device); philox: in-register stream (default)")
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     torch.manual_seed(42)
@@ -62,7 +65,7 @@ def run(task, argv=None):
         num_samples=args.num_data, bert_model_prefix=prefix, vit_model_prefix="visual_encoder",
         sparsity_ratio_granularity=args.sparsity_ratio_granularity,
         max_sparsity_per_layer=args.p + 0.1, score_method="MEZO-GradOnly_sum",
-        num_data_first_stage=32, task=task, stage1_mode=args.stage1)
+        num_data_first_stage=32, task=task, stage1_mode=args.stage1, z_source=args.z_source)
     model, table = pruner.prune()
     if dev.type == "cuda":
         torch.cuda.synchronize()

@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--profile-host", default=None,
                     help="cProfile the timed region's host side into this file (diagnosis only: "
                          "the profiler slows the loop)")
+    ap.add_argument("--no-parity-leg", action="store_true",
+                    help="skip the short z_source='torch' leg after the timed region")
     ap.add_argument("--no-k1-events", action="store_true",
                     help="no event pairs, no blocker: the uninstrumented loop (rocprofv3 "
                          "cross-check of the K1 durations; the line then carries no roofline)")
@@ -419,12 +421,12 @@ def main():
                                         n_lanes=args.lanes, eval_batch=args.eval_batch,
                                         batched_advance=not args.no_batched_advance))
 
-    def run(layer_ids, timed):
+    def run(layer_ids, timed, z_source="philox", reset=None, events=True):
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
         np.random.seed(42)
         loss_fn = shared_loss
         if hasattr(loss_fn, "reset"):
-            if not timed:
+            if (not timed) if reset is None else reset:
                 loss_fn.reset()
             # (the timed region keeps the prefix cache the warm-up left at the block in front of
             # its first matrix — the steady state of a real pass, where the cached states are
@@ -438,8 +440,8 @@ def main():
         run.loss_fns.append(loss_fn)
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
-                           z_source="philox", k1_form=args.k1_form)
-        kern.enabled = timed and not args.no_k1_events
+                           z_source=z_source, k1_form=args.k1_form)
+        kern.enabled = timed and events and not args.no_k1_events
         out = ls.return_sparsity()
         kern.enabled = False
         return ls, out
@@ -480,6 +482,52 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    import copy as _copy
+    timed_stats = _copy.deepcopy(getattr(run.loss_fns[-1], "stats", None))   # before the extra legs
+
+    class _Snap:
+        stats = timed_stats or {}
+    snap = _Snap() if timed_stats is not None else object()
+    # ---- outside the timed region: the price of the reference's own z ----------------------
+    # (`z_source="torch"`: torch.manual_seed + torch.normal per unit on the device, z materialised,
+    # K1 one launch per layer fed from memory — the entrypoints' `--z_source torch`).  One ViT-g
+    # block and one FlanT5 decoder block, each scored twice from the same cached prefix: first
+    # with torch's draws, then with the in-register stream.
+    parity_mode = None
+    if not args.no_parity_leg and not args.full_forward and world == 1:
+        kern.enabled = False
+        legs = {}
+        vit_blocks = [b for b in block_starts if prunable[b].startswith("visual_encoder")]
+        dec_blocks = [b for b in block_starts if ".decoder." in prunable[b]]
+        picks = [bs[len(bs) // 2] for bs in (vit_blocks, dec_blocks) if bs]
+        ends = {b: (block_starts[block_starts.index(b) + 1]
+                    if block_starts.index(b) + 1 < len(block_starts) else n_total) for b in picks}
+        for b in picks:
+            ids = list(range(b, ends[b]))
+            run([b], timed=False, reset=True)               # prefix cache -> this block, untimed
+            for mode in ("torch", "philox"):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run(ids, timed=True, z_source=mode, reset=False, events=False)
+                torch.cuda.synchronize()
+                legs.setdefault(mode, []).append((len(ids), time.perf_counter() - t1))
+        n_l = sum(n for n, _ in legs["torch"])
+        parity_mode = {
+            "what": "z drawn as the reference does (torch.manual_seed(seed); torch.normal on the "
+                    "device) instead of in registers: same loop, K1 fed from memory, one launch "
+                    "per layer; measured outside the timed region on one ViT-g block and one "
+                    "FlanT5 decoder block, philox leg on the same matrices right after",
+            "layers": n_l,
+            "parity_mode_layers_per_s": n_l / sum(t for _, t in legs["torch"]),
+            "philox_same_layers_per_s": n_l / sum(t for _, t in legs["philox"]),
+            "per_block": [{"first_matrix": prunable[b], "matrices": legs["torch"][i][0],
+                           "torch_ms_per_layer": 1e3 * legs["torch"][i][1] / legs["torch"][i][0],
+                           "philox_ms_per_layer": 1e3 * legs["philox"][i][1] / legs["philox"][i][0]}
+                          for i, b in enumerate(picks)],
+        }
+        parity_mode["slowdown"] = (parity_mode["philox_same_layers_per_s"]
+                                   / parity_mode["parity_mode_layers_per_s"])
 
     kind = args.k1_form
     k1 = kern.summary(kind)
@@ -534,18 +582,17 @@ def main():
             # device (graph captures of newly entered stages synchronise; the bitwise guard reads
             # a loss back) — the loop is device-bound when enqueue << ms_per_step
             "host_enqueue_ms_per_step": 1e3 * max(0.0, ls.stats.get("host_enqueue_seconds", 0.0)
-                                                  - _blocked(run.loss_fns[-1])) / args.steps,
-            "host_blocked_on_device_ms_per_step": 1e3 * _blocked(run.loss_fns[-1]) / args.steps,
+                                                  - _blocked(snap)) / args.steps,
+            "host_blocked_on_device_ms_per_step": 1e3 * _blocked(snap) / args.steps,
             # inside the timed region and inside `value`: the bitwise guard's own sequential
             # re-evaluations, one-off per entry stage (this sample: one per ~2.5 matrices; a whole
             # 588-matrix run: one per ~9)
-            "guard_gpu_ms_per_step": (1e3 * getattr(run.loss_fns[-1], "stats", {}).get(
+            "guard_gpu_ms_per_step": (1e3 * getattr(snap, "stats", {}).get(
                 "guard_gpu_seconds", 0.0) / args.steps),
             "cpu_model": _cpu_model_name(),
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
-            "suffix_forward": (_compact_stats(run.loss_fns[-1].stats)
-                               if hasattr(run.loss_fns[-1], "stats") else None),
+            "suffix_forward": (_compact_stats(snap.stats) if hasattr(snap, "stats") else None),
         },
     }
     if k1:
@@ -581,6 +628,9 @@ def main():
                 "triple": "4*s*numel (read W; write theta+, theta-, restored)",
                 "single": "2*s*numel per pass (read W, write W)"}[kind],
         }
+    if parity_mode is not None:
+        out["parity_mode_layers_per_s"] = parity_mode["parity_mode_layers_per_s"]
+        out["parity_mode"] = parity_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, prunable, batches_local, args)
     if rank == 0:

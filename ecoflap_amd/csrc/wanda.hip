@@ -30,24 +30,28 @@ struct ColsqArgs {
     int64_t tokens, cols;
     int rows_per_chunk, nchunks;
     float* partial;          // [nchunks][cols]
-    unsigned* tickets;       // [gridDim.x + 1], zero between launches
+    unsigned* tickets;       // [colblocks + 1], zero between launches
     float* scaler_row;
     float decay, n_new;      // host form
-    int64_t* n_dev;          // device form
+    int64_t* n_dev;          // device form (nullptr: host form)
     int64_t batch;
+    int colblocks;           // column blocks of this input (= gridDim.x of the one-input launch)
+    int first_wg;            // multi-input launch: first workgroup of this input
+    int vector;              // 16-byte column vectors usable
+    int raw;                 // 1: scaler_row[c] = ||x_c||^2 of THIS input only (no running mean)
 };
 
-template <int DT, bool VECTOR, bool FROM_DEV>
-__global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
+// the work of workgroup (bx = column block, by = row chunk) of one hooked input
+template <int DT, bool VECTOR>
+__device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, const int by,
+                                           float (*lds)[64 * 8], unsigned* last) {
     constexpr int N = VECTOR ? Vec<DT>::N : 1;
-    __shared__ float lds[4][64 * 8];
-    __shared__ unsigned last;
     const void* __restrict__ x = a.x;
     const int64_t tokens = a.tokens, cols = a.cols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t cvec = (int64_t)blockIdx.x * 64 + lane;  // column vector handled by this lane
+    const int64_t cvec = (int64_t)bx * 64 + lane;  // column vector handled by this lane
     const int64_t ncvec = cols / N;
-    const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_chunk;
+    const int64_t r0 = (int64_t)by * a.rows_per_chunk;
     int64_t r1 = r0 + a.rows_per_chunk;
     if (r1 > tokens) r1 = tokens;
     float acc[N];
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
             // device-scope (sc1) store: written through this XCD's L2, so the workgroup that
             // finishes the column block — possibly on another XCD — reads it without anyone
             // having to write back or invalidate a whole L2 (what a release fence would do)
-            __hip_atomic_store(&a.partial[(int64_t)blockIdx.y * cols + cvec * N + i], s,
+            __hip_atomic_store(&a.partial[(int64_t)by * cols + cvec * N + i], s,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -107,17 +111,17 @@ __global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
     __builtin_amdgcn_s_waitcnt(0);         // this wave's partial stores have been performed
     __syncthreads();
     if (threadIdx.x == 0)
-        last = (__hip_atomic_fetch_add(&a.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.nchunks - 1u);
+        *last = (__hip_atomic_fetch_add(&a.tickets[bx], 1u, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.nchunks - 1u);
     __syncthreads();
-    if (!last) return;
+    if (!*last) return;
     float decay = a.decay, n_new = a.n_new;
-    if (FROM_DEV) {                        // formed as the host form does (double, then float)
+    if (a.n_dev) {                         // formed as the host form does (double, then float)
         const int64_t n0 = a.n_dev[0];
         decay = (float)((double)n0 / (double)(n0 + a.batch));
         n_new = (float)(n0 + a.batch);
     }
-    const int64_t c0 = (int64_t)blockIdx.x * 64 * N;
+    const int64_t c0 = (int64_t)bx * 64 * N;
     for (int64_t c = c0 + threadIdx.x; c < c0 + 64 * N && c < cols; c += 256) {
         float s = 0.f;
         int k = 0;
@@ -135,19 +139,81 @@ __global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
                                    __HIP_MEMORY_SCOPE_AGENT);
         const float nrm = __builtin_sqrtf(s);  // torch.norm(...): sqrt of the sum of squares
         const float sq = nrm * nrm;            // ... ** 2
-        const float r = a.scaler_row[c] * decay;  // scaler_row *= n / (n + b)
-        a.scaler_row[c] = r + sq / n_new;         // += ... / nsamples
+        if (a.raw) {
+            a.scaler_row[c] = sq;              // this input's own statistic (data-parallel replay)
+        } else {
+            const float r = a.scaler_row[c] * decay;  // scaler_row *= n / (n + b)
+            a.scaler_row[c] = r + sq / n_new;         // += ... / nsamples
+        }
     }
+    // every wave of this workgroup has read n_dev (and used it) before thread 0 takes the
+    // grid-level ticket: the workgroup that takes the LAST one bumps the count
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&a.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (FROM_DEV) {                    // every column block has read n_dev before its ticket
-            if (__hip_atomic_fetch_add(&a.tickets[gridDim.x], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-                __hip_atomic_store(&a.tickets[gridDim.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.tickets[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.n_dev) {                     // every column block has read n_dev before its ticket
+            if (__hip_atomic_fetch_add(&a.tickets[a.colblocks], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.colblocks - 1u) {
+                __hip_atomic_store(&a.tickets[a.colblocks], 0u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
                 a.n_dev[0] += a.batch;
             }
         }
     }
+}
+
+template <int DT, bool VECTOR>
+__global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
+    __shared__ float lds[4][64 * 8];
+    __shared__ unsigned last;
+    colsq_body<DT, VECTOR>(a, blockIdx.x, blockIdx.y, lds, &last);
+}
+
+// ALL hooked inputs of a transformer block for one calibration sample in ONE launch (the
+// reference calls add_batch from one forward hook per Linear, W:240-252 / :521-533): the
+// per-input launches are pure latency (11-17 us for 1.6-25 MB).  Workgroups of the inputs are
+// laid out one input after another; same arithmetic per input as the one-input kernel.
+struct ColsqMultiArgs {
+    ColsqArgs it[ECOFLAP_COLSQ_MAX_ITEMS];
+    int n;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void colsq_multi_kernel(const ColsqMultiArgs m) {
+    __shared__ float lds[4][64 * 8];
+    __shared__ unsigned last;
+    int i = 0;
+    const int wg = blockIdx.x;
+#pragma unroll 1
+    while (i + 1 < m.n && wg >= m.it[i + 1].first_wg) ++i;
+    const ColsqArgs& a = m.it[i];
+    const int local = wg - a.first_wg;
+    const int bx = local % a.colblocks, by = local / a.colblocks;
+    if (a.vector) colsq_body<DT, true>(a, bx, by, lds, &last);
+    else colsq_body<DT, false>(a, bx, by, lds, &last);
+}
+
+// The running mean replayed from per-batch statistics (raw rows of the kernels above), in
+// global batch order: what the one-process loop computes, bit for bit, when the batches were
+// reduced on different ranks.  sq: [J][ld] fp32; batches: int64[J] (device).
+__global__ __launch_bounds__(256) void colsq_replay_kernel(float* __restrict__ scaler_row,
+                                                           const float* __restrict__ sq,
+                                                           const int64_t* __restrict__ batches,
+                                                           int J, int64_t cols, int64_t ld,
+                                                           int64_t n_before) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float row = scaler_row[c];
+    int64_t n0 = n_before;
+    for (int j = 0; j < J; ++j) {
+        const int64_t b = batches[j];
+        const float decay = (float)((double)n0 / (double)(n0 + b));
+        const float n_new = (float)(n0 + b);
+        const float r = row * decay;
+        row = r + sq[(int64_t)j * ld + c] / n_new;
+        n0 += b;
+    }
+    scaler_row[c] = row;
 }
 
 static inline int colsq_rows_per_chunk(int64_t tokens, int64_t cols) {
@@ -195,19 +261,15 @@ extern "C" int ecoflap_colsqnorm_accum_dev(float* scaler_row, const void* x, int
                             workspace_bytes, stream);
 }
 
-static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
-                            int dtype, int64_t nsamples_before, int64_t* nsamples_dev,
-                            int64_t batch, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+static int colsq_fill(ColsqArgs& a, float* scaler_row, const void* x, int64_t tokens,
+                      int64_t cols, int dtype, int64_t nsamples_before, int64_t* nsamples_dev,
+                      int64_t batch, int raw, void* workspace) {
     if (tokens <= 0 || cols <= 0 || nsamples_before < 0 || batch <= 0) return ECOFLAP_ESIZE;
     if (!scaler_row || !x || !workspace) return ECOFLAP_ENULL;
-    if (workspace_bytes < ecoflap_colsqnorm_workspace_bytes(tokens, cols)) return ECOFLAP_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     const int nvec = dtype == ECOFLAP_F32 ? 4 : 8;
     const bool vector = (cols % nvec == 0) && aligned16(x);
     const int64_t ncv = vector ? cols / nvec : cols;
     if ((ncv + 63) / 64 > COLSQ_MAX_COLBLOCKS) return ECOFLAP_ESIZE;
-    ColsqArgs a;
     a.x = x; a.tokens = tokens; a.cols = cols;
     a.rows_per_chunk = colsq_rows_per_chunk(tokens, cols);
     a.nchunks = colsq_nchunks(tokens, cols);
@@ -218,18 +280,96 @@ static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, in
     a.n_new = (float)(nsamples_before + batch);
     a.n_dev = nsamples_dev;
     a.batch = batch;
-    const dim3 grid((unsigned)((ncv + 63) / 64), (unsigned)a.nchunks);
+    a.colblocks = (int)((ncv + 63) / 64);
+    a.first_wg = 0;
+    a.vector = vector ? 1 : 0;
+    a.raw = raw;
+    return 0;
+}
+
+static int colsq_accum_impl(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
+                            int dtype, int64_t nsamples_before, int64_t* nsamples_dev,
+                            int64_t batch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (tokens <= 0 || cols <= 0) return ECOFLAP_ESIZE;
+    if (workspace_bytes < ecoflap_colsqnorm_workspace_bytes(tokens, cols)) return ECOFLAP_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ColsqArgs a;
+    const int rc = colsq_fill(a, scaler_row, x, tokens, cols, dtype, nsamples_before, nsamples_dev,
+                              batch, 0, workspace);
+    if (rc) return rc;
+    const dim3 grid((unsigned)a.colblocks, (unsigned)a.nchunks);
 #define COLSQ(DT_)                                                                                \
     do {                                                                                          \
-        if (vector && nsamples_dev) hipLaunchKernelGGL((colsq_kernel<DT_, true, true>), grid, dim3(256), 0, s, a);   \
-        else if (vector) hipLaunchKernelGGL((colsq_kernel<DT_, true, false>), grid, dim3(256), 0, s, a);            \
-        else if (nsamples_dev) hipLaunchKernelGGL((colsq_kernel<DT_, false, true>), grid, dim3(256), 0, s, a);      \
-        else hipLaunchKernelGGL((colsq_kernel<DT_, false, false>), grid, dim3(256), 0, s, a);                       \
+        if (a.vector) hipLaunchKernelGGL((colsq_kernel<DT_, true>), grid, dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((colsq_kernel<DT_, false>), grid, dim3(256), 0, s, a);            \
     } while (0)
     if (dtype == ECOFLAP_F32) COLSQ(ECOFLAP_F32);
     else if (dtype == ECOFLAP_F16) COLSQ(ECOFLAP_F16);
     else COLSQ(ECOFLAP_BF16);
 #undef COLSQ
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// Workspace of the multi-input call: ECOFLAP_COLSQ_MAX_ITEMS ticket areas of FIXED size at the
+// head (input i always finds its tickets at the same place, whatever the shapes of the call, so
+// a zeroed-once workspace can serve calls of different shapes one after another), then the
+// inputs' partial sums.
+static inline size_t colsq_item_partial_bytes(int64_t tokens, int64_t cols) {
+    if (tokens <= 0 || cols <= 0) return 0;
+    return ((size_t)colsq_nchunks(tokens, cols) * (size_t)cols * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" size_t ecoflap_colsqnorm_multi_workspace_bytes(const ecoflap_colsq_item* items, int n) {
+    if (!items || n <= 0) return 0;
+    size_t total = (size_t)ECOFLAP_COLSQ_MAX_ITEMS * colsq_ticket_bytes(0);
+    for (int i = 0; i < n; ++i) total += colsq_item_partial_bytes(items[i].tokens, items[i].cols);
+    return total;
+}
+
+extern "C" int ecoflap_colsqnorm_accum_multi(const ecoflap_colsq_item* items, int n, int dtype,
+                                             void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (!items || !workspace) return ECOFLAP_ENULL;
+    if (n <= 0 || n > ECOFLAP_COLSQ_MAX_ITEMS) return ECOFLAP_ESIZE;
+    if (workspace_bytes < ecoflap_colsqnorm_multi_workspace_bytes(items, n)) return ECOFLAP_EWORKSPACE;
+    ColsqMultiArgs m;
+    m.n = n;
+    size_t off = (size_t)ECOFLAP_COLSQ_MAX_ITEMS * colsq_ticket_bytes(0);
+    int wg = 0;
+    for (int i = 0; i < n; ++i) {
+        const ecoflap_colsq_item& it = items[i];
+        const int rc = colsq_fill(m.it[i], it.scaler_row, it.x, it.tokens, it.cols, dtype,
+                                  it.nsamples_dev ? 0 : it.nsamples_before, it.nsamples_dev,
+                                  it.batch, it.raw ? 1 : 0, workspace);
+        if (rc) return rc;
+        m.it[i].tickets = (unsigned*)((char*)workspace + (size_t)i * colsq_ticket_bytes(0));
+        m.it[i].partial = (float*)((char*)workspace + off);
+        m.it[i].first_wg = wg;
+        wg += m.it[i].colblocks * m.it[i].nchunks;
+        off += colsq_item_partial_bytes(it.tokens, it.cols);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ECOFLAP_F32)
+        hipLaunchKernelGGL((colsq_multi_kernel<ECOFLAP_F32>), dim3((unsigned)wg), dim3(256), 0, s, m);
+    else if (dtype == ECOFLAP_F16)
+        hipLaunchKernelGGL((colsq_multi_kernel<ECOFLAP_F16>), dim3((unsigned)wg), dim3(256), 0, s, m);
+    else
+        hipLaunchKernelGGL((colsq_multi_kernel<ECOFLAP_BF16>), dim3((unsigned)wg), dim3(256), 0, s, m);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_colsq_replay(float* scaler_row, const float* sq, const int64_t* batches_dev,
+                                    int n_batches, int64_t cols, int64_t ld,
+                                    int64_t nsamples_before, void* stream) {
+    if (!scaler_row || !sq || !batches_dev) return ECOFLAP_ENULL;
+    if (n_batches <= 0 || cols <= 0 || ld < cols || nsamples_before < 0) return ECOFLAP_ESIZE;
+    hipLaunchKernelGGL(colsq_replay_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, scaler_row, sq, batches_dev, n_batches, cols, ld,
+                       nsamples_before);
     ECO_CHECK_LAUNCH();
     return 0;
 }

@@ -51,6 +51,13 @@ def build_parser():
     p.add_argument("--vit_pruned_checkpoint", type=str, default=None)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--out_dir", type=str, default=".")
+    # build-side: where the zeroth-order perturbation z comes from
+    p.add_argument("--z_source", default="philox", choices=["philox", "torch"],
+                   help="philox (default): z generated in registers by the K1 kernel, never in "
+                        "memory — the build's own stream, no reference run can equal its table; "
+                        "torch: torch.manual_seed(seed) + torch.normal on the parameter's device, "
+                        "the reference's own draw (layer_single_base_pruner.py:482-485) — the "
+                        "parity mode: the table the reference's arithmetic gives on this GPU")
     return p
 
 
@@ -134,6 +141,7 @@ def config_dict(args):
         "sparsity_dict": args.sparsity_dict,
         "prune_per_model": args.prune_per_model,
         "iteration": args.iteration,
+        "z_source": getattr(args, "z_source", "philox"),      # build-side extra (kw-only)
     }
     if str(args.pruning_method).startswith("blipt5_"):
         cfg.update(t5_prune_spec=args.t5_prune_spec, vit_prune_spec=args.vit_prune_spec,
@@ -145,7 +153,9 @@ def config_dict(args):
     return cfg
 
 
-def main(argv=None):
+def main(argv=None, kernels=None):
+    """kernels: backend object for the pruner (tests hand in the oracle-backed checker; None =
+    the HIP library, which raises if it is not built)."""
     args = build_parser().parse_args(argv)
     from . import load_pruner
     device = torch.device(args.device)
@@ -157,7 +167,10 @@ def main(argv=None):
     model, loader = build_model_and_loader(args, device)
     load_pruned_checkpoints(model, args.t5_pruned_checkpoint, args.vit_pruned_checkpoint)
     orig_total = sum((p != 0).float().sum() for p in model.parameters())
-    pruner = load_pruner(args.pruning_method, model, loader, cfg=config_dict(args))
+    cfg = config_dict(args)
+    if kernels is not None:
+        cfg["kernels"] = kernels
+    pruner = load_pruner(args.pruning_method, model, loader, cfg=cfg)
     start = time.time()
     model, sparsity_dict = pruner.prune()
     remaining = sum((p != 0).float().sum() for p in model.parameters())

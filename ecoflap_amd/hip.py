@@ -24,7 +24,9 @@ EXPORTS = [
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
-    "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev", "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
+    "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev",
+    "ecoflap_colsqnorm_multi_workspace_bytes", "ecoflap_colsqnorm_accum_multi", "ecoflap_colsq_replay",
+    "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
     "ecoflap_wanda_prune_matrix", "ecoflap_wanda_block_workspace_bytes", "ecoflap_wanda_prune_block",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
@@ -46,6 +48,15 @@ class WandaItem(ctypes.Structure):
                 ("mask_out", ctypes.c_void_p), ("dtype", ctypes.c_int), ("mode", ctypes.c_int)]
 
 
+class ColsqItem(ctypes.Structure):
+    """`ecoflap_colsq_item` (include/ecoflap_hip.h)."""
+    _fields_ = [("scaler_row", ctypes.c_void_p), ("x", ctypes.c_void_p),
+                ("tokens", ctypes.c_int64), ("cols", ctypes.c_int64),
+                ("nsamples_before", ctypes.c_int64), ("nsamples_dev", ctypes.c_void_p),
+                ("batch", ctypes.c_int64), ("raw", ctypes.c_int)]
+
+
+COLSQ_MAX_ITEMS = 16
 WANDA_MAX_ITEMS = 16
 WANDA_ROWS, WANDA_MATRIX = 0, 1
 
@@ -87,6 +98,10 @@ def load_library():
     lib.ecoflap_colsqnorm_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
     lib.ecoflap_colsqnorm_accum_dev.argtypes = [vp, vp, i64, i64, ci, vp, i64, vp, sz, vp]
+    lib.ecoflap_colsqnorm_multi_workspace_bytes.restype = sz
+    lib.ecoflap_colsqnorm_multi_workspace_bytes.argtypes = [vp, ci]
+    lib.ecoflap_colsqnorm_accum_multi.argtypes = [vp, ci, ci, vp, sz, vp]
+    lib.ecoflap_colsq_replay.argtypes = [vp, vp, vp, ci, i64, i64, i64, vp]
     lib.ecoflap_wanda_workspace_bytes.restype = sz
     lib.ecoflap_wanda_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
@@ -164,6 +179,7 @@ class HipKernels:
         self.lib = load_library()
         self.ws = Workspace()
         self.k6_ws = Workspace(zeroed=True)
+        self.k6_multi_ws = Workspace(zeroed=True)     # its own layout: never shared with k6_ws
         self.hess_ws = Workspace()
         self._pair_tables = {}
 
@@ -366,6 +382,62 @@ class HipKernels:
         _check(self.lib.ecoflap_colsqnorm_accum_dev(
             _ptr(scaler_row), _ptr(x2d), tokens, cols, DTYPE_CODE[x2d.dtype], _ptr(n_dev),
             int(batch), _ptr(ws), ws.numel(), _stream()), "ecoflap_colsqnorm_accum_dev")
+
+    def colsqnorm_accum_multi(self, items, ws=None):
+        """ONE launch for all hooked inputs of a block (one calibration sample).
+        items: [(scaler_row, x2d, nsamples_before, n_dev or None, batch, raw)], one dtype;
+        ws: private workspace (captured graphs keep its address) or None = a cached one.
+        -> the workspace used."""
+        out = None
+        by_dtype = {}
+        for it in items:
+            by_dtype.setdefault(it[1].dtype, []).append(it)
+        for dt, group in by_dtype.items():
+            for g0 in range(0, len(group), COLSQ_MAX_ITEMS):
+                chunk = group[g0:g0 + COLSQ_MAX_ITEMS]
+                arr = (ColsqItem * len(chunk))()
+                for slot, (row, x2d, n_before, n_dev, batch, raw) in zip(arr, chunk):
+                    _gpu(row, "scaler_row")
+                    _gpu(x2d, "x")
+                    slot.scaler_row, slot.x = _ptr(row), _ptr(x2d)
+                    slot.tokens, slot.cols = x2d.shape
+                    slot.nsamples_before = int(n_before)
+                    slot.nsamples_dev = None if n_dev is None else _ptr(n_dev)
+                    slot.batch, slot.raw = int(batch), int(bool(raw))
+                nb = self.lib.ecoflap_colsqnorm_multi_workspace_bytes(arr, len(chunk))
+                if ws is not None and len(by_dtype) == 1 and len(group) <= COLSQ_MAX_ITEMS:
+                    use = ws
+                else:
+                    use = self.k6_multi_ws.get(nb, chunk[0][1].device)
+                _check(self.lib.ecoflap_colsqnorm_accum_multi(
+                    arr, len(chunk), DTYPE_CODE[dt], _ptr(use), use.numel(), _stream()),
+                    "ecoflap_colsqnorm_accum_multi")
+                out = use
+        return out
+
+    def colsqnorm_multi_workspace(self, items):
+        """Private zeroed workspace for `colsqnorm_accum_multi(items, ws)` under graph capture
+        (None when the items do not fit one launch: mixed dtypes / more than 16 inputs)."""
+        if len({it[1].dtype for it in items}) != 1 or len(items) > COLSQ_MAX_ITEMS:
+            return None
+        arr = (ColsqItem * len(items))()
+        for slot, (row, x2d, *_rest) in zip(arr, items):
+            slot.tokens, slot.cols = x2d.shape
+        nb = self.lib.ecoflap_colsqnorm_multi_workspace_bytes(arr, len(items))
+        return torch.zeros(max(int(nb), 16), dtype=torch.uint8, device=items[0][1].device)
+
+    def colsq_replay(self, scaler_row, sq, batches, nsamples_before=0):
+        """scaler_row <- the running mean over per-batch statistics sq[j] (rows of a [J, ld]
+        fp32 tensor, first `cols` entries used) in order, batch sizes `batches` (list of int)."""
+        _gpu(scaler_row, "scaler_row")
+        if sq.device.type != "cuda" or sq.dtype != torch.float32 or sq.stride(-1) != 1:
+            raise EcoflapHipError("sq must be a GPU fp32 tensor with unit inner stride")
+        J, cols = sq.shape
+        assert cols == scaler_row.numel() and J == len(batches)
+        b = torch.tensor([int(v) for v in batches], dtype=torch.int64).to(sq.device, non_blocking=False)
+        _check(self.lib.ecoflap_colsq_replay(_ptr(scaler_row), _ptr(sq), _ptr(b), J, cols,
+                                             sq.stride(0), int(nsamples_before), _stream()),
+               "ecoflap_colsq_replay")
 
     # ---- K7 ---------------------------------------------------------------------------
     def _wanda(self, fn, name, w, scaler_row, k, mask_out):

@@ -55,6 +55,7 @@ class WrappedGPT:
         self.n_dev = None          # device-side sample count while a block graph is captured / replayed
         self.dev_ws = None
         self.dev_batch = 0
+        self.sink = None           # block-level collector: ONE K6 launch per block and sample
 
     def add_batch(self, inp, out):
         if len(inp.shape) == 2:
@@ -63,6 +64,9 @@ class WrappedGPT:
         x = inp.reshape((-1, inp.shape[-1]))
         if not x.is_contiguous():
             x = x.contiguous()
+        if self.sink is not None:
+            self.sink.add(self, x, tmp)    # launched with the block's other inputs (`flush`)
+            return
         if self.n_dev is not None:
             # graph capture: same update, the count lives on the device (the replay loop keeps
             # `nsamples` in step on the host)
@@ -73,6 +77,124 @@ class WrappedGPT:
             return
         self.kernels.colsqnorm_accum(self.scaler_row, x, self.nsamples, tmp)
         self.nsamples += tmp
+
+
+class _K6Collector:
+    """The forward hooks of a block's Linears hand their inputs over here; `flush()` (after the
+    block's forward, also inside a graph capture) reduces all of them in ONE launch
+    (`ecoflap_colsqnorm_accum_multi`).  Same arithmetic per input as one `add_batch` each.
+
+    raw=True (data-parallel stage 2): each input's own statistic ||x_c||^2 goes into a flat
+    per-sample row instead of the running mean; `merge()` exchanges the rows of all ranks'
+    batches and replays the mean in GLOBAL batch order (`ecoflap_colsq_replay`), so every rank
+    ends with the one-process scaler_row bit for bit."""
+
+    def __init__(self, kernels, raw=False):
+        self.kernels, self.raw = kernels, raw
+        self.pending = []
+        self.ws = None             # private workspace while a graph is captured / replayed
+        self.sites = None          # raw: [(wrapped, offset, cols)] in hook order (one forward)
+        self.flat = None           # raw: static [sum cols] target of one forward
+        self.site_batches = None   # raw: batch (leading dim) per site
+        self.samples = []          # raw: one flat row per local calibration sample
+        self.launches = 0
+        self.capturing = False     # inside a graph capture: launches are recorded, not run
+
+    def add(self, wrapped, x, batch):
+        if any(p[0] is wrapped for p in self.pending):
+            self.flush()           # a Linear called twice in one forward: in order, not at once
+        self.pending.append((wrapped, x, batch))
+
+    def flush(self):
+        if not self.pending:
+            return
+        pend, self.pending = self.pending, []
+        if self.raw:
+            # one forward may flush more than once (a Linear called twice): sites accumulate
+            # until `end_sample`
+            if self.flat is None or self._site_cursor + len(pend) > len(self.sites or []):
+                self._grow_sites(pend)
+            items = []
+            for w_, x, b in pend:
+                w0, off, cols = self.sites[self._site_cursor]
+                assert w0 is w_ and cols == x.shape[1]
+                items.append((self.flat[off:off + cols], x, 0, None, b, True))
+                self.site_batches[self._site_cursor] = b
+                self._site_cursor += 1
+                if not self.capturing:
+                    w_.nsamples += b
+        else:
+            items = [(w_.scaler_row, x, w_.nsamples, w_.n_dev, b, False) for w_, x, b in pend]
+            for w_, _, b in pend:
+                if w_.n_dev is None:
+                    w_.nsamples += b
+                else:
+                    w_.dev_batch = b
+        self.kernels.colsqnorm_accum_multi(items, self.ws)
+        self.launches += 1
+        self._last_items = items
+
+    _site_cursor = 0
+
+    def _grow_sites(self, pend):
+        assert not self.samples, "hook sequence changed between calibration samples"
+        sites = list(self.sites or [])
+        off = sum(c for _, _, c in sites)
+        for w_, x, _ in pend:
+            sites.append((w_, off, x.shape[1]))
+            off += x.shape[1]
+        old = self.flat
+        self.flat = torch.zeros(off, dtype=torch.float32, device=pend[0][1].device)
+        if old is not None:
+            self.flat[:old.numel()].copy_(old)
+        self.sites = sites
+        self.site_batches = (self.site_batches or []) + [0] * len(pend)
+
+    def end_sample(self, replayed=False):
+        """after one calibration sample's forward (+ flush), run eagerly or replayed from the
+        captured graph (`replayed`: the host-side counts did not move with the launch)"""
+        if self.raw:
+            if not replayed:
+                assert self._site_cursor == len(self.sites)
+            else:
+                for (w_, _, _), b in zip(self.sites, self.site_batches):
+                    w_.nsamples += b
+            self.samples.append((self.flat.clone(), list(self.site_batches)))
+        self._site_cursor = 0
+
+    def private_workspace(self):
+        """for graph capture: a workspace of its own for the launch just flushed eagerly"""
+        self.ws = self.kernels.colsqnorm_multi_workspace(self._last_items)
+        return self.ws is not None
+
+    def merge(self, local_batch_ids, n_global, process_group):
+        """raw mode, after the block's pass: all ranks' per-batch rows -> every rank replays the
+        running mean over the global batch order.  ONE all-reduce of a [batches, sum cols] fp32
+        matrix whose rows each have exactly one non-zero contributor (exact)."""
+        import torch.distributed as dist
+        total = self.flat.numel()
+        dev = self.flat.device
+        glob = torch.zeros(n_global, total + len(self.sites), dtype=torch.float32, device=dev)
+        for bi, (row, bs) in zip(local_batch_ids, self.samples):
+            glob[bi, :total] = row
+            glob[bi, total:] = torch.tensor(bs, dtype=torch.float32, device=dev)   # small ints: exact
+        dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=process_group)
+        batches = glob[:, total:].round().to(torch.int64).cpu().tolist()
+        by_w = {}
+        for si, (w_, off, cols) in enumerate(self.sites):
+            by_w.setdefault(id(w_), (w_, []))[1].append((si, off, cols))
+        for w_, sites in by_w.values():
+            if len(sites) == 1:
+                si, off, cols = sites[0]
+                sq = glob[:, off:off + cols]
+                bl = [batches[j][si] for j in range(n_global)]
+            else:        # called several times per forward: (sample, site) order
+                sq = torch.stack([glob[j, off:off + cols] for j in range(n_global)
+                                  for _, off, cols in sites]).contiguous()
+                bl = [batches[j][si] for j in range(n_global) for si, _, _ in sites]
+            w_.scaler_row.zero_()
+            self.kernels.colsq_replay(w_.scaler_row, sq, bl, 0)
+            w_.nsamples_global = int(sum(bl))
 
 
 class _StopForward(Exception):
@@ -174,10 +296,12 @@ class _BlockwiseWanda:
         handle = blocks[0].register_forward_pre_hook(grab, with_kwargs=True)
         total = 0
         rank, world = self._rank_world()
+        self.local_batch_ids, self.global_batches = [], 0
         try:
             for bi, batch in enumerate(dataloader):
                 if total >= n_samples:
                     break
+                self.global_batches = bi + 1
                 if batch_len is not None:
                     total += batch_len(batch)
                 else:
@@ -185,6 +309,7 @@ class _BlockwiseWanda:
                               else batch["image"].shape[0])
                 if (bi % world) != rank:
                     continue              # another rank calibrates on this batch
+                self.local_batch_ids.append(bi)
                 try:
                     forward_fn(model, batch)
                 except _StopForward:
@@ -216,9 +341,14 @@ class _BlockwiseWanda:
                                               n_samples, optional_keys, batch_len)
         n_batches = min(n_samples, len(inps))     # (:226/:505: compared against the batch count)
 
+        collector = [None]        # the live block's K6 collector (None: plain pass / SparseGPT)
+
         def call(block, j):
             with torch.no_grad(), autocast():
                 y = block(inps[j], **caches[j])
+            if collector[0] is not None:
+                collector[0].flush()
+                collector[0].end_sample()
             return y[0] if take_first else y
 
         # equally shaped calibration samples on the GPU: each block forward (with its K6 hooks
@@ -239,13 +369,23 @@ class _BlockwiseWanda:
                 outs[0] = y0
             static_x = inps[0].clone()
             static_kw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in caches[0].items()}
+            col = collector[0] if wrapped else None
             for w_ in (wrapped or {}).values():
-                w_.n_dev = torch.tensor([w_.nsamples], dtype=torch.int64, device=static_x.device)
+                if col is None or not col.raw:
+                    w_.n_dev = torch.tensor([w_.nsamples], dtype=torch.int64, device=static_x.device)
+            if col is not None:
+                col.private_workspace()       # (None: the cached one; this stream only)
+                col.capturing = True
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
                 with autocast():
                     y = block(static_x, **static_kw)
+                if col is not None:
+                    col.flush()
                 y = y[0] if take_first else y
+            if col is not None:
+                col.capturing = False
+                col._site_cursor = 0
             for j in range(1, n_batches):
                 static_x.copy_(inps[j], non_blocking=True)
                 for k, v in caches[j].items():
@@ -254,10 +394,15 @@ class _BlockwiseWanda:
                 graph.replay()
                 if keep:
                     outs[j] = y.clone()
-                for w_ in (wrapped or {}).values():
-                    w_.nsamples += w_.dev_batch
+                if col is not None and col.raw:
+                    col.end_sample(replayed=True)
+                else:
+                    for w_ in (wrapped or {}).values():
+                        w_.nsamples += w_.dev_batch
             for w_ in (wrapped or {}).values():
                 w_.n_dev, w_.dev_ws = None, None
+            if col is not None:
+                col.ws = None
             torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
             del graph
 
@@ -275,6 +420,14 @@ class _BlockwiseWanda:
                     lambda _m, inp, out, _n=name: wrapped[_n].add_batch(inp[0].data, out.data))
                 for name in wrapped
             ]
+            _, world = self._rank_world()
+            if not sparsegpt and hasattr(self.kernels, "colsqnorm_accum_multi"):
+                # ONE K6 launch per block and sample; under data parallelism the per-batch
+                # statistics are kept apart and replayed in global order (exact)
+                collector[0] = _K6Collector(
+                    self.kernels, raw=world > 1 and hasattr(self.kernels, "colsq_replay"))
+                for w_ in wrapped.values():
+                    w_.sink = collector[0]
             if graphed:
                 graph_pass(block, wrapped, keep=False)
             else:
@@ -282,7 +435,18 @@ class _BlockwiseWanda:
                     outs[j] = call(block, j)
             for h in handles:
                 h.remove()
-            if not sparsegpt:
+            col, collector[0] = collector[0], None
+            for w_ in wrapped.values():
+                w_.sink = None
+            if col is not None:
+                self.owner.stage_stats.setdefault("k6_launches", 0)
+                self.owner.stage_stats["k6_launches"] += col.launches
+            if col is not None and col.raw:
+                self.owner.stage_stats["k6_dp_exact_blocks"] = (
+                    self.owner.stage_stats.get("k6_dp_exact_blocks", 0) + 1)
+                col.merge(self.local_batch_ids[:n_batches], self.global_batches,
+                          getattr(self.owner, "process_group", None))
+            elif not sparsegpt:
                 self._merge_statistics(wrapped)
             else:
                 self._merge_hessians(wrapped)

@@ -200,6 +200,37 @@ int ecoflap_colsqnorm_accum_dev(float* scaler_row, const void* x, int64_t tokens
                                 int64_t batch, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* All hooked inputs of ONE transformer block for one calibration sample in ONE launch
+ * (the reference's per-Linear forward hooks, wanda_pruner.py:240-252 / :521-533, each call
+ * add_batch on their own input): up to ECOFLAP_COLSQ_MAX_ITEMS inputs of one dtype, the
+ * same arithmetic per input as ecoflap_colsqnorm_accum[_dev].
+ *   nsamples_dev != NULL: the device form (count read from / bumped in device memory);
+ *   raw != 0: scaler_row[c] = norm(x_c, 2)**2 of THIS input alone — no running mean, the
+ *             counts are neither read nor bumped (data-parallel stage 2: per-batch rows are
+ *             exchanged and replayed in global batch order by ecoflap_colsq_replay).
+ * One workspace for the call (zeroed once by its owner, like the one-input form). */
+#define ECOFLAP_COLSQ_MAX_ITEMS 16
+typedef struct {
+    float* scaler_row;          /* float[cols] */
+    const void* x;              /* [tokens, cols] row-major */
+    int64_t tokens, cols;
+    int64_t nsamples_before;    /* host form (ignored when nsamples_dev != NULL) */
+    int64_t* nsamples_dev;      /* device form, or NULL */
+    int64_t batch;              /* leading dimension of the hook's input (W:72-75) */
+    int raw;
+} ecoflap_colsq_item;
+size_t ecoflap_colsqnorm_multi_workspace_bytes(const ecoflap_colsq_item* items, int n);
+int ecoflap_colsqnorm_accum_multi(const ecoflap_colsq_item* items, int n, int dtype,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+/* The running mean of wanda_pruner.py:80-84 replayed over per-batch statistics:
+ *   for j in 0..n_batches-1:  row = row * (n/(n+b_j)) + sq[j][c] / (n+b_j);  n += b_j
+ * with exactly the roundings of the fused update above, so batches reduced on different
+ * ranks give the one-process scaler_row bit for bit.  sq: float[n_batches][ld] (device),
+ * batches_dev: int64[n_batches] (device). */
+int ecoflap_colsq_replay(float* scaler_row, const float* sq, const int64_t* batches_dev,
+                         int n_batches, int64_t cols, int64_t ld, int64_t nsamples_before,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------
  * K7  Wanda metric + selection + zeroing
  * metric = |W| * sqrt(scaler_row)  (fp32)          wanda_pruner.py:260, :541

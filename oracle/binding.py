@@ -46,6 +46,8 @@ class Oracle:
         L.oracle_absprod_reduce.argtypes = [vp, vp, i64, ci, ci, ci]
         L.oracle_absprod_reduce.restype = ctypes.c_double
         L.oracle_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64]
+        L.oracle_colsq_raw.argtypes = [vp, vp, i64, i64, ci]
+        L.oracle_colsq_replay.argtypes = [vp, vp, vp, i64, i64, i64, i64]
         L.oracle_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp]
         L.oracle_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp]
         L.oracle_mask_mul.argtypes = [vp, vp, i64, ci]
@@ -99,6 +101,18 @@ class Oracle:
         tokens, cols = x2d.shape
         self.lib.oracle_colsqnorm_accum(_p(scaler_row), _p(x2d), tokens, cols, DT[x2d.dtype],
                                         n_before, batch)
+
+    def colsq_raw(self, out_row, x2d):
+        _cpu(out_row), _cpu(x2d)
+        tokens, cols = x2d.shape
+        self.lib.oracle_colsq_raw(_p(out_row), _p(x2d), tokens, cols, DT[x2d.dtype])
+
+    def colsq_replay(self, scaler_row, sq, batches, n_before=0):
+        _cpu(scaler_row), _cpu(sq)
+        assert sq.dtype == torch.float32 and sq.dim() == 2
+        b = torch.tensor([int(v) for v in batches], dtype=torch.int64)
+        self.lib.oracle_colsq_replay(_p(scaler_row), _p(sq), _p(b), sq.shape[0], sq.shape[1],
+                                     sq.shape[1], n_before)
 
     def wanda_prune_rows(self, w, scaler_row, k, want_mask=True):
         _cpu(w), _cpu(scaler_row)

@@ -273,6 +273,36 @@ void oracle_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens, in
     }
 }
 
+/* One input's own statistic, torch.norm(x, p=2, dim=tokens) ** 2 (W:84), and the running mean
+ * of W:80-84 replayed over such per-batch rows in order — the decomposition the data-parallel
+ * stage 2 exchanges; composing the two equals oracle_colsqnorm_accum call by call. */
+void oracle_colsq_raw(float* out_row, const void* x, int64_t tokens, int64_t cols, int dt) {
+    for (int64_t c = 0; c < cols; ++c) {
+        double s = 0.0;
+        for (int64_t t = 0; t < tokens; ++t) {
+            float v = load_dt(x, t * cols + c, dt);
+            s += (double)(v * v);
+        }
+        float nrm = sqrtf((float)s);
+        out_row[c] = nrm * nrm;
+    }
+}
+void oracle_colsq_replay(float* scaler_row, const float* sq, const int64_t* batches, int64_t J,
+                         int64_t cols, int64_t ld, int64_t n_before) {
+    for (int64_t c = 0; c < cols; ++c) {
+        float row = scaler_row[c];
+        int64_t n0 = n_before;
+        for (int64_t j = 0; j < J; ++j) {
+            float decay = (float)((double)n0 / (double)(n0 + batches[j]));
+            float n_new = (float)(n0 + batches[j]);
+            float r = row * decay;
+            row = r + sq[j * ld + c] / n_new;
+            n0 += batches[j];
+        }
+        scaler_row[c] = row;
+    }
+}
+
 /* ------------------------------------------------------------------ K7 (W:260-279, W:541-558) */
 static inline float wanda_metric(const void* w, int64_t i, int dt, float sq) {
     return fabsf(load_dt(w, i, dt)) * sq;   /* abs(W) * sqrt(scaler_row) in fp32 */

@@ -63,6 +63,24 @@ class OracleKernels:
         self.o.colsqnorm_accum(s, self._host(x2d), nsamples_before, batch)
         scaler_row.copy_(s)
 
+    def colsqnorm_accum_multi(self, items, ws=None):
+        """items: [(scaler_row, x2d, nsamples_before, n_dev or None, batch, raw)]"""
+        for row, x2d, n_before, n_dev, batch, raw in items:
+            if raw:
+                out = torch.empty(row.shape, dtype=torch.float32)
+                self.o.colsq_raw(out, self._host(x2d))
+                row.copy_(out)
+                continue
+            if n_dev is not None:
+                n_before = int(n_dev.item())
+                n_dev += batch
+            self.colsqnorm_accum(row, x2d, n_before, batch)
+
+    def colsq_replay(self, scaler_row, sq, batches, nsamples_before=0):
+        s = self._host(scaler_row)
+        self.o.colsq_replay(s, self._host(sq).contiguous(), batches, nsamples_before)
+        scaler_row.copy_(s)
+
     def wanda_prune_rows(self, w, scaler_row, k, mask_out=None):
         h = self._host(w)
         m = self.o.wanda_prune_rows(h, self._host(scaler_row), k, want_mask=True)

@@ -114,7 +114,9 @@ def _run_wanda(rank, world):
                max_sparsity_per_layer=0.6, num_data_first_stage=8,
                sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum",
                kernels=OracleKernels(), z_source=torch_cpu_normal)
-    model, table = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg).prune()
+    pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg)
+    model, table = pruner.prune()
+    _run_wanda.last_stats = dict(pruner.stage_stats)
     return table, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
 
@@ -124,15 +126,17 @@ def _wanda_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.save(_run_wanda(rank, world), os.path.join(out_dir, f"w{rank}.pt"))
+        torch.save(_run_wanda.last_stats, os.path.join(out_dir, f"wstats{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
     """Whole blipt5_wanda_pruner under DP=2: stage 1 bit-identical to one process; stage 2
-    shards the calibration batches and all-reduces the column statistics once per block, so
-    both replicas end with IDENTICAL pruned weights, and the same pruning pattern as one
-    process up to re-association of the fp32 statistics (equal here)."""
+    shards the calibration batches, exchanges the PER-BATCH column statistics once per block
+    and replays the reference's running mean (wanda_pruner.py:80-84) in global batch order on
+    every rank: both replicas AND the one-process run end with the same pruned state_dict,
+    bit for bit."""
     single_table, single_w = _run_wanda(0, 1)
     port = 31500 + os.getpid() % 2000
     mp.spawn(_wanda_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
@@ -141,9 +145,21 @@ def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
     assert t0 == t1 == single_table
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k                       # replicas agree bit for bit
-    agree = sum(int(((w0[k] == 0) == (single_w[k] == 0)).sum()) for k in w0)
-    total = sum(v.numel() for v in w0.values())
-    assert agree / total > 0.9999
+        assert torch.equal(w0[k], single_w[k]), k                 # ... and equal one process
+    stats = torch.load(tmp_path / "wstats0.pt", weights_only=False)
+    assert stats["k6_dp_exact_blocks"] == 6                       # 2 ViT + 2 encoder + 2 decoder
+
+
+def test_three_ranks_uneven_shards_wanda_equals_one_process(tmp_path):
+    """4 calibration batches over 3 ranks (2 + 1 + 1): same pruned state_dict as one process."""
+    single_table, single_w = _run_wanda(0, 1)
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_wanda_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        t, w = torch.load(tmp_path / f"w{r}.pt", weights_only=False)
+        assert t == single_table
+        for k in w:
+            assert torch.equal(w[k], single_w[k]), (r, k)
 
 
 # ---------------------------------------------------------------- Real-* / global gradient pruning

@@ -100,8 +100,7 @@ def test_rccl_two_ranks_full_pruner_replicas_agree(tmp_path):
     assert t0 == t1 == single[0]                              # stage 1: bit-identical table
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k                   # replicas agree bit for bit
-    agree = sum(int(((w0[k] == 0) == (single[2][k] == 0)).sum()) for k in w0)
-    assert agree / sum(v.numel() for v in w0.values()) > 0.999
+        assert torch.equal(w0[k], single[2][k]), k            # and equal the one-process run
 
 
 def test_bench_self_launch_refuses_more_ranks_than_gpus():

@@ -412,6 +412,66 @@ def test_colsqnorm_single_launch_shared_workspace_and_device_count(kern, oracle)
     assert torch.equal(s_host, s_dev)
 
 
+@pytest.mark.parametrize("dt,shapes", [
+    (torch.float16, [(8 * 257, 1408), (8 * 257, 1408), (8 * 257, 1408), (8 * 257, 6144)]),     # ViT-g block
+    (torch.bfloat16, [(8 * 48, 2048)] * 4 + [(8 * 16, 2048)] * 3 + [(8 * 48, 2048)] * 2
+                     + [(8 * 16, 5120)] + [(37, 130)]),                                         # T5 decoder block + odd
+    (torch.float32, [(1, 8), (513, 2048), (37, 130)])])
+def test_colsq_multi_one_launch_per_block_equals_per_input_launches(kern, oracle, dt, shapes):
+    """`ecoflap_colsqnorm_accum_multi`: all hooked inputs of a block in ONE launch == one
+    `ecoflap_colsqnorm_accum` per input, bit for bit (same arithmetic per input), over three
+    samples through one shared workspace; the device-count form likewise; the raw form (this
+    input's ||x_c||^2 alone) == the oracle's restatement (2e-6) and, replayed through
+    `ecoflap_colsq_replay`, == the fused running mean bit for bit."""
+    torch.manual_seed(len(shapes))
+    samples = [[gpu((torch.randn(t, c) * 1.3).to(dt)) for t, c in shapes] for _ in range(3)]
+    single = [torch.zeros(c, device="cuda") for _, c in shapes]
+    multi = [torch.zeros(c, device="cuda") for _, c in shapes]
+    multi_dev = [torch.zeros(c, device="cuda") for _, c in shapes]
+    n_dev = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in shapes]
+    raws = []
+    ws_dev = None
+    for j, xs in enumerate(samples):
+        for row, x in zip(single, xs):
+            kern.colsqnorm_accum(row, x, 8 * j, 8)
+        kern.colsqnorm_accum_multi([(row, x, 8 * j, None, 8, False) for row, x in zip(multi, xs)])
+        items = [(row, x, 0, nd, 8, False) for row, x, nd in zip(multi_dev, xs, n_dev)]
+        if ws_dev is None:
+            ws_dev = kern.colsqnorm_multi_workspace(items)
+        kern.colsqnorm_accum_multi(items, ws_dev)
+        raw = [torch.full((c,), float("nan"), device="cuda") for _, c in shapes]
+        kern.colsqnorm_accum_multi([(row, x, 0, None, 8, True) for row, x in zip(raw, xs)])
+        raws.append(raw)
+    for i in range(len(shapes)):
+        assert torch.equal(single[i], multi[i]), i
+        assert torch.equal(single[i], multi_dev[i]), i
+        assert int(n_dev[i].item()) == 24
+        ref = torch.empty(shapes[i][1])
+        oracle.colsq_raw(ref, samples[0][i].cpu())
+        np.testing.assert_allclose(raws[0][i].cpu().numpy(), ref.numpy(), rtol=2e-6)
+        replayed = torch.zeros(shapes[i][1], device="cuda")
+        kern.colsq_replay(replayed, torch.stack([raws[j][i] for j in range(3)]), [8, 8, 8])
+        assert torch.equal(replayed, single[i]), i
+        # strided rows (a column slice of the exchanged [batches, sum cols] matrix)
+        wide = torch.zeros(3, shapes[i][1] + 24, device="cuda")
+        wide[:, 16:16 + shapes[i][1]] = torch.stack([raws[j][i] for j in range(3)])
+        replayed2 = torch.zeros(shapes[i][1], device="cuda")
+        kern.colsq_replay(replayed2, wide[:, 16:16 + shapes[i][1]], [8, 8, 8])
+        assert torch.equal(replayed2, single[i]), i
+        # the oracle's replay of the oracle's raw rows == the oracle's fused update
+        o_fused = torch.zeros(shapes[i][1])
+        o_rows = []
+        for j in range(3):
+            xh = samples[j][i].cpu()
+            oracle.colsqnorm_accum(o_fused, xh, 8 * j, 8)
+            r = torch.empty(shapes[i][1])
+            oracle.colsq_raw(r, xh)
+            o_rows.append(r)
+        o_rep = torch.zeros(shapes[i][1])
+        oracle.colsq_replay(o_rep, torch.stack(o_rows), [8, 8, 8])
+        assert torch.equal(o_rep, o_fused)
+
+
 # ------------------------------------------------------------------------------ K7
 def _ties(w, levels):
     return (torch.round(w * levels) / levels)
@@ -743,6 +803,28 @@ def test_stage1_torch_z_source_on_device(kern):
         assert got[0] == want[0]
         for k, v in got[2].items():
             assert torch.equal(v, want[2][k]), k
+
+
+def test_harness_z_source_torch_hip_equals_oracle():
+    """The entrypoint's parity mode (`--z_source torch`, what `LAVIS/scripts/blip2/
+    ecoflap_zeroth.py 0 12341 --z_source torch` passes through): the harness run with the HIP
+    library == the harness run with the oracle's arithmetic, both fed torch's own device draws
+    (torch.manual_seed(seed); torch.normal(..., device=param.device), the reference's lines
+    layer_single_base_pruner.py:482-485) — sparsity table and pruned weights bit for bit."""
+    from oracle_backend import OracleKernels
+    import ecoflap_amd.harness as H
+    argv = ["--shape", "blip2", "--toy", "--device", "cuda", "--pruning_method", "blipt5_wanda_pruner",
+            "--score_method", "MEZO-GradOnly_sum", "--sparsity_ratio_granularity", "block",
+            "--max_sparsity_per_layer", "0.6", "--prunining_dataset_batch_size", "2", "--num_data", "8",
+            "--num_data_first_stage", "8", "--t5_prune_spec", "2-0.5-1.0-1.0",
+            "--vit_prune_spec", "2-0.5-1.0-1.0", "--z_source", "torch"]
+    m_hip, t_hip = H.main(argv)
+    stats = H.main.last_stage_stats
+    m_ora, t_ora = H.main(argv, kernels=OracleKernels())
+    assert isinstance(t_hip, dict) and t_hip == t_ora and len(set(t_hip.values())) > 1
+    for (k, a), (_, b) in zip(m_hip.state_dict().items(), m_ora.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert stats["stage1"]["forwards"] > 0
 
 
 @pytest.mark.parametrize("fp32", [True, False])

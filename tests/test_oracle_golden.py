@@ -76,6 +76,34 @@ def test_wrapped_gpt_running_mean(oracle, golden_dir):
             np.testing.assert_allclose(s.numpy(), g[f"{key}_s{i}"], rtol=1e-5, atol=0)
 
 
+def test_wrapped_gpt_raw_rows_replayed_equal_the_running_mean(oracle, golden_dir):
+    """The decomposition the data-parallel stage 2 exchanges: per-batch ||x_c||^2 rows
+    (`oracle_colsq_raw`) replayed in order (`oracle_colsq_replay`) == WrappedGPT.add_batch call
+    by call (wanda_pruner.py:71-84) — bit for bit against the fused restatement, 1e-5 against
+    the reference's own scaler_row goldens."""
+    g = np.load(os.path.join(golden_dir, "g5_wrapped_gpt.npz"))
+    for case in g["cases"]:
+        key, steps = str(case).split("|")
+        dt = NP2T[key.split("_")[0]]
+        cols = int(key.split("_")[1])
+        fused = torch.zeros(cols, dtype=torch.float32)
+        rows, bs, n = [], [], 0
+        for i in range(int(steps)):
+            x = from_bits(g[f"{key}_x{i}"], dt)
+            b = 1 if x.dim() == 2 else x.shape[0]
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()
+            oracle.colsqnorm_accum(fused, x2, n, b)
+            n += b
+            r = torch.empty(cols, dtype=torch.float32)
+            oracle.colsq_raw(r, x2)
+            rows.append(r)
+            bs.append(b)
+            rep = torch.zeros(cols, dtype=torch.float32)
+            oracle.colsq_replay(rep, torch.stack(rows), bs)
+            assert torch.equal(rep, fused), (key, i)
+            np.testing.assert_allclose(rep.numpy(), g[f"{key}_s{i}"], rtol=1e-5, atol=0)
+
+
 def test_philox_known_answer(oracle):
     """Random123 known-answer vectors (kat_vectors) for philox4x32 at 7 and 10 rounds:
     all-zero, all-ones and the pi-digits counter/key."""
