@@ -304,6 +304,7 @@ def self_launch(n, argv, script=None, timeout=None):
                 stdout=rank0_out if r == 0 else sys.stderr, stderr=sys.stderr))
         t_end = None if timeout is None else time.time() + timeout
         worst = 0
+        killed_here = set()                       # ranks the launcher itself ended
         while True:
             codes = [p.poll() for p in procs]
             if all(c is not None for c in codes):
@@ -313,16 +314,19 @@ def self_launch(n, argv, script=None, timeout=None):
                 # one rank died (the others would sit in a collective until the process group's
                 # own timeout) or the caller's limit passed: end exactly the PIDs started here
                 worst = 1 if failed else 124
-                for p in procs:
+                for i, p in enumerate(procs):
                     if p.poll() is None:
+                        killed_here.add(i)
                         p.kill()
                 for p in procs:
                     p.wait()
                 break
             time.sleep(0.2)
-        for p in procs:
+        for i, p in enumerate(procs):
             rc = p.returncode
-            if rc and worst != 124:               # a signal (negative) reads as 128 + signal
+            # the code reported is that of the rank that FAILED, not the -9 of the survivors this
+            # launcher killed because of it; a signal (negative) reads as 128 + signal
+            if rc and worst != 124 and i not in killed_here:
                 worst = max(worst, rc if rc > 0 else 128 - rc)
         rank0_out.seek(0)
         out0 = rank0_out.read()
@@ -333,7 +337,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no GPU call before this point (module imports only)
-        visible = torch.cuda.device_count()         # counting devices does not initialise HIP
+        # counting devices goes through amdsmi / sysfs on this image and does not initialise HIP
+        # in the parent; where torch has to fall back to hipGetDeviceCount the check is skipped
+        # (ECOFLAP_BENCH_NO_COUNT=1) and the ranks themselves report a missing device
+        visible = (args.gpus if os.environ.get("ECOFLAP_BENCH_NO_COUNT")
+                   else torch.cuda.device_count())
         if visible < args.gpus and not args.same_device:
             print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible",
                   file=sys.stderr)

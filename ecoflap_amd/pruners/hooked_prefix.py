@@ -121,6 +121,14 @@ class HookedPrefixLoss:
 
     def _cached_call(self, model, samples, cuda_enabled):
         key = id(samples)
+        # the cache is keyed by the batch OBJECT: keep it alive (an id can be recycled once its
+        # object is gone — a loader yielding fresh batches would be served another batch's
+        # activations) and check identity
+        held = self.__dict__.setdefault("_held", {})
+        if held.get(key) is not samples:
+            held[key] = samples
+            self.cache.pop(key, None)
+            self.valid.pop(key, None)
         record_sequence = self.sequence is None
         seen = []
         limit = self._limit()
@@ -154,14 +162,20 @@ class HookedPrefixLoss:
                 return out
             return patched
 
+        had_own = {}
         for mod in self.paths:
+            had_own[mod] = "forward" in mod.__dict__
             originals[mod] = mod.forward
             mod.forward = make(mod, originals[mod])
         try:
             out = self.loss_func(model, samples, cuda_enabled)
         finally:
             for mod, fwd in originals.items():
-                mod.forward = fwd
+                if had_own[mod]:
+                    mod.forward = fwd
+                else:
+                    del mod.forward       # back to the class's forward: nothing left on the instance
+
         if record_sequence:
             self.sequence = seen
             limit = self._limit()

@@ -1,7 +1,8 @@
 """Loss closures handed to stage 1, `(model, batch, cuda_enabled) -> (0-dim loss, batch_len)` —
 the three the LAVIS pruners use (LAVIS/lavis/compression/pruners/utils.py:21-67: the language
 and vision-language ones read the model's own "loss"; the vision one rebuilds a cross entropy
-from `predict()`'s x100-scaled zero-shot logits)."""
+from `predict()`'s x100-scaled zero-shot logits) and CoOp's CLIP contrastive closure
+(CoOp/trainers/zsclip.py:73-91)."""
 import torch
 import torch.nn.functional as F
 
@@ -39,3 +40,24 @@ def loss_vision(model, samples, cuda_enabled):
     targets = out["targets"]
     picked = F.softmax(out["predictions"] / 100, -1).gather(1, targets.view(-1, 1)).squeeze(1)
     return -(picked.log().mean()), len(targets)
+
+
+def clip_contrastive(prompt_tokens):
+    """CoOp's zero-shot CLIP closure (CoOp/trainers/zsclip.py:73-91), handed to its pruner as
+    `forward_to_cache(model, batch, device)`: every image of the batch is paired with the
+    prompt of its OWN label ("a photo of a {class}."), the two-tower model returns the
+    image->text and text->image logit matrices, and the loss is the symmetric InfoNCE — the mean
+    of the two cross entropies against the diagonal, both taken in fp32.
+
+    prompt_tokens: LongTensor [num_classes, context] — the tokenised prompt of every class.  The
+    reference tokenises the formatted strings inside the closure (`clip.tokenize`, CoOp's
+    vendored BPE); the build takes ids, as every synthetic shape here does.
+    -> closure(model, batch{"img","label"}, device) -> (0-dim fp32 loss, batch_len)."""
+    def forward_to_cache(model, batch, device):
+        labels = batch["label"]
+        text = prompt_tokens.to(labels.device)[labels].to(device)
+        per_image, per_text = model(batch["img"].to(device), text)
+        diagonal = torch.arange(per_image.shape[0], device=device, dtype=torch.long)
+        both = F.cross_entropy(per_image.float(), diagonal) + F.cross_entropy(per_text.float(), diagonal)
+        return both / 2, labels.shape[0]
+    return forward_to_cache

@@ -206,6 +206,7 @@ class PrefixCachedLoss:
         # output of the batched path (per group / per evaluation / shared pass), keyed by where
         # they came from; None in production
         self.trace = None
+        self.trace_subops = False   # with `trace`: also checksums of the EVA blocks' intermediates
         self._inject_mismatch_once = False
         self.gchains = {}           # (family, g) -> _StageGraphs at batch g*B (lane 0)
         self._group_ready = set()   # (lane id, family, entry, R, S) captured with the device quiescent
@@ -866,6 +867,11 @@ class PrefixCachedLoss:
                     for j in range(entry + 1, R)}
                 tr.setdefault("_meta", {})[("group", items[0][0])] = (
                     gch, stream, entry, R, [slot for slot, _, _ in items])
+                for j in range(entry + 1, R):
+                    for name, t in gch.subops.get(j, {}).items():
+                        v = t.reshape(-1, t.shape[-1]).view(torch.int16)
+                        tr[("sub", items[0][0], j, name, "rows")] = v.sum(1, dtype=torch.int64)
+                        tr[("sub", items[0][0], j, name, "cols")] = v.sum(0, dtype=torch.int64)
             for pos, (slot, _, _) in enumerate(items):
                 x = _slice_state(mid, pos, B, g)
                 if S > R:
@@ -927,6 +933,7 @@ class _StageGraphs:
         self.solo = {}                  # stage -> the same, captured standalone (run_stage)
         self.pool = None
         self.bridges = {}               # stage -> tensors to copy into its static input
+        self.subops = {}                # stage -> {name: intermediate tensor} (diagnostics)
 
     def _capture(self, j, static_in):
         import time
@@ -939,10 +946,18 @@ class _StageGraphs:
         if self.stream is not None:
             kw["stream"] = self.stream
         last = (j == len(self.plan) - 1)
-        with torch.no_grad(), capture_graph(graph, **kw):
-            out = self.plan[j][2](static_in)
-            if last:
-                out = {"__loss__": self.owner.result(out)}
+        from ..shapes import fused as _fused
+        sink = {} if getattr(self.owner, "trace_subops", False) else None
+        _fused.TRACE_SINK = sink
+        try:
+            with torch.no_grad(), capture_graph(graph, **kw):
+                out = self.plan[j][2](static_in)
+                if last:
+                    out = {"__loss__": self.owner.result(out)}
+        finally:
+            _fused.TRACE_SINK = None
+        if sink:
+            self.subops[j] = sink
         self.graphs[j] = (graph, static_in, out)
         self.owner.stats["graph_captures"] += 1
         self.owner.stats["capture_seconds"] += time.time() - t0

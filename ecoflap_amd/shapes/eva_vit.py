@@ -46,10 +46,12 @@ class Attention(nn.Module):
             if fused.qkv_bias_add(qkv, self.q_bias, self.v_bias) is None:
                 qkv = qkv + torch.cat(
                     (self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(qkv.dtype)
+        from . import fused
+        fused.trace("01_qkv", qkv)
         qkv = qkv.reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         x = F.scaled_dot_product_attention(q, k, v, attn_mask=rel_pos_bias, scale=self.scale)
-        x = x.transpose(1, 2).reshape(B, N, -1)
+        x = fused.trace("02_attn", x.transpose(1, 2).reshape(B, N, -1))
         return self.proj(x)
 
 
@@ -64,14 +66,23 @@ class Block(nn.Module):
     def forward(self, x, rel_pos_bias=None):
         from . import fused          # one kernel per norm (and residual add) on the GPU loop
         h = fused.add_layernorm(x, None, self.norm1)
-        a = self.attn(self.norm1(x) if h is None else h[1], rel_pos_bias=rel_pos_bias)
+        a = self.attn(fused.trace("00_ln1", self.norm1(x) if h is None else h[1]),
+                      rel_pos_bias=rel_pos_bias)
+        fused.trace("03_proj", a)
         h = fused.add_layernorm(x, a, self.norm2)
         if h is None:
             x = x + a
             h2 = self.norm2(x)
         else:
             x, h2 = h
-        return x + self.mlp(h2)
+        if fused.TRACE_SINK is None:
+            return x + self.mlp(h2)
+        fused.trace("04_x1", x)
+        fused.trace("05_ln2", h2)
+        m = fused.trace("06_fc1", self.mlp.fc1(h2))          # Mlp.forward, op by op
+        m = fused.trace("07_gelu", self.mlp.act(m))
+        m = fused.trace("08_fc2", self.mlp.fc2(m))
+        return fused.trace("09_out", x + m)
 
 
 class PatchEmbed(nn.Module):

@@ -9,6 +9,17 @@ from .. import hip as _hip
 
 _lib = None
 
+# diagnostics (tools/diag/transient_hunt.py --subops): while a stage graph is captured, the
+# EVA block records its intermediate tensors here (name -> tensor, kept alive so the graph
+# pool never reuses them); None in production
+TRACE_SINK = None
+
+
+def trace(name, t):
+    if TRACE_SINK is not None:
+        TRACE_SINK[name] = t
+    return t
+
 
 def _get():
     global _lib

@@ -695,6 +695,65 @@ def golden_global(registry):
     save("g12_global_pruners.npz", **out)
 
 
+def golden_clip():
+    """G15: CoOp's CLIP contrastive closure.  `forward_to_cache` is a function nested inside
+    `ZeroshotCLIP.build_model` (CoOp/trainers/zsclip.py:73-91) whose module imports Dassl (an
+    empty submodule upstream), so the module cannot be imported: the nested function's own AST
+    node is compiled from the file where it lies and run with the names it closes over
+    (`temp`, `classnames`, `clip.tokenize`, `torch`, `F`) supplied here.  Stored: inputs, the
+    id table the stand-in tokenizer produced, and the losses the reference function returned."""
+    import ast
+    import torch.nn.functional as F
+    from ecoflap_amd.shapes.clip_two_tower import ClipTwoTower, clip_batches
+    path = os.path.join(REF, "CoOp/trainers/zsclip.py")
+    tree = ast.parse(open(path).read())
+    node = next(n for n in ast.walk(tree)
+                if isinstance(n, ast.FunctionDef) and n.name == "forward_to_cache")
+    classnames = [f"class_{i}_thing" for i in range(10)]
+    temp = "a photo of a {}."
+    context, vocab = 6, 64
+
+    def tokenize(text):
+        # stand-in for CoOp's BPE (clip.tokenize returns [1, context] ids, end-of-text = highest id)
+        ids = [1 + (sum(ord(c) * (i + 1) for c in text[j::4]) % (vocab - 3)) for j, i in
+               zip(range(4), range(4))]
+        return torch.tensor([[0] + ids + [vocab - 1]][:1], dtype=torch.long)[:, :context]
+
+    ns = {"torch": torch, "F": F, "temp": temp, "classnames": classnames,
+          "clip": types.SimpleNamespace(tokenize=tokenize)}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    ref_closure = ns["forward_to_cache"]
+    torch.manual_seed(11)
+    model = ClipTwoTower(vocab=vocab, context=context).eval()
+    batches = clip_batches(12, 4, num_classes=len(classnames), seed=3)
+    table = torch.cat([tokenize(temp.format(c.replace("_", " "))) for c in classnames])
+    arrays = {"prompt_tokens": table.numpy()}
+    for k, v in model.state_dict().items():
+        arrays[f"init::{k}"] = bits(v)
+    with torch.no_grad():
+        for i, b in enumerate(batches):
+            loss, n = ref_closure(model, b, torch.device("cpu"))
+            arrays[f"img{i}"] = bits(b["img"])
+            arrays[f"label{i}"] = b["label"].numpy()
+            arrays[f"loss{i}"] = bits(loss.reshape(1))
+            arrays[f"len{i}"] = np.array([n])
+    # and through the reference's own stage 1: LayerSparsity with this closure as loss_func
+    sys.path.insert(0, os.path.join(REF, "UPop"))
+    from pruners.layer_single_base_pruner import LayerSparsity  # type: ignore
+    mapping = {k: k for k, v in model.named_parameters() if v.dim() == 2 and "visual" in k}
+    np.random.seed(5)
+    for p in model.parameters():
+        p.requires_grad = True
+    ls = LayerSparsity(model, batches, lambda m, b, dev: ref_closure(m, b, torch.device("cpu")),
+                       12, 0.5, 0.7, "MEZO-GradOnly_sum", 1, 1e-3, mapping)
+    table_out = ls.return_sparsity()
+    arrays["table_keys"] = np.array(sorted(table_out))
+    arrays["table_vals"] = np.array([table_out[k] for k in sorted(table_out)], dtype=np.float64)
+    for k, v in model.state_dict().items():
+        arrays[f"final::{k}"] = bits(v)
+    save("g15_clip_contrastive.npz", **arrays)
+
+
 def golden_names():
     d = torch.load(os.path.join(REF, "LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth"),
                    map_location="cpu", weights_only=False)
@@ -708,7 +767,9 @@ if __name__ == "__main__":
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
     only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global",
-                            "protected"]
+                            "protected", "clip"]
+    if "clip" in only:
+        golden_clip()
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:

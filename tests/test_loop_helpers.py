@@ -168,6 +168,17 @@ def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatc
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=OracleKernels(), z_source=torch_cpu_normal)
         sp = ls.return_sparsity()
+        # the forward patches are gone from the instances again (deepcopy / pickle see plain modules)
+        assert not any("forward" in m.__dict__ for m in model.modules())
+        if hooked:
+            # a batch object the cache has not seen (same id or not) is never served another
+            # batch's record: the cache holds the object it was filled from
+            assert all(loss._held[k] is b for k, b in ((id(b), b) for b in batches))
+            fresh = {k: v.clone() for k, v in batches[0].items()}
+            with torch.no_grad():
+                a = loss(model, fresh, False)[0]
+                b = loss_vision_language(model, batches[0], False)[0]
+            assert torch.equal(a, b)
         return ls.loss_table, sp, {k: v.clone() for k, v in model.state_dict().items()}, loss
 
     full = run(False)

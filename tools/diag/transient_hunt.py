@@ -118,7 +118,8 @@ class DoubleRun:
         bad = [(w, p) for w, p, f in zip(where, pairs, ne) if f]
         ev = {"layer": self.layer, "chunk": self.chunks, "n_bad_tensors": len(bad),
               "bad": [], "time": time.time()}
-        for (k, j, t), (x, y) in bad[:40]:
+        shown = [b for b in bad if not (isinstance(b[0][0], tuple) and b[0][0][0] == "sub")]
+        for (k, j, t), (x, y) in shown[:6]:
             d = (x != y)
             idx = d.nonzero()
             info = {"key": repr(k), "stage": None if j is None else plan[j][0], "tensor": t,
@@ -126,6 +127,8 @@ class DoubleRun:
             if idx.numel():
                 info["min_idx"] = idx.min(0).values.tolist()
                 info["max_idx"] = idx.max(0).values.tolist()
+                if x.dim() == 3:
+                    info["dim1_values"] = idx[:, 1].unique().tolist()[:80]
                 if x.dim() >= 2:
                     info["distinct_dim0"] = int(idx[:, 0].unique().numel())
                     info["distinct_dim1"] = int(idx[:, 1].unique().numel())
@@ -135,6 +138,20 @@ class DoubleRun:
                 info["max_abs_diff"] = float((xf - yf).abs().max())
                 info["first_vals"] = [xf[:4].tolist(), yf[:4].tolist()]
             ev["bad"].append(info)
+        # first differing intermediate inside an EVA block (checksums per row / per column)
+        subs = sorted([(k[2], k[3], k[4], k[1], x, y) for (k, j, t), (x, y) in bad
+                       if isinstance(k, tuple) and k[0] == "sub"], key=lambda r: (r[0], r[1], r[2]))
+        if subs:
+            j0, name0 = subs[0][0], subs[0][1]
+            first = {"stage": plan[j0][0], "op": name0, "group_first_slot": subs[0][3]}
+            for j_, n_, kind, _, x, y in subs:
+                if (j_, n_) != (j0, name0):
+                    continue
+                d = (x != y).nonzero().flatten().tolist()
+                first[kind] = _ranges(d)
+                first[kind + "_count"] = len(d)
+            first["ops_differing_in_that_stage"] = sorted({n_ for j_, n_, *_ in subs if j_ == j0})
+            ev["first_subop"] = first
         ev["losses_run1"] = [float(v) for a, b, _ in r1 for v in (a, b)]
         ev["losses_run2"] = [float(v) for a, b, _ in r2 for v in (a, b)]
         # the first differing group stage: replay it again from the recorded input
@@ -174,6 +191,17 @@ class DoubleRun:
         self.log.flush()
 
 
+def _ranges(ids):
+    """[3,4,5,9,10] -> [[3,5],[9,10]]"""
+    out = []
+    for v in ids:
+        if out and v == out[-1][1] + 1:
+            out[-1][1] = v
+        else:
+            out.append([v, v])
+    return out[:200]
+
+
 class _null:
     def __enter__(self):
         return self
@@ -202,6 +230,9 @@ def main():
     ap.add_argument("--eval-batch", type=int, default=16)
     ap.add_argument("--pad-slots", type=int, default=2)
     ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = all passes)")
+    ap.add_argument("--subops", action="store_true",
+                    help="also compare row / column checksums of every intermediate of the EVA "
+                         "blocks of the group chains (first differing op inside the block)")
     ap.add_argument("--out", default="gpurun_out/transient_hunt.jsonl")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
@@ -237,6 +268,7 @@ def main():
 
     inner = PrefixCachedLoss(model, use_graphs=True, n_lanes=args.lanes, eval_batch=args.eval_batch,
                              group_batch=args.group, pad_slots=args.pad_slots)
+    inner.trace_subops = bool(args.subops)
     loss = DoubleRun(inner, log)
     kern = hip.HipKernels()
     t0 = time.time()
