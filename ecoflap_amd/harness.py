@@ -58,6 +58,13 @@ def build_parser():
                         "torch: torch.manual_seed(seed) + torch.normal on the parameter's device, "
                         "the reference's own draw (layer_single_base_pruner.py:482-485) — the "
                         "parity mode: the table the reference's arithmetic gives on this GPU")
+    p.add_argument("--k1_form", default="block", choices=["block", "units", "triple", "single"],
+                   help="K1 launch form (bit-identical results): one launch per transformer block "
+                        "(default), per layer, per unit, or the reference's three in-place passes")
+    p.add_argument("--eval_batch", type=int, default=16,
+                   help="loss evaluations of a layer per pass of the batch-invariant suffix (1: one "
+                        "suffix per evaluation)")
+    p.add_argument("--lanes", type=int, default=2, help="concurrent evaluation lanes (weight replicas)")
     return p
 
 
@@ -141,7 +148,10 @@ def config_dict(args):
         "sparsity_dict": args.sparsity_dict,
         "prune_per_model": args.prune_per_model,
         "iteration": args.iteration,
-        "z_source": getattr(args, "z_source", "philox"),      # build-side extra (kw-only)
+        "z_source": getattr(args, "z_source", "philox"),      # build-side extras (kw-only)
+        "k1_form": getattr(args, "k1_form", "block"),
+        "eval_batch": getattr(args, "eval_batch", 16),
+        "n_lanes": getattr(args, "lanes", 2),
     }
     if str(args.pruning_method).startswith("blipt5_"):
         cfg.update(t5_prune_spec=args.t5_prune_spec, vit_prune_spec=args.vit_prune_spec,

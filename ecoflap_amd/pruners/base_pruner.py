@@ -62,7 +62,8 @@ class LayerWiseBasePruner(BasePruner):
                  max_sparsity_per_layer=0.8, score_method="GradMagSquare_avg",
                  num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
                  prune_per_model=False, kernels=None, z_source="philox", process_group=None,
-                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, **kwargs):
+                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, k1_form="block",
+                 **kwargs):
         super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
                          importance_scores_cache=importance_scores_cache,
                          keep_indices_or_masks_cache=keep_indices_or_masks_cache,
@@ -88,6 +89,7 @@ class LayerWiseBasePruner(BasePruner):
         self.use_graphs = use_graphs
         self.n_lanes = n_lanes
         self.eval_batch = eval_batch
+        self.k1_form = k1_form
         self.stage_stats = {}
 
     def model_setup_and_record_attributes(self, model):

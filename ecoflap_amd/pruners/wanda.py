@@ -570,7 +570,9 @@ class _StageOneMixin:
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,
             mapping, prune_per_model=self.prune_per_model, per_model_group=list(per_model_group),
-            kernels=self.kernels, z_source=self.z_source, process_group=self.process_group)
+            kernels=self.kernels, z_source=self.z_source, process_group=self.process_group,
+            k1_form=getattr(self, "k1_form", "block"),
+            grad_graphs=bool(getattr(self, "use_graphs", True)))
         self.kernels = ls.kernels
         out = ls.return_sparsity()
         self.stage_stats["stage1"] = dict(ls.stats)

@@ -1,0 +1,117 @@
+"""BASELINE.json's single-GPU configs at FULL size through the harness (`-m gpu`): every
+launch form of the loop gives the same sparsity table and the same pruned state_dict
+(sha256), and at true FlanT5-XL width the HIP library equals the oracle's arithmetic.
+(configs[0] is the CPU-runnable toy; configs[3] needs 8 GPUs.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_blip2_zeroth_order_full_size_all_loop_forms_agree():
+    """configs[2]: BLIP-2 (ViT-g fp16 + Q-Former + FlanT5-XL bf16), 588 matrices, 128 pairs bs 8,
+    MEZO-GradOnly_sum, block groups, max 0.6, + Wanda.  Production form (one K1 launch per block,
+    16 evaluations per pass, groups of 4 on two lanes) vs the plain form (one K1 launch per layer,
+    one suffix per evaluation): identical table and pruned weights."""
+    import run_config
+    a = run_config.run("3")
+    assert a["prunable_matrices"] == 588 and a["prunable_elements"] == 3701932032
+    assert a["table_entries"] == 588 and a["distinct_sparsities"] == 87
+    assert 0.49 < a["pruned_fraction"] < 0.51 and a["max_sparsity"] <= 0.6 + 1e-6
+    sf = a["stage_stats"]["stage1"]["suffix_forward"]
+    assert sf.get("batched_evals", 0) > 15000 and sf.get("grouped_evals", 0) > 3000
+    for key in ("batched_disabled_at", "grouping_disabled_at", "padding_disabled_at",
+                "advance_mismatch_at"):
+        assert sf.get(key) is None, (key, sf.get(key))
+    assert not sf.get("transient_mismatches")
+    torch.cuda.empty_cache()
+    b = run_config.run("3", ["--k1_form", "units", "--eval_batch", "1"])
+    assert b["stage_stats"]["stage1"]["suffix_forward"].get("batched_evals", 0) == 0
+    assert a["table_sha256"] == b["table_sha256"]
+    assert a["pruned_weights_sha256"] == b["pruned_weights_sha256"]
+
+
+def test_config2_flant5xl_first_order_full_size_graph_replay_equals_eager():
+    """configs[1]: FlanT5-XL shape, 432 matrices, GradMagAbs_sum, 128 sequences bs 1, + Wanda:
+    forward+backward replayed from one captured graph vs the eager loop."""
+    import run_config
+    a = run_config.run("2")
+    assert a["prunable_matrices"] == 432 and a["prunable_elements"] == 2717908992
+    assert a["table_entries"] == 432 and a["distinct_sparsities"] == 48
+    assert 0.49 < a["pruned_fraction"] < 0.51
+    torch.cuda.empty_cache()
+    import ecoflap_amd
+    real = ecoflap_amd.load_pruner
+    try:
+        ecoflap_amd.load_pruner = lambda name, model, loader, cfg_path=None, cfg=None: real(
+            name, model, loader, cfg=dict(cfg, use_graphs=False))
+        b = run_config.run("2")
+    finally:
+        ecoflap_amd.load_pruner = real
+    assert a["table_sha256"] == b["table_sha256"]
+    assert a["pruned_weights_sha256"] == b["pruned_weights_sha256"]
+
+
+def test_config2_true_width_slice_hip_equals_oracle():
+    """FlanT5-XL WIDTH (d_model 2048, d_ff 5120, 32 heads), 2 + 2 blocks, 8 sequences: first-order
+    scores, table and Wanda masks of the HIP library == the oracle's arithmetic on the same GPU
+    forward / backward."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleKernels
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.t5 import T5, t5_config
+    res = {}
+    for name, backend in (("hip", None), ("oracle", OracleKernels())):
+        torch.manual_seed(0)
+        with torch.device("cuda"):
+            model = T5(t5_config(num_layers=2), dtype=torch.bfloat16, init_std=0.02).eval()
+        batches = S.text_batches(8, 1, vocab=32128, seed=42, device="cuda")
+        np.random.seed(42)
+        cfg = dict(prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+                   max_sparsity_per_layer=0.6, score_method="GradMagAbs_sum", num_data_first_stage=8)
+        if backend is not None:
+            cfg["kernels"] = backend
+        pruner = load_pruner("t5_wanda_pruner", model, batches, cfg=cfg)
+        model, table = pruner.prune()
+        res[name] = (table, {k: v.cpu() for k, v in model.state_dict().items()},
+                     {k: float(v.sum()) for k, v in pruner.layer_sparsity_engine.importance_measure.items()})
+        del model, pruner
+        torch.cuda.empty_cache()
+    assert res["hip"][0] == res["oracle"][0] and len(res["hip"][0]) == 36
+    for k, v in res["hip"][2].items():
+        assert abs(v - res["oracle"][2][k]) <= 1e-5 * abs(v) + 1e-30, k
+    for k, v in res["hip"][1].items():
+        assert torch.equal(v, res["oracle"][1][k]), k
+
+
+def test_config5_blip_vqa_full_size_single_gpu():
+    """configs[4] on one GPU: BLIP-VQA base shape (ViT-B/16 @480 + question encoder + answer
+    decoder, 288 prunable matrices), intended-mode zeroth-order stage 1 on the task loss, Wanda
+    local prune, one masked fine-tune step (K8)."""
+    sys.path.insert(0, os.path.join(ROOT, "UPop"))
+    import hashlib
+    import _entry
+
+    def once(extra):
+        model, table = _entry.run("vqa", ["--stage1", "intended", "--num_data", "128"] + extra)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for k, v in sorted(model.state_dict().items()):
+            if v.dim() == 2:
+                h.update(v.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+        blocks = {k: v for k, v in model.state_dict().items()
+                  if v.dim() == 2 and (".blocks." in k or ".layer." in k)}
+        frac = sum(int((v == 0).sum()) for v in blocks.values()) / sum(v.numel() for v in blocks.values())
+        return table, h.hexdigest(), frac
+
+    t1, w1, frac = once(["--finetune_steps", "1"])
+    assert isinstance(t1, dict) and len(t1) == 288 and len(set(t1.values())) > 8
+    assert 0.47 < frac < 0.53 and max(t1.values()) <= 0.6 + 1e-6

@@ -41,9 +41,9 @@ CONFIGS = {
 }
 
 
-def main():
-    which = sys.argv[1]
-    extra = sys.argv[2:]
+def run(which, extra=()):
+    """-> summary dict of one config run through the harness (tests/test_full_configs.py)"""
+    extra = list(extra)
     t0 = time.time()
     model, table = harness.main(CONFIGS[which] + extra)
     torch.cuda.synchronize()
@@ -59,7 +59,7 @@ def main():
     weights_sha = hashlib.sha256()
     for k in sorted(blocks):
         weights_sha.update(blocks[k].detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
-    print(json.dumps({
+    return {
         "config": which, "wall_seconds": wall, "prunable_matrices": len(blocks),
         "prunable_elements": total, "pruned_fraction": zeros / total,
         "table_entries": len(table) if isinstance(table, dict) else 0,
@@ -67,7 +67,11 @@ def main():
         "distinct_sparsities": len(vals), "min_sparsity": vals[0] if vals else None,
         "max_sparsity": vals[-1] if vals else None,
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
-        "stage_stats": getattr(harness.main, "last_stage_stats", None)}, default=str))
+        "stage_stats": getattr(harness.main, "last_stage_stats", None)}
+
+
+def main():
+    print(json.dumps(run(sys.argv[1], sys.argv[2:]), default=str))
 
 
 if __name__ == "__main__":
