@@ -91,7 +91,7 @@ def launch(shape, flags):
     gpu = sys.argv[1] if len(sys.argv) > 1 else "0"
     port = sys.argv[2] if len(sys.argv) > 2 else "12341"
     extra = " ".join(sys.argv[3:])
-    program = (f"HIP_VISIBLE_DEVICES={gpu} {sys.executable} -m torch.distributed.run"
+    program = (f"HIP_VISIBLE_DEVICES={gpu} TENSILE_STREAMK_DATA_PARALLEL=1 {sys.executable} -m torch.distributed.run"
                f" --nproc_per_node=1 --master-addr 127.0.0.1 --master_port {port}"
                f" -m ecoflap_amd.harness --shape {shape} {flags} {extra}")
     print(program)

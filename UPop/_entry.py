@@ -3,6 +3,8 @@ section + masked fine-tune loop of UPop/ecoflap_compress_caption.py:225-249,
 ecoflap_compress_nlvr.py:233-257, ecoflap_compression_retrieval_flickr.py:351-375,
 ecoflap_compression_vqa.py:250-275 and :108-129, :312-315) on shape-compatible random-init
 models with synthetic task tuples.  Each entrypoint fixes (task, model shape, BERT prefix)."""
+import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
 import argparse
 import os
 import sys

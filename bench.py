@@ -26,6 +26,8 @@ own 128 calibration pairs (16 batches of 8); N ranks = 128*N pairs per matrix
 whole-job aggregate is N * K / seconds.  One process per GPU, RCCL only for the one
 all-reduce of the loss table.
 """
+import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
 import argparse
 import json
 import os

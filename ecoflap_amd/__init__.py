@@ -9,6 +9,10 @@ there is no CPU fallback.
 """
 import sys
 
+from . import blas_guard
+
+blas_guard.configure()      # before this process's first GEMM (see blas_guard.py)
+
 from .registry import registry  # noqa: F401
 from .pruners import (  # noqa: F401  (importing registers the pruners)
     BasePruner, BLIPT5LayerWandaPruner, LayerSparsity, T5LayerWandaPruner, VITLayerWandaPruner,

@@ -14,6 +14,8 @@ random-init module and the calibration loader is synthetic (`--shape`, `--toy`).
         --t5_prune_spec 24-0.5-1.0-1.0 --vit_prune_spec 39-0.5-1.0-1.0 --save_pruned_model \
         --job_id demo
 """
+import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
 import argparse
 import os
 import time

@@ -100,6 +100,9 @@ class LayerWiseBasePruner(BasePruner):
             requires_grad_record[n] = p.requires_grad
             p.requires_grad = True
         device = next(iter(model.parameters())).device
+        if device.type == "cuda":
+            from .. import blas_guard
+            blas_guard.verify(device)     # the GEMM library must be in its reproducible mode
         return dtype_record, requires_grad_record, device
 
     def model_reset(self, model, dtype_record, requires_grad_record, device):

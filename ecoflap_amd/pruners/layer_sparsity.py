@@ -693,6 +693,10 @@ class LayerSparsity:
         if mapping is None or len(mapping) == 0:
             return _UniformSparsity(original_sparsity)
 
+        dev0 = next(iter(self.model.parameters())).device
+        if dev0.type == "cuda":
+            from .. import blas_guard
+            blas_guard.verify(dev0)       # reproducible GEMMs (ecoflap_amd/blas_guard.py)
         if len(self.importance_measure) == 0:
             if self.score_compute.startswith("MEZO"):
                 self.importance_measure = self.compute_importance_scores_mezo(mapping)

@@ -1,4 +1,6 @@
 import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
+import os
 import sys
 
 import pytest

@@ -805,6 +805,43 @@ def test_stage1_torch_z_source_on_device(kern):
             assert torch.equal(v, want[2][k]), k
 
 
+def test_gemm_library_runs_in_its_reproducible_mode():
+    """Root cause of round 2's one-off loss mismatch (ecoflap_amd/blas_guard.py): hipBLASLt's
+    Stream-K kernel for the ViT-g fc1 GEMM is not reproducible call to call in its default mode.
+    With TENSILE_STREAMK_DATA_PARALLEL=1 (set at package import, checked live by `verify`):
+    120 000 calls of that GEMM on two concurrent streams, every one bit-identical to the first.
+    The default mode is then run in a child process for the record (its count is printed; it
+    reproduced the fault in every run so far: 8 / 120 000, 7 / 200 000, 1 / 60 000 on one stream)."""
+    import json
+    import subprocess
+    import sys
+    from ecoflap_amd import blas_guard
+    assert os.environ.get(blas_guard.ENV) == "1"
+    assert blas_guard.verify("cuda") is True
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "diag", "streamk_gemm_stress.py")
+
+    def stress(env, iters):
+        r = subprocess.run([sys.executable, script, "--iters", str(iters), "--streams", "2"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("STRESS ")][-1]
+        return json.loads(line[len("STRESS "):])
+
+    safe = stress(dict(os.environ, **{blas_guard.ENV: "1"}), 60000)
+    assert safe["bad_calls"] == [0, 0], safe
+    assert "SK3" in " ".join(safe["kernels"])          # the same Stream-K kernel, data-parallel
+    default_env = {k: v for k, v in os.environ.items() if k != blas_guard.ENV}
+    unsafe = stress(default_env, 120000)
+    print("default-mode Stream-K, differing calls per stream:", unsafe["bad_calls"],
+          "patterns:", json.dumps(unsafe["patterns"])[:600])
+    if sum(unsafe["bad_calls"]) == 0:
+        pytest.skip("the library's default mode showed no differing call in 240 000 on this box")
+    pat = unsafe["patterns"][0]
+    # the signature: 8-row slivers inside 256-row macro tiles
+    assert all((a % 8 == 0 and b - a == 7) for a, b in pat["rows"]), pat["rows"][:8]
+
+
 def test_harness_z_source_torch_hip_equals_oracle():
     """The entrypoint's parity mode (`--z_source torch`, what `LAVIS/scripts/blip2/
     ecoflap_zeroth.py 0 12341 --z_source torch` passes through): the harness run with the HIP

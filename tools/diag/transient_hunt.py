@@ -13,6 +13,8 @@ of `ECOFLAP_VERIFY_BATCHED=1 tools/run_config.py 3`.
 
     python3 tools/diag/transient_hunt.py --passes 10 --lanes 2 --group 4 [--layers 0-155]
 """
+import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
 import argparse
 import json
 import os

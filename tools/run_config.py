@@ -6,6 +6,8 @@ size, not bench lines.
     python3 tools/run_config.py 2     # FlanT5-XL first-order GradMagAbs_sum, 128 seqs bs 1
     python3 tools/run_config.py 3     # BLIP-2 zeroth-order MEZO-GradOnly_sum, 128 pairs bs 8
 """
+import os
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
 import json
 import os
 import sys
