@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_layers
 mkdir -p $OUT; rm -rf /tmp/prof_l
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l -- python3 $R/bench.py --no-cpu-baseline --warmup 2 --layers $1 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l -- python3 $R/bench.py --no-cpu-baseline --no-parity-leg --warmup 2 --layers $1 > $OUT/bench.json 2> $OUT/bench.err
 cp $(find /tmp/prof_l -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 tr=$(find /tmp/prof_l -name "*kernel_trace.csv" | head -1)
 python3 - "$tr" <<'PY'
