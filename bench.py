@@ -617,7 +617,13 @@ def main():
             "unit": "GB/s",
             "frac": k1["gbs"] / HBM_PEAK_GBS,
             "traffic": load_pmc_traffic(kind, k1["bytes_per_launch"]),
-            "traffic_source": "profiles/k1_pmc_traffic.json (rocprofv3 --pmc, separate passes)",
+            # NOT a reading of this run (PMC counters cannot be collected from inside the process):
+            # this run's algorithmic bytes x the traffic/algorithmic ratio the committed rocprofv3
+            # --pmc passes measured for the same kernel (FETCH_SIZE and WRITE_SIZE in separate
+            # passes, FETCH doubled for gfx950 as MI355X_MICROARCH.md prescribes)
+            "traffic_source": "derived: algorithmic bytes x the ratio in profiles/k1_pmc_traffic.json "
+                              "(rocprofv3 --pmc, separate passes, of the same kernel); not a "
+                              "counter reading of this run",
             "launches": k1["launches"],
             "avg_launch_us": k1["avg_us"],
             "layers_per_launch": kern.layers_per_launch if kind == "block" else None,

@@ -1,0 +1,203 @@
+// attention.hip — multi-head self-attention of the EVA ViT-g blocks for gfx950 (plumbing for the
+// build's shape modules, include/ecoflap_shape_ops.h; not part of the pruner ABI).
+//
+// The zeroth-order loop is forward-bound, and the library's fused attention runs the ViT-g shape
+// (257 tokens, 16 heads of 88) at 67 TFLOP/s: 0.7 ms per block at 16 concatenated evaluations, a
+// sixth of a ViT-g matrix's step.  This kernel serves exactly that shape family (N <= 288 tokens,
+// head width <= 96, fp16, no mask, no dropout):
+//
+//   * one workgroup (4 waves) per (image, head); the head's K [N, D] and V^T [D, N] live in LDS
+//     for the whole workgroup (K rows at a 16*odd-byte pitch, V^T rows likewise: every
+//     ds_read_b128 of 16 consecutive rows covers all 64 banks once);
+//   * a wave takes 32 queries at a time: S^T = K Q^T by v_mfma_f32_32x32x16_f16 (queries on the
+//     lanes, keys in the registers: a query's softmax is a per-lane loop plus one exchange with
+//     lane ^ 32), all N scores of the tile in registers, exact two-pass softmax in fp32;
+//   * O^T = V^T P^T takes the P tile straight from those registers as the B operand (the MFMA's k
+//     order inside a 16-key step is 8(j>>2) + 4h + (j&3): V^T is stored with its keys in that order,
+//     so the A operand is one ds_read_b128 too);
+//   * reads qkv as the qkv Linear wrote it ([B, N, 3, H, D]) and writes [B, N, H*D]: no permute /
+//     contiguous copies around it.
+// Per (image, head) independent: batch invariant by construction.
+#include "common.h"
+#include "../../include/ecoflap_shape_ops.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define AT_NT 9                 // tiles of 32 keys / queries (N <= 288)
+#define AT_ROWS (AT_NT * 32)
+#define AT_DC 6                 // 16-wide chunks of the head dimension (D <= 96)
+#define AT_DT 3                 // 32-wide tiles of the head dimension
+#define AT_KPITCH_MAX 208       // bytes per K row in LDS: 2*D rounded up to 16 * odd
+#define AT_VPITCH 592           // bytes per V^T row in LDS: 296 halves = 16 * 37
+
+struct AttnArgs {
+    const _Float16* qkv;        // [B, N, 3, H, D]
+    _Float16* out;              // [B, N, H * D]
+    int B, N, H, D;
+    int kpitch;                 // bytes
+    float scale_log2e;          // softmax scale * log2(e)
+};
+
+static __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[AT_ROWS * AT_KPITCH_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[AT_DT * 32 * AT_VPITCH];
+    const int N = a.N, D = a.D, H = a.H, kpitch = a.kpitch;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row_stride = (int64_t)3 * H * D;
+    const _Float16* base = a.qkv + (int64_t)b * N * row_stride + (int64_t)h * D;
+    const int nt = (N + 31) >> 5;
+    // ---- K and V^T of this head into LDS (padding rows / keys zero: 0 * garbage must stay 0) ----
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < AT_ROWS * AT_KPITCH_MAX / 16; i += 256) ((u32x4*)Ks)[i] = z;
+        for (int i = tid; i < AT_DT * 32 * AT_VPITCH / 16; i += 256) ((u32x4*)Vt)[i] = z;
+    }
+    __syncthreads();
+    {
+        const int vpr = D >> 3;
+        for (int v = tid; v < N * vpr; v += 256) {
+            const int key = v / vpr, c = v - key * vpr;
+            const _Float16* src = base + (int64_t)key * row_stride + 8 * c;
+            const u32x4 kv = *(const u32x4*)(src + (int64_t)H * D);
+            const u32x4 vv = *(const u32x4*)(src + (int64_t)2 * H * D);
+            *(u32x4*)(Ks + key * kpitch + 16 * c) = kv;
+            // key -> its place in the MFMA's k order inside its group of 16
+            const int k16 = key & 15;
+            const int pos = (key & ~15) + 8 * ((k16 >> 2) & 1) + (k16 & 3) + 4 * (k16 >> 3);
+            unsigned char* dst = Vt + (8 * c) * AT_VPITCH + 2 * pos;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *(uint16_t*)(dst + e * AT_VPITCH) = (uint16_t)(vv[e >> 1] >> (16 * (e & 1)));
+        }
+    }
+    __syncthreads();
+    const int r = lane & 31, hh = lane >> 5;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int qt = wave; qt < nt; qt += 4) {
+        const int q = 32 * qt + r;
+        const int qc = q < N ? q : N - 1;
+        // Q^T fragments (B operand: k = d on the half-lanes, column = query on the lanes)
+        f16x8 qf[AT_DC];
+#pragma unroll
+        for (int c = 0; c < AT_DC; ++c) {
+            const int d0 = 16 * c + 8 * hh;
+            qf[c] = d0 < D ? *(const f16x8*)(base + (int64_t)qc * row_stride + d0) : zero8;
+        }
+        // S^T = K Q^T: tile t holds keys 32t .. 32t+31 (rows, in the registers) x 32 queries (lanes)
+        f32x16 s[AT_NT];
+#pragma unroll
+        for (int t = 0; t < AT_NT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
+            if (t < nt) {
+#pragma unroll
+                for (int c = 0; c < AT_DC; ++c) {
+                    const int d0 = 16 * c + 8 * hh;
+                    const f16x8 kf = d0 < D ? *(const f16x8*)(Ks + (32 * t + r) * kpitch + 2 * d0) : zero8;
+                    s[t] = mfma16(kf, qf[c], s[t]);
+                }
+            }
+        }
+        // exact softmax over the keys of this lane's query: own registers, then lane ^ 32
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < AT_NT; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const float v = key < N ? s[t][i] : -__builtin_inff();
+                    s[t][i] = v;
+                    m = __builtin_fmaxf(m, v);
+                }
+            }
+        }
+        m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+        const float c2 = a.scale_log2e, mc = m * c2;
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < AT_NT; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(s[t][i] * c2 - mc);
+                    s[t][i] = p;
+                    l += p;
+                }
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        // O^T = V^T P^T: P tile t, k-step st = registers 8 st .. 8 st + 7 of s[t], as they stand
+        f32x16 o[AT_DT];
+#pragma unroll
+        for (int dt = 0; dt < AT_DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < AT_NT; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pk[j] = Vec<ECOFLAP_F16>::f2h_pk(s[t][8 * st + 2 * j], s[t][8 * st + 2 * j + 1]);
+                    const f16x8 pf = __builtin_bit_cast(f16x8, pk);
+#pragma unroll
+                    for (int dt = 0; dt < AT_DT; ++dt) {
+                        if (32 * dt < D) {
+                            const f16x8 vf = *(const f16x8*)(Vt + (32 * dt + r) * AT_VPITCH +
+                                                             2 * (32 * t + 16 * st + 8 * hh));
+                            o[dt] = mfma16(vf, pf, o[dt]);
+                        }
+                    }
+                }
+            }
+        }
+        if (q < N) {
+            const float inv = 1.0f / l;
+            _Float16* orow = a.out + ((int64_t)b * N + q) * H * D + (int64_t)h * D;
+#pragma unroll
+            for (int dt = 0; dt < AT_DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * dt + 8 * g + 4 * hh;
+                    if (d < D) {
+                        uint2 w2;
+                        w2.x = Vec<ECOFLAP_F16>::f2h_pk(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+                        w2.y = Vec<ECOFLAP_F16>::f2h_pk(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                        *(uint2*)(orow + d) = w2;
+                    }
+                }
+        }
+    }
+}
+
+extern "C" int ecoflap_vit_attention(const void* qkv, void* out, int64_t batch, int64_t tokens,
+                                     int64_t heads, int64_t head_dim, float scale, int dtype,
+                                     void* stream) {
+    if (dtype != ECOFLAP_F16) return ECOFLAP_EDTYPE;
+    if (batch <= 0 || tokens <= 0 || tokens > AT_ROWS || heads <= 0 || head_dim < 8 ||
+        head_dim > 16 * AT_DC || (head_dim % 8) != 0 || batch * heads > 0x7fffffffLL)
+        return ECOFLAP_ESIZE;
+    if (!qkv || !out) return ECOFLAP_ENULL;
+    if (!aligned16(qkv) || (((uintptr_t)out) & 7u)) return ECOFLAP_EALIGN;
+    AttnArgs a;
+    a.qkv = (const _Float16*)qkv;
+    a.out = (_Float16*)out;
+    a.B = (int)batch; a.N = (int)tokens; a.H = (int)heads; a.D = (int)head_dim;
+    int kp = 2 * (int)head_dim;                    // 16-byte vectors per row must be odd
+    if (((kp / 16) & 1) == 0) kp += 16;
+    a.kpitch = kp;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(vit_attention_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}

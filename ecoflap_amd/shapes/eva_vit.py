@@ -48,6 +48,10 @@ class Attention(nn.Module):
                     (self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(qkv.dtype)
         from . import fused
         fused.trace("01_qkv", qkv)
+        if rel_pos_bias is None:
+            x = fused.vit_attention(qkv, self.num_heads, self.scale)    # GPU, fp16, <= 288 tokens
+            if x is not None:
+                return self.proj(fused.trace("02_attn", x))
         qkv = qkv.reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         x = F.scaled_dot_product_attention(q, k, v, attn_mask=rel_pos_bias, scale=self.scale)

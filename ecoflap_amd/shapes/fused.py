@@ -30,6 +30,7 @@ def _get():
         lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
         lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
+        lib.ecoflap_vit_attention.argtypes = [vp, vp, i64, i64, i64, i64, f32, ci, vp]
         _lib = lib
     return _lib
 
@@ -115,3 +116,27 @@ def qkv_bias_add(qkv, q_bias, v_bias):
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_qkv_bias_add failed ({rc})")
     return qkv
+
+
+def vit_attention(qkv, heads, scale):
+    """softmax(q k^T * scale) v per (image, head) straight from the qkv Linear's output
+    ([B, N, 3 * heads * head_dim] = [B, N, 3, heads, head_dim]) into [B, N, heads * head_dim]:
+    one kernel instead of permute / contiguous copies + the library's fused attention (which runs
+    the ViT-g shape, 257 tokens x 16 heads of 88, at a few percent of the MFMA rate).
+    -> tensor or None (caller runs torch's scaled_dot_product_attention)."""
+    import os
+    if (torch.is_grad_enabled() or qkv.device.type != "cuda" or qkv.dtype != torch.float16
+            or qkv.dim() != 3 or not qkv.is_contiguous() or os.environ.get("ECOFLAP_NO_FUSED_ATTENTION")):
+        return None
+    B, N, C3 = qkv.shape
+    if C3 % (3 * heads) != 0:
+        return None
+    D = C3 // (3 * heads)
+    if N > 288 or D > 96 or D % 8 != 0 or D < 8:
+        return None
+    out = torch.empty((B, N, heads * D), dtype=qkv.dtype, device=qkv.device)
+    rc = _get().ecoflap_vit_attention(qkv.data_ptr(), out.data_ptr(), B, N, heads, D, float(scale),
+                                      _hip.DTYPE_CODE[qkv.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_vit_attention failed ({rc})")
+    return out

@@ -38,6 +38,14 @@ int ecoflap_add_layernorm(const void* x, const void* residual, const float* w, c
 int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias, int64_t rows,
                          int64_t dim, int dtype, void* stream);
 
+/* Multi-head self-attention of the EVA ViT blocks (LAVIS/lavis/models/eva_vit.py:119-141 without
+ * the relative position bias BLIP-2's tower does not use): out = softmax(q k^T * scale) v per
+ * (image, head).  qkv: [batch, tokens, 3, heads, head_dim] of F16 as the qkv Linear wrote it;
+ * out: [batch, tokens, heads * head_dim].  tokens <= 288, head_dim <= 96 and a multiple of 8.
+ * fp32 scores / softmax, probabilities rounded to f16 for the second product. */
+int ecoflap_vit_attention(const void* qkv, void* out, int64_t batch, int64_t tokens,
+                          int64_t heads, int64_t head_dim, float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

