@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--profile-host", default=None,
                     help="cProfile the timed region's host side into this file (diagnosis only: "
                          "the profiler slows the loop)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver's scaling run measures): every rank scores "
+                         "the matrices on its own --num-data pairs; strong: --num-data pairs in "
+                         "total, split over the ranks (a user with one calibration set and N GPUs)")
     ap.add_argument("--no-parity-leg", action="store_true",
                     help="skip the short z_source='torch' leg after the timed region")
     ap.add_argument("--no-k1-events", action="store_true",
@@ -393,6 +397,13 @@ def main():
     img = 28 if args.toy else 224
     vocab = 96 if args.toy else 32128
     # every rank its own shard of the global calibration set (global batch index = rank + N*j)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        if (args.num_data // args.batch_size) % world != 0:
+            print(f"bench.py: --scaling strong needs the {args.num_data // args.batch_size} batches "
+                  f"to divide over {world} ranks", file=sys.stderr)
+            sys.exit(2)
+        args.num_data //= world
     batches_local = S.image_text_batches(args.num_data, args.batch_size, img_size=img, vocab=vocab,
                                          in_len=16, out_len=16, seed=42 + rank, device=dev)
     nb_local = len(batches_local)
@@ -542,7 +553,9 @@ def main():
     kind = args.k1_form
     k1 = kern.summary(kind)
     drift = kern.summary("drift")
-    value = world * args.steps / elapsed
+    # weak: a matrix scored on 128 pairs per rank = one unit per rank; strong: the ranks share
+    # ONE calibration set, a matrix is scored once by all of them together
+    value = (1 if strong else world) * args.steps / elapsed
 
     out = {
         "metric": "layers scored/sec (zeroth-order, BLIP-2 @0.5)",
@@ -556,7 +569,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "bf16/fp16 weights (T5 bf16, ViT-g fp16), fp32 arithmetic per op",
         "data": "synthetic",
@@ -569,6 +582,7 @@ def main():
             "prunable_elements": numel_total,
             "layers_timed": layer_ids,
             "pairs_per_gpu": args.num_data,
+            "pairs_total": args.num_data * world,
             "batch_size": args.batch_size,
             "forwards_per_step": 2 * nb_local,
             "k1_form": args.k1_form,

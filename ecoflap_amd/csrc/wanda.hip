@@ -397,6 +397,8 @@ struct SqrtGroup {
     int64_t cols[WMAX];
     uint32_t* zero[WMAX];         // matrix mode: the item's selection state, cleared here (no memset launch)
     int zero_words;
+    uint32_t* zero2[WMAX];        // ... and the head of its bracket state
+    int zero2_words;
 };
 __global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
     const int it = group_item(g, blockIdx.x);
@@ -405,6 +407,8 @@ __global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
     if (c < g.cols[it]) g.dst[it][c] = __builtin_sqrtf(g.src[it][c]);
     if (g.zero[it])
         for (int i = lb * 256 + threadIdx.x; i < g.zero_words; i += nb * 256) g.zero[it][i] = 0u;
+    if (g.zero2[it])
+        for (int i = lb * 256 + threadIdx.x; i < g.zero2_words; i += nb * 256) g.zero2[it][i] = 0u;
 }
 
 template <int DT>
@@ -1373,6 +1377,367 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
     }
 }
 
+// =====================================================================================
+// K7 matrix mode, sampled bracket: 2 reads + 1 write of W instead of 4 + 1
+// =====================================================================================
+// The three histogram passes above read W three times to find ONE number.  Here a sample of
+// WS_SAMPLE_VECS vectors per matrix (pseudo-randomly placed, one per stride) brackets the (k+1)-th
+// smallest metric between two sample order statistics 5 sigma either side of its expected rank
+// (~4 % of the elements); ONE full pass counts exactly what lies below the bracket and histograms
+// what lies inside it (512 bins: an LDS atomic for 4 % of the elements instead of all of them);
+// the apply pass then knows the bin that holds the threshold, zeroes everything below that bin,
+// keeps everything above it and appends the bin's own few hundred elements (index, metric bits)
+// to a list; the last workgroup to finish selects the threshold among them exactly and settles
+// them.  Every count is exact, so the result is the reference's (W:555-558) bit for bit; when the
+// bracket misses (probability ~1e-6 per matrix), the bin is too crowded for the list (massive
+// ties) or the threshold is not finite, the pass flags the matrix WITHOUT having decided anything
+// wrongly (elements below the bin are pruned in the exact answer too) and the host runs the
+// three-histogram path on it.
+#define WS_SAMPLE_VECS 2048
+#define WS_BINS 512
+#define WS_CAP 8192
+
+struct BracketState {
+    // zeroed by the sqrt kernel
+    uint32_t count_below;
+    uint32_t list_count, ticket, fallback;
+    uint32_t hist[WS_BINS];
+    // written by the sample workgroup
+    uint32_t lo, hi, shift, valid;
+    uint32_t list_idx[WS_CAP];
+    uint32_t list_bits[WS_CAP];
+};
+#define WS_ZERO_WORDS (4 + WS_BINS)
+
+// rank (1-based) -> (bin, rank inside the bin) over an LDS histogram of 2048 bins, 256 threads
+static __device__ __forceinline__ void find_rank_256(const uint32_t* h, uint32_t rank, uint32_t* wave4,
+                                                     uint32_t* out2) {
+    uint32_t c[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c[i] = h[8 * threadIdx.x + i]; sum += c[i]; }
+    uint32_t total;
+    const uint32_t incl = block_scan_256(sum, wave4, total);
+    uint32_t run = incl - sum;
+    if (run < rank && rank <= incl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (run < rank && rank <= run + c[i]) { out2[0] = 8 * threadIdx.x + i; out2[1] = rank - run; }
+            run += c[i];
+        }
+    }
+    __syncthreads();
+}
+
+struct SampleGroup {
+    int n;
+    const void* w[WMAX];
+    const float* scaler_row[WMAX];     // the raw statistic: sqrt taken here (same value as the table)
+    int64_t rows[WMAX], cols[WMAX];
+    uint32_t rank0[WMAX];
+    BracketState* bs[WMAX];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void wanda_matrix_sample_kernel(const SampleGroup g) {
+    constexpr int N = Vec<DT>::N;
+    constexpr int S = WS_SAMPLE_VECS * N;
+    __shared__ uint32_t sb[WS_SAMPLE_VECS * 8];
+    __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
+    __shared__ uint32_t wave4[4], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
+    const int it = blockIdx.x;
+    const void* __restrict__ w = g.w[it];
+    const float* __restrict__ sr = g.scaler_row[it];
+    const int64_t cols = g.cols[it];
+    const int64_t vpr = cols / N, nvec = g.rows[it] * vpr;
+    const int64_t step = nvec / WS_SAMPLE_VECS;
+    for (int i = threadIdx.x; i < 2048; i += 256) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WS_SAMPLE_VECS; i += 256) {
+        const uint32_t jitter = (uint32_t)(((uint64_t)((uint32_t)i * 2654435761u) * (uint64_t)step) >> 32);
+        const int64_t v = (int64_t)i * step + jitter;
+        const int64_t c0 = (v % vpr) * N;
+        float f[N];
+        Vec<DT>::unpack(ld16(w, v), f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sr[c0 + e]));
+            sb[i * N + e] = b;
+            atomicAdd(&h1[b >> 21], 1u);
+        }
+    }
+    __syncthreads();
+    // sample ranks 5 sigma either side of the expected one
+    const double numel = (double)g.rows[it] * (double)cols;
+    const double p = (double)g.rank0[it] / numel;
+    const double mid = p * S;
+    const double dev = 5.0 * __builtin_sqrt((double)S * p * (1.0 - p)) + 8.0;
+    const bool open_lo = mid - dev < 1.0, open_hi = mid + dev > (double)S;
+    const uint32_t r_lo = open_lo ? 1u : (uint32_t)(mid - dev);
+    const uint32_t r_hi = open_hi ? (uint32_t)S : (uint32_t)(mid + dev);
+    find_rank_256(h1, r_lo, wave4, o_lo);
+    find_rank_256(h1, r_hi, wave4, o_hi);
+    const uint32_t b_lo = o_lo[0], b_hi = o_hi[0];
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const uint32_t b = sb[i];
+        if ((b >> 21) == b_lo) atomicAdd(&h2a[(b >> 10) & 2047u], 1u);
+        if ((b >> 21) == b_hi) atomicAdd(&h2b[(b >> 10) & 2047u], 1u);
+    }
+    __syncthreads();
+    find_rank_256(h2a, o_lo[1], wave4, s_lo);
+    find_rank_256(h2b, o_hi[1], wave4, s_hi);
+    if (threadIdx.x == 0) {
+        const uint32_t lo = open_lo ? 0u : ((b_lo << 21) | (s_lo[0] << 10));
+        const uint64_t hi64 = open_hi ? 0x100000000ull
+                                      : ((uint64_t)((b_hi << 21) | (s_hi[0] << 10)) + 1024ull);
+        const uint32_t hi = hi64 > 0xffffffffull ? 0xffffffffu : (uint32_t)hi64;
+        const uint32_t width = hi - lo;
+        int shift = 0;
+        while (shift < 31 && ((width - 1u) >> shift) >= (uint32_t)WS_BINS) ++shift;
+        BracketState* bs = g.bs[it];
+        bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift;
+        bs->valid = hi > lo ? 1u : 0u;
+    }
+}
+
+struct BracketGroup {
+    MatGroup m;
+    BracketState* bs[WMAX];
+};
+
+template <int DT>
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const BracketGroup bg) {
+    const MatGroup& g = bg.m;
+    const int it = group_item(g, blockIdx.x);
+    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    const void* __restrict__ w = g.w[it];
+    const float* sq = g.sq[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    BracketState* bs = bg.bs[it];
+    constexpr int N = Vec<DT>::N;
+    __shared__ uint32_t h[WS_BINS];
+    __shared__ uint32_t red[WM_WAVES];
+    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    if (!bs->valid) return;
+    const uint32_t lo = bs->lo, width = bs->hi - bs->lo, shift = bs->shift;
+    for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS) h[i] = 0;
+    sq = stage_sq(sq, cols, sq_lds);
+    __syncthreads();
+    uint32_t below = 0;
+    const int64_t vpr = cols / N;
+    const int64_t nvec = rows * vpr;
+    const int64_t stride = (int64_t)nb * WM_THREADS;
+    const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
+    uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
+    for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
+        u32x4 wv[WM_UNROLL];
+#pragma unroll
+        for (int j = 0; j < WM_UNROLL; ++j)
+            if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
+#pragma unroll
+        for (int j = 0; j < WM_UNROLL; ++j) {
+            const int64_t v = v0 + j * stride;
+            const int64_t c0 = (int64_t)cv * N;
+            cv += step32;
+            if (cv >= vpr32) cv -= vpr32;
+            if (v >= nvec) continue;
+            float f[N];
+            Vec<DT>::unpack(wv[j], f);
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+                    const uint32_t rel = b - lo;
+                    below += b < lo ? 1u : 0u;
+                    if (b >= lo && rel < width) atomicAdd(&h[rel >> shift], 1u);
+                }
+            }
+        }
+    }
+    // count below the bracket: wave sum, then one atomic per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = below;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < WM_WAVES; ++k) t += red[k];
+        if (t) atomicAdd(&bs->count_below, t);
+    }
+    for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS)
+        if (h[i]) atomicAdd(&bs->hist[i], h[i]);
+}
+
+template <int DT>
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const BracketGroup bg) {
+    const MatGroup& g = bg.m;
+    const int it = group_item(g, blockIdx.x);
+    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    void* w = g.w[it];
+    const float* sq = g.sq[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    const uint32_t rank0 = g.rank0[it];
+    BracketState* bs = bg.bs[it];
+    uint8_t* mask_out = g.mask[it];
+    constexpr int N = Vec<DT>::N;
+    __shared__ uint32_t wave4[WM_WAVES];
+    __shared__ uint32_t out2[2];
+    __shared__ uint32_t is_last;
+    __shared__ uint32_t arr[WS_CAP];
+    __shared__ uint32_t hsel[2048];
+    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    if (!bs->valid) {
+        if (lb == 0 && threadIdx.x == 0) bs->fallback = 1u;
+        return;
+    }
+    const uint32_t lo = bs->lo, hi = bs->hi, shift = bs->shift;
+    const uint32_t below = bs->count_below;
+    const uint32_t c = threadIdx.x < WS_BINS ? bs->hist[threadIdx.x] : 0u;
+    sq = stage_sq(sq, cols, sq_lds);
+    uint32_t total;
+    const uint32_t incl = block_scan_wm(c, wave4, total);
+    const bool miss = rank0 <= below || rank0 - below > total;
+    const uint32_t r = rank0 - below;
+    if (threadIdx.x == 0) { out2[0] = 0xffffffffu; out2[1] = 0; }
+    __syncthreads();
+    if (!miss && incl - c < r && r <= incl) { out2[0] = threadIdx.x; out2[1] = r - (incl - c); }
+    __syncthreads();
+    const uint32_t bin = out2[0], rr = out2[1];
+    uint64_t binhi64 = (uint64_t)lo + ((uint64_t)(bin + 1u) << shift);
+    if (binhi64 > (uint64_t)hi) binhi64 = hi;
+    // (a bin reaching into Inf / NaN bit patterns: `metric <= thres` is not an order on bits there)
+    if (miss || bin == 0xffffffffu || binhi64 > 0x7f800000ull) {
+        if (lb == 0 && threadIdx.x == 0) bs->fallback = 1u;
+        return;
+    }
+    const uint32_t binlo = lo + (bin << shift), binw = (uint32_t)binhi64 - binlo;
+    {
+        const int64_t vpr = cols / N;
+        const int64_t nvec = rows * vpr;
+        const int64_t stride = (int64_t)nb * WM_THREADS;
+        const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
+        uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
+        for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
+            u32x4 wv[WM_UNROLL];
+#pragma unroll
+            for (int j = 0; j < WM_UNROLL; ++j)
+                if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
+#pragma unroll
+            for (int j = 0; j < WM_UNROLL; ++j) {
+                const int64_t v = v0 + j * stride;
+                const int64_t c0 = (int64_t)cv * N;
+                cv += step32;
+                if (cv >= vpr32) cv -= vpr32;
+                if (v >= nvec) continue;
+                float f[N];
+                uint32_t bits[N];
+                Vec<DT>::unpack(wv[j], f);
+                uint32_t lo4 = 0, hi4 = 0, und = 0, pr = 0;
+#pragma unroll
+                for (int q = 0; q < N / 4; ++q) {
+                    const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * q + i;
+                        const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __uint_as_float(s4[i]));
+                        bits[e] = b;
+                        const bool prune = b < binlo;
+                        const bool open = b >= binlo && (b - binlo) < binw;
+                        pr |= (prune ? 1u : 0u) << e;
+                        und |= (open ? 1u : 0u) << e;
+                        if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
+                        else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
+                    }
+                }
+                if (!und) {
+                    if (pr) {
+#pragma unroll
+                        for (int e = 0; e < N; ++e) if ((pr >> e) & 1u) f[e] = 0.0f;
+                        st16(w, v, Vec<DT>::pack(f));
+                    }
+                    if (mask_out) {
+                        uint8_t* m = mask_out + v * N;
+                        *(uint32_t*)m = lo4;
+                        if (N == 8) *(uint32_t*)(m + 4) = hi4;
+                    }
+                } else {
+                    // a vector with an element of the threshold's bin: element stores only, and
+                    // never the open element's own bytes (the last workgroup may write them)
+#pragma unroll
+                    for (int e = 0; e < N; ++e) {
+                        const int64_t idx = v * N + e;
+                        if ((und >> e) & 1u) {
+                            const uint32_t slot = atomicAdd(&bs->list_count, 1u);
+                            if (slot < (uint32_t)WS_CAP) {
+                                __hip_atomic_store(&bs->list_idx[slot], (uint32_t)idx, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&bs->list_bits[slot], bits[e], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        } else {
+                            const bool prune = (pr >> e) & 1u;
+                            if (prune) Vec<DT>::store1(w, idx, 0.0f);
+                            if (mask_out) mask_out[idx] = prune ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- the last workgroup of this matrix settles the threshold's bin ----------------------
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = (__hip_atomic_fetch_add(&bs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   == nb - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    const uint32_t n = __hip_atomic_load(&bs->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n > (uint32_t)WS_CAP || n < rr) {          // too crowded (ties): the host finishes this matrix
+        if (threadIdx.x == 0) bs->fallback = 2u;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS)
+        arr[i] = __hip_atomic_load(&bs->list_bits[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // rr-th smallest of arr[0..n): radix select, 11 + 11 + 10 bits
+    uint32_t prefix = 0, remaining = rr;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+        const uint32_t himask = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
+        const uint32_t dmask = pass == 2 ? 1023u : 2047u;
+        for (int i = threadIdx.x; i < 2048; i += WM_THREADS) hsel[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS) {
+            const uint32_t b = arr[i];
+            if ((b & himask) == prefix) atomicAdd(&hsel[(b >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        const uint32_t c0 = hsel[2 * threadIdx.x], c1 = hsel[2 * threadIdx.x + 1];
+        uint32_t tot;
+        const uint32_t inc = block_scan_wm(c0 + c1, wave4, tot);
+        const uint32_t exc = inc - (c0 + c1);
+        if (exc < remaining && remaining <= inc) {
+            const bool second = remaining > exc + c0;
+            out2[0] = 2 * threadIdx.x + (second ? 1u : 0u);
+            out2[1] = remaining - exc - (second ? c0 : 0u);
+        }
+        __syncthreads();
+        prefix |= out2[0] << sh;
+        remaining = out2[1];
+        __syncthreads();
+    }
+    const uint32_t thres = prefix;           // bits of sorted[k]
+    for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS) {
+        const uint32_t idx = __hip_atomic_load(&bs->list_idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool prune = arr[i] <= thres;
+        if (prune) Vec<DT>::store1(w, (int64_t)idx, 0.0f);
+        if (mask_out) mask_out[idx] = prune ? 1 : 0;
+    }
+}
+
 static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
 
 extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
@@ -1386,7 +1751,8 @@ extern "C" size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* 
     size_t total = 0;
     if (!items) return 0;
     for (int i = 0; i < n_items; ++i)
-        if (items[i].cols > 0) total += sq_bytes(items[i].cols) + sizeof(MatrixSelState);
+        if (items[i].cols > 0)
+            total += sq_bytes(items[i].cols) + sizeof(MatrixSelState) + sizeof(BracketState);
     return total;
 }
 
@@ -1440,14 +1806,18 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         st[i] = (MatrixSelState*)p;      // cleared by the sqrt kernel below (matrix-mode items)
         p += sizeof(MatrixSelState);
     }
+    BracketState* bst[WMAX];
+    for (int i = 0; i < n_items; ++i) { bst[i] = (BracketState*)p; p += sizeof(BracketState); }
     {
         SqrtGroup g;
         g.n = n_items;
         g.zero_words = (int)(sizeof(MatrixSelState) / sizeof(uint32_t));
+        g.zero2_words = WS_ZERO_WORDS;
         g.start[0] = 0;
         for (int i = 0; i < n_items; ++i) {
             g.src[i] = items[i].scaler_row; g.dst[i] = sq[i]; g.cols[i] = items[i].cols;
             g.zero[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)st[i] : nullptr;
+            g.zero2[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)bst[i] : nullptr;
             g.start[i + 1] = g.start[i] + (int32_t)((items[i].cols + 255) / 256);
         }
         hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)g.start[n_items]), dim3(256), 0, s, g);
@@ -1570,23 +1940,84 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             g.start[q + 1] = g.start[q] + (int32_t)nb;
         }
         const dim3 grid((unsigned)g.start[g.n]), blk(WM_THREADS);
-#define MATRIX_GO(DT_)                                                                              \
+#define MATRIX_LEGACY(DT_, G_, GRID_)                                                               \
     do {                                                                                            \
         if (vec) {                                                                                  \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, true, WM_SUB0>), grid, blk, 0, s, g); \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, true>), grid, blk, 0, s, g);       \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, true>), grid, blk, 0, s, g);       \
-            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, true>), grid, blk, 0, s, g);         \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, true, WM_SUB0>), GRID_, blk, 0, s, G_); \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, true>), GRID_, blk, 0, s, G_);     \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, true>), GRID_, blk, 0, s, G_);     \
+            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, true>), GRID_, blk, 0, s, G_);       \
         } else {                                                                                    \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, false>), grid, blk, 0, s, g);      \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, false>), grid, blk, 0, s, g);      \
-            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, false>), grid, blk, 0, s, g);      \
-            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, false>), grid, blk, 0, s, g);        \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 0, false>), GRID_, blk, 0, s, G_);    \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 1, false>), GRID_, blk, 0, s, G_);    \
+            hipLaunchKernelGGL((wanda_matrix_hist_kernel<DT_, 2, false>), GRID_, blk, 0, s, G_);    \
+            hipLaunchKernelGGL((wanda_matrix_apply_kernel<DT_, false>), GRID_, blk, 0, s, G_);      \
         }                                                                                           \
+    } while (0)
+        // sampled bracket (2 reads + 1 write) when every matrix of the group is big enough to
+        // sample one vector per stride; otherwise / on a flagged matrix the three histograms
+        static const bool force_legacy = getenv("ECOFLAP_WANDA_LEGACY") != nullptr;
+        bool sampled = vec && !force_legacy;
+        for (int q = 0; q < g.n && sampled; ++q) {
+            const int64_t nv = g.rows[q] * g.cols[q] / (a.dtype == ECOFLAP_F32 ? 4 : 8);
+            if (nv < 8 * WS_SAMPLE_VECS || g.cols[q] > WM_SQ_LDS) sampled = false;
+        }
+        if (!sampled) {
+#define MATRIX_GO(DT_) MATRIX_LEGACY(DT_, g, grid)
+            DT_SWITCH(a.dtype, MATRIX_GO);
+#undef MATRIX_GO
+            ECO_CHECK_LAUNCH();
+            continue;
+        }
+        SampleGroup sg;
+        BracketGroup bg;
+        bg.m = g;
+        sg.n = g.n;
+        for (int q = 0; q < g.n; ++q) {
+            const ecoflap_wanda_item& b = items[members[q]];
+            sg.w[q] = b.w; sg.scaler_row[q] = b.scaler_row; sg.rows[q] = b.rows; sg.cols[q] = b.cols;
+            sg.rank0[q] = g.rank0[q]; sg.bs[q] = bst[members[q]]; bg.bs[q] = bst[members[q]];
+        }
+#define MATRIX_GO(DT_)                                                                              \
+    do {                                                                                            \
+        hipLaunchKernelGGL((wanda_matrix_sample_kernel<DT_>), dim3((unsigned)g.n), dim3(256), 0, s, sg); \
+        hipLaunchKernelGGL((wanda_matrix_bracket_kernel<DT_>), grid, blk, 0, s, bg);                \
+        hipLaunchKernelGGL((wanda_matrix_apply2_kernel<DT_>), grid, blk, 0, s, bg);                 \
     } while (0)
         DT_SWITCH(a.dtype, MATRIX_GO);
 #undef MATRIX_GO
         ECO_CHECK_LAUNCH();
+        // every count above is exact; a matrix the pass could not settle (bracket miss, a crowded
+        // threshold bin, a non-finite threshold) carries a flag and nothing wrongly decided: the
+        // three-histogram path finishes it.  One stream sync per block call.
+        uint32_t flags[WMAX];
+        for (int q = 0; q < g.n; ++q) {
+            hipError_t e = hipMemcpyAsync(&flags[q], &bst[members[q]]->fallback, sizeof(uint32_t),
+                                          hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        {
+            hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return (int)e;
+        }
+        MatGroup lg;
+        lg.n = 0;
+        lg.start[0] = 0;
+        for (int q = 0; q < g.n; ++q) {
+            if (!flags[q]) continue;
+            const int z = lg.n++;
+            lg.w[z] = g.w[q]; lg.sq[z] = g.sq[q]; lg.rows[z] = g.rows[q]; lg.cols[z] = g.cols[q];
+            lg.rank0[z] = g.rank0[q]; lg.st[z] = g.st[q]; lg.mask[z] = g.mask[q];
+            lg.start[z + 1] = lg.start[z] + (g.start[q + 1] - g.start[q]);
+        }
+        if (lg.n) {
+            const dim3 lgrid((unsigned)lg.start[lg.n]);
+#define MATRIX_GO(DT_) MATRIX_LEGACY(DT_, lg, lgrid)
+            DT_SWITCH(a.dtype, MATRIX_GO);
+#undef MATRIX_GO
+            ECO_CHECK_LAUNCH();
+        }
+#undef MATRIX_LEGACY
     }
     return 0;
 }

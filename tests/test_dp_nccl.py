@@ -140,3 +140,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu_over_gloo():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] is None
     assert line["process_group"] == {"backend": "gloo", "world_size": 2, "all_reduce_of_ones": 2}
+    assert line["scaling"] == "weak" and line["config"]["pairs_total"] == 2 * line["config"]["pairs_per_gpu"]
+    # strong scaling: ONE calibration set split over the ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--toy",
+                        "--steps", "4", "--warmup", "1", "--same-device", "--dist-backend", "gloo",
+                        "--no-cpu-baseline", "--scaling", "strong"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    strong = json.loads(r.stdout.strip().splitlines()[-1])
+    assert strong["scaling"] == "strong"
+    assert strong["config"]["pairs_total"] == line["config"]["pairs_per_gpu"]
+    assert strong["config"]["pairs_per_gpu"] * 2 == strong["config"]["pairs_total"]

@@ -51,6 +51,25 @@ def main():
         s = torch.zeros(cols, device="cuda")
         med, mn = timed(lambda i: kern.colsqnorm_accum(s, xs[i], 8 * i, 8), sets)
         res.append(("K6 colsqnorm", name, nbytes, med, mn))
+    # K6, ONE launch for all hooked inputs of a transformer block (one calibration batch, bs 8)
+    for name, dt, shapes in [("vit-g block: 4 inputs", torch.float16,
+                              [(8 * 257, 1408)] * 3 + [(8 * 257, 6144)]),
+                             ("t5 enc block: 7 inputs", torch.bfloat16,
+                              [(8 * 48, 2048)] * 6 + [(8 * 48, 5120)]),
+                             ("t5 dec block: 11 inputs", torch.bfloat16,
+                              [(8 * 16, 2048)] * 4 + [(8 * 16, 2048)] + [(8 * 48, 2048)] * 2
+                              + [(8 * 16, 2048)] * 3 + [(8 * 16, 5120)])]:
+        if not want("k6"):
+            break
+        nbytes = sum(t * c * 2 for t, c in shapes)
+        sets = max(2, int(6e8 // nbytes))
+        xs = [[torch.randn(t, c, device="cuda").to(dt) for t, c in shapes] for _ in range(sets)]
+        rows_ = [torch.zeros(c, device="cuda") for _, c in shapes]
+        fn = lambda i: kern.colsqnorm_accum_multi(                               # noqa: E731
+            [(r, x, 8 * i, None, 8, False) for r, x in zip(rows_, xs[i])])
+        med, mn = timed(fn, sets)
+        res.append(("K6 multi", name, nbytes, med, mn))
+        del xs
     # K7 rows: T5 matrices (bf16); matrix mode: ViT matrices (fp16)
     for name, rows, cols, dt, mode in [("t5 wo 2048x5120", 2048, 5120, torch.bfloat16, "rows"),
                                        ("t5 wi 5120x2048", 5120, 2048, torch.bfloat16, "rows"),
