@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define AT_DT 3                 // 32-wide tiles of the head dimension
 #define AT_KPITCH_MAX 208       // bytes per K row in LDS: 2*D rounded up to 16 * odd
 #define AT_VPITCH 592           // bytes per V^T row in LDS: 296 halves = 16 * 37
+#define AT_FILL 6               // 16-byte vectors of K and of V per thread and fill round
 
 struct AttnArgs {
     const _Float16* qkv;        // [B, N, 3, H, D]
@@ -59,35 +60,66 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
         for (int i = tid; i < AT_DT * 32 * AT_VPITCH / 16; i += 256) ((u32x4*)Vt)[i] = z;
     }
     __syncthreads();
-    {
-        const int vpr = D >> 3;
-        for (int v = tid; v < N * vpr; v += 256) {
-            const int key = v / vpr, c = v - key * vpr;
-            const _Float16* src = base + (int64_t)key * row_stride + 8 * c;
-            const u32x4 kv = *(const u32x4*)(src + (int64_t)H * D);
-            const u32x4 vv = *(const u32x4*)(src + (int64_t)2 * H * D);
-            *(u32x4*)(Ks + key * kpitch + 16 * c) = kv;
-            // key -> its place in the MFMA's k order inside its group of 16
-            const int k16 = key & 15;
-            const int pos = (key & ~15) + 8 * ((k16 >> 2) & 1) + (k16 & 3) + 4 * (k16 >> 3);
-            unsigned char* dst = Vt + (8 * c) * AT_VPITCH + 2 * pos;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *(uint16_t*)(dst + e * AT_VPITCH) = (uint16_t)(vv[e >> 1] >> (16 * (e & 1)));
-        }
-    }
-    __syncthreads();
     const int r = lane & 31, hh = lane >> 5;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int qt = wave; qt < nt; qt += 4) {
-        const int q = 32 * qt + r;
-        const int qc = q < N ? q : N - 1;
-        // Q^T fragments (B operand: k = d on the half-lanes, column = query on the lanes)
-        f16x8 qf[AT_DC];
+    // the first tile's Q^T fragments are requested before the fill (their latency hides under it)
+    f16x8 qf[AT_DC];
+    {
+        const int q0 = 32 * wave + r;
+        const int qc0 = q0 < N ? q0 : N - 1;
 #pragma unroll
         for (int c = 0; c < AT_DC; ++c) {
             const int d0 = 16 * c + 8 * hh;
-            qf[c] = d0 < D ? *(const f16x8*)(base + (int64_t)qc * row_stride + d0) : zero8;
+            qf[c] = (d0 < D && wave < nt) ? *(const f16x8*)(base + (int64_t)qc0 * row_stride + d0) : zero8;
+        }
+    }
+    {
+        // all of a round's global loads are in flight before the first LDS write (one memory
+        // latency per round of AT_FILL vectors per thread instead of one per vector)
+        const int vpr = D >> 3;
+        const int total = N * vpr;
+        for (int v0 = tid; v0 < total; v0 += 256 * AT_FILL) {
+            u32x4 kv[AT_FILL], vv[AT_FILL];
+            int keys[AT_FILL], cs[AT_FILL];
+#pragma unroll
+            for (int j = 0; j < AT_FILL; ++j) {
+                const int v = v0 + 256 * j;
+                const int vv_ = v < total ? v : total - 1;
+                keys[j] = vv_ / vpr;
+                cs[j] = vv_ - keys[j] * vpr;
+                const _Float16* src = base + (int64_t)keys[j] * row_stride + 8 * cs[j];
+                kv[j] = *(const u32x4*)(src + (int64_t)H * D);
+                vv[j] = *(const u32x4*)(src + (int64_t)2 * H * D);
+            }
+#pragma unroll
+            for (int j = 0; j < AT_FILL; ++j) {
+                if (v0 + 256 * j >= total) continue;
+                const int key = keys[j], c = cs[j];
+                *(u32x4*)(Ks + key * kpitch + 16 * c) = kv[j];
+                // key -> its place in the MFMA's k order inside its group of 16
+                const int k16 = key & 15;
+                const int pos = (key & ~15) + 8 * ((k16 >> 2) & 1) + (k16 & 3) + 4 * (k16 >> 3);
+                unsigned char* dst = Vt + (8 * c) * AT_VPITCH + 2 * pos;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *(uint16_t*)(dst + e * AT_VPITCH) = (uint16_t)(vv[j][e >> 1] >> (16 * (e & 1)));
+            }
+        }
+    }
+    __syncthreads();
+    for (int qt = wave; qt < nt; qt += 4) {
+        const int q = 32 * qt + r;
+        // Q^T fragments (B operand: k = d on the half-lanes, column = query on the lanes) of the
+        // NEXT tile of this wave, requested now, used after this tile's products
+        f16x8 qn[AT_DC];
+        {
+            const int qx = 32 * (qt + 4) + r;
+            const int qcx = qx < N ? qx : N - 1;
+#pragma unroll
+            for (int c = 0; c < AT_DC; ++c) {
+                const int d0 = 16 * c + 8 * hh;
+                qn[c] = (d0 < D && qt + 4 < nt) ? *(const f16x8*)(base + (int64_t)qcx * row_stride + d0) : zero8;
+            }
         }
         // S^T = K Q^T: tile t holds keys 32t .. 32t+31 (rows, in the registers) x 32 queries (lanes)
         f32x16 s[AT_NT];
@@ -176,6 +208,8 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                     }
                 }
         }
+#pragma unroll
+        for (int c = 0; c < AT_DC; ++c) qf[c] = qn[c];
     }
 }
 

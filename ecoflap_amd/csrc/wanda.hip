@@ -1743,8 +1743,8 @@ static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(flo
 extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
     (void)rows;
     if (cols <= 0) return 0;
-    // sqrt table (padded to 256 B) + matrix-mode selection state
-    return sq_bytes(cols) + sizeof(MatrixSelState);
+    // sqrt table (padded to 256 B) + matrix-mode selection states
+    return sq_bytes(cols) + sizeof(MatrixSelState) + sizeof(BracketState);
 }
 
 extern "C" size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* items, int n_items) {
