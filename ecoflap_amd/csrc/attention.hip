@@ -121,33 +121,47 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                 qn[c] = (d0 < D && qt + 4 < nt) ? *(const f16x8*)(base + (int64_t)qcx * row_stride + d0) : zero8;
             }
         }
-        // S^T = K Q^T: tile t holds keys 32t .. 32t+31 (rows, in the registers) x 32 queries (lanes)
+        // S^T = K Q^T: tile t holds keys 32t .. 32t+31 (rows, in the registers) x 32 queries (lanes).
+        // d-chunk outermost: nine INDEPENDENT accumulators per step (no MFMA waits for the one
+        // before it) and the next chunk's nine K fragments are in flight while this chunk's
+        // products issue (one wave per SIMD: nobody else hides the LDS latency).  All AT_NT tiles
+        // are computed whatever N is (K rows past N are zero; those keys are masked below).
         f32x16 s[AT_NT];
 #pragma unroll
-        for (int t = 0; t < AT_NT; ++t) {
+        for (int t = 0; t < AT_NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
-            if (t < nt) {
+        {
+            const unsigned char* krow = Ks + r * kpitch + 16 * hh;
+            f16x8 kf[2][AT_NT];
 #pragma unroll
-                for (int c = 0; c < AT_DC; ++c) {
-                    const int d0 = 16 * c + 8 * hh;
-                    const f16x8 kf = d0 < D ? *(const f16x8*)(Ks + (32 * t + r) * kpitch + 2 * d0) : zero8;
-                    s[t] = mfma16(kf, qf[c], s[t]);
+            for (int t = 0; t < AT_NT; ++t) kf[0][t] = *(const f16x8*)(krow + 32 * t * kpitch);
+#pragma unroll
+            for (int c = 0; c < AT_DC; ++c) {
+                if (c + 1 < AT_DC) {
+#pragma unroll
+                    for (int t = 0; t < AT_NT; ++t)
+                        kf[(c + 1) & 1][t] = *(const f16x8*)(krow + 32 * t * kpitch + 32 * (c + 1));
                 }
+                const bool live = 16 * c + 8 * hh < D;      // (a row's last chunk may be half padding)
+#pragma unroll
+                for (int t = 0; t < AT_NT; ++t)
+                    s[t] = mfma16(live ? kf[c & 1][t] : zero8, qf[c], s[t]);
+                // (keep the scheduler from hoisting every later chunk's loads up here: 54 fragments
+                // in flight at once spill)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // exact softmax over the keys of this lane's query: own registers, then lane ^ 32
         float m = -__builtin_inff();
 #pragma unroll
         for (int t = 0; t < AT_NT; ++t) {
-            if (t < nt) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    const float v = key < N ? s[t][i] : -__builtin_inff();
-                    s[t][i] = v;
-                    m = __builtin_fmaxf(m, v);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const float v = key < N ? s[t][i] : -__builtin_inff();
+                s[t][i] = v;
+                m = __builtin_fmaxf(m, v);
             }
         }
         m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
@@ -155,13 +169,11 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
         float l = 0.f;
 #pragma unroll
         for (int t = 0; t < AT_NT; ++t) {
-            if (t < nt) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(s[t][i] * c2 - mc);
-                    s[t][i] = p;
-                    l += p;
-                }
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(s[t][i] * c2 - mc);
+                s[t][i] = p;
+                l += p;
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -171,25 +183,29 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
         for (int dt = 0; dt < AT_DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+        {
+            // three independent accumulators per step; the next step's three V^T fragments are in
+            // flight while this step's products issue (V^T rows past D and keys past N are zero)
+            const unsigned char* vrow = Vt + r * AT_VPITCH + 16 * hh;
+            f16x8 vf[2][AT_DT];
 #pragma unroll
-        for (int t = 0; t < AT_NT; ++t) {
-            if (t < nt) {
+            for (int dt = 0; dt < AT_DT; ++dt) vf[0][dt] = *(const f16x8*)(vrow + 32 * dt * AT_VPITCH);
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    u32x4 pk;
+            for (int ks = 0; ks < 2 * AT_NT; ++ks) {          // ks = 2 t + st: 16 keys per step
+                if (ks + 1 < 2 * AT_NT) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        pk[j] = Vec<ECOFLAP_F16>::f2h_pk(s[t][8 * st + 2 * j], s[t][8 * st + 2 * j + 1]);
-                    const f16x8 pf = __builtin_bit_cast(f16x8, pk);
-#pragma unroll
-                    for (int dt = 0; dt < AT_DT; ++dt) {
-                        if (32 * dt < D) {
-                            const f16x8 vf = *(const f16x8*)(Vt + (32 * dt + r) * AT_VPITCH +
-                                                             2 * (32 * t + 16 * st + 8 * hh));
-                            o[dt] = mfma16(vf, pf, o[dt]);
-                        }
-                    }
+                    for (int dt = 0; dt < AT_DT; ++dt)
+                        vf[(ks + 1) & 1][dt] = *(const f16x8*)(vrow + 32 * dt * AT_VPITCH + 32 * (ks + 1));
                 }
+                const int t = ks >> 1, st = ks & 1;
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pk[j] = Vec<ECOFLAP_F16>::f2h_pk(s[t][8 * st + 2 * j], s[t][8 * st + 2 * j + 1]);
+                const f16x8 pf = __builtin_bit_cast(f16x8, pk);
+#pragma unroll
+                for (int dt = 0; dt < AT_DT; ++dt) o[dt] = mfma16(vf[ks & 1][dt], pf, o[dt]);
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (q < N) {
