@@ -18,6 +18,8 @@
 //   * reads qkv as the qkv Linear wrote it ([B, N, 3, H, D]) and writes [B, N, H*D]: no permute /
 //     contiguous copies around it.
 // Per (image, head) independent: batch invariant by construction.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/ecoflap_shape_ops.h"
 
@@ -29,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define AT_DC 6                 // 16-wide chunks of the head dimension (D <= 96)
 #define AT_DT 3                 // 32-wide tiles of the head dimension
 #define AT_KPITCH_MAX 208       // bytes per K row in LDS: 2*D rounded up to 16 * odd
-#define AT_VPITCH 592           // bytes per V^T row in LDS: 296 halves = 16 * 37
+#define AT_VPITCH 192           // bytes per V row in LDS (96 halves: 4 consecutive rows x 64 B cover all banks once)
 #define AT_FILL 6               // 16-byte vectors of K and of V per thread and fill round
 
 struct AttnArgs {
@@ -38,6 +40,7 @@ struct AttnArgs {
     int B, N, H, D;
     int kpitch;                 // bytes
     float scale_log2e;          // softmax scale * log2(e)
+    int debug;                  // ablation switches for tools/attention_launches.py (0 in production)
 };
 
 static __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
@@ -46,20 +49,19 @@ static __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
 
 __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char Ks[AT_ROWS * AT_KPITCH_MAX];
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[AT_DT * 32 * AT_VPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[AT_ROWS * AT_VPITCH];
     const int N = a.N, D = a.D, H = a.H, kpitch = a.kpitch;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row_stride = (int64_t)3 * H * D;
     const _Float16* base = a.qkv + (int64_t)b * N * row_stride + (int64_t)h * D;
     const int nt = (N + 31) >> 5;
-    // ---- K and V^T of this head into LDS (padding rows / keys zero: 0 * garbage must stay 0) ----
+    // ---- K and V of this head into LDS, both row-major.  Rows past N: V's must be zero (their
+    // probabilities are, and 0 * garbage must stay 0); K's may hold anything (masked below) ----
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < AT_ROWS * AT_KPITCH_MAX / 16; i += 256) ((u32x4*)Ks)[i] = z;
-        for (int i = tid; i < AT_DT * 32 * AT_VPITCH / 16; i += 256) ((u32x4*)Vt)[i] = z;
+        for (int i = N * (AT_VPITCH / 16) + tid; i < AT_ROWS * (AT_VPITCH / 16); i += 256) ((u32x4*)Vs)[i] = z;
     }
-    __syncthreads();
     const int r = lane & 31, hh = lane >> 5;
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // the first tile's Q^T fragments are requested before the fill (their latency hides under it)
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
             qf[c] = (d0 < D && wave < nt) ? *(const f16x8*)(base + (int64_t)qc0 * row_stride + d0) : zero8;
         }
     }
-    {
+    if (!(a.debug & 1)) {
         // all of a round's global loads are in flight before the first LDS write (one memory
         // latency per round of AT_FILL vectors per thread instead of one per vector)
         const int vpr = D >> 3;
@@ -96,13 +98,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                 if (v0 + 256 * j >= total) continue;
                 const int key = keys[j], c = cs[j];
                 *(u32x4*)(Ks + key * kpitch + 16 * c) = kv[j];
-                // key -> its place in the MFMA's k order inside its group of 16
-                const int k16 = key & 15;
-                const int pos = (key & ~15) + 8 * ((k16 >> 2) & 1) + (k16 & 3) + 4 * (k16 >> 3);
-                unsigned char* dst = Vt + (8 * c) * AT_VPITCH + 2 * pos;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *(uint16_t*)(dst + e * AT_VPITCH) = (uint16_t)(vv[j][e >> 1] >> (16 * (e & 1)));
+                *(u32x4*)(Vs + key * AT_VPITCH + 16 * c) = vv[j];
             }
         }
     }
@@ -131,7 +127,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
         for (int t = 0; t < AT_NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[t][i] = 0.f;
-        {
+        if (!(a.debug & 2)) {
             const unsigned char* krow = Ks + r * kpitch + 16 * hh;
             f16x8 kf[2][AT_NT];
 #pragma unroll
@@ -152,30 +148,40 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // exact softmax over the keys of this lane's query: own registers, then lane ^ 32
-        float m = -__builtin_inff();
+        // exact softmax over the keys of this lane's query: own registers, then lane ^ 32.
+        // Four independent chains for the maximum and for the sum (one wave per SIMD: a serial
+        // chain of 144 dependent ops would expose every VALU latency).
+        float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        if (!(a.debug & 4)) {
 #pragma unroll
-        for (int t = 0; t < AT_NT; ++t) {
+            for (int t = 0; t < AT_NT; ++t) {
+                if (32 * t + 32 > N) {          // uniform: only the tile(s) reaching past N mask
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const float v = key < N ? s[t][i] : -__builtin_inff();
-                s[t][i] = v;
-                m = __builtin_fmaxf(m, v);
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        s[t][i] = key < N ? s[t][i] : -__builtin_inff();
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx[i & 3] = __builtin_fmaxf(mx[i & 3], s[t][i]);
             }
         }
+        float m = __builtin_fmaxf(__builtin_fmaxf(mx[0], mx[1]), __builtin_fmaxf(mx[2], mx[3]));
         m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
         const float c2 = a.scale_log2e, mc = m * c2;
-        float l = 0.f;
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!(a.debug & 4)) {
 #pragma unroll
-        for (int t = 0; t < AT_NT; ++t) {
+            for (int t = 0; t < AT_NT; ++t) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(s[t][i] * c2 - mc);
-                s[t][i] = p;
-                l += p;
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(s[t][i] * c2 - mc);
+                    s[t][i] = p;
+                    ls[i & 3] += p;
+                }
             }
         }
+        float l = (ls[0] + ls[1]) + (ls[2] + ls[3]);
         l += __shfl_xor(l, 32, 64);
         // O^T = V^T P^T: P tile t, k-step st = registers 8 st .. 8 st + 7 of s[t], as they stand
         f32x16 o[AT_DT];
@@ -183,20 +189,28 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
         for (int dt = 0; dt < AT_DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-        {
-            // three independent accumulators per step; the next step's three V^T fragments are in
-            // flight while this step's products issue (V^T rows past D and keys past N are zero)
-            const unsigned char* vrow = Vt + r * AT_VPITCH + 16 * hh;
-            f16x8 vf[2][AT_DT];
-#pragma unroll
-            for (int dt = 0; dt < AT_DT; ++dt) vf[0][dt] = *(const f16x8*)(vrow + 32 * dt * AT_VPITCH);
+        if (!(a.debug & 8)) {
+            // three independent accumulators per step.  V stays row-major in LDS; its transposed
+            // A fragments come from ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q,
+            // columns 4p..4p+3 of a 4-key x 16-column block and receives column (lane & 15) of the 4
+            // keys - exactly the MFMA's k order (keys 4h..4h+3 and 8+4h..8+4h+3 of the step).
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+            const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+            const unsigned char* vb = Vs + (4 * hh + qq) * AT_VPITCH + 2 * (16 * (grp & 1) + 4 * pp);
+            u32x4 vf[2][AT_DT];
+#define AT_TR(KS_, DT_, HALF_) __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+        (lds_s16x4)(vb + (16 * (KS_) + 8 * (HALF_)) * AT_VPITCH + 64 * (DT_)))
+#define AT_LOADV(BUF_, KS_)                                                                      \
+    _Pragma("unroll") for (int dt = 0; dt < AT_DT; ++dt) {                                       \
+        const s16x4 x0 = AT_TR(KS_, dt, 0), x1 = AT_TR(KS_, dt, 1);                               \
+        const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);       \
+        vf[BUF_][dt] = u32x4{u0.x, u0.y, u1.x, u1.y};                                             \
+    }
+            AT_LOADV(0, 0)
 #pragma unroll
             for (int ks = 0; ks < 2 * AT_NT; ++ks) {          // ks = 2 t + st: 16 keys per step
-                if (ks + 1 < 2 * AT_NT) {
-#pragma unroll
-                    for (int dt = 0; dt < AT_DT; ++dt)
-                        vf[(ks + 1) & 1][dt] = *(const f16x8*)(vrow + 32 * dt * AT_VPITCH + 32 * (ks + 1));
-                }
+                if (ks + 1 < 2 * AT_NT) { AT_LOADV((ks + 1) & 1, ks + 1) }
                 const int t = ks >> 1, st = ks & 1;
                 u32x4 pk;
 #pragma unroll
@@ -204,11 +218,14 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                     pk[j] = Vec<ECOFLAP_F16>::f2h_pk(s[t][8 * st + 2 * j], s[t][8 * st + 2 * j + 1]);
                 const f16x8 pf = __builtin_bit_cast(f16x8, pk);
 #pragma unroll
-                for (int dt = 0; dt < AT_DT; ++dt) o[dt] = mfma16(vf[ks & 1][dt], pf, o[dt]);
+                for (int dt = 0; dt < AT_DT; ++dt)
+                    o[dt] = mfma16(__builtin_bit_cast(f16x8, vf[ks & 1][dt]), pf, o[dt]);
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+#undef AT_LOADV
+#undef AT_TR
         }
-        if (q < N) {
+        if (q < N && !(a.debug & 16)) {
             const float inv = 1.0f / l;
             _Float16* orow = a.out + ((int64_t)b * N + q) * H * D + (int64_t)h * D;
 #pragma unroll
@@ -246,6 +263,10 @@ extern "C" int ecoflap_vit_attention(const void* qkv, void* out, int64_t batch, 
     if (((kp / 16) & 1) == 0) kp += 16;
     a.kpitch = kp;
     a.scale_log2e = scale * 1.4426950408889634f;
+    {
+        const char* dbg = getenv("ECOFLAP_ATTN_DEBUG");
+        a.debug = dbg ? atoi(dbg) : 0;
+    }
     hipLaunchKernelGGL(vit_attention_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0,
                        (hipStream_t)stream, a);
     ECO_CHECK_LAUNCH();
