@@ -137,6 +137,8 @@ def vit_attention(qkv, heads, scale):
     out = torch.empty((B, N, heads * D), dtype=qkv.dtype, device=qkv.device)
     rc = _get().ecoflap_vit_attention(qkv.data_ptr(), out.data_ptr(), B, N, heads, D, float(scale),
                                       _hip.DTYPE_CODE[qkv.dtype], _stream())
+    if rc == -3:        # ECOFLAP_ESIZE: the head's K image does not fit the kernel's LDS buffers
+        return None
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_vit_attention failed ({rc})")
     return out

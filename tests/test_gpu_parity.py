@@ -1433,7 +1433,7 @@ def test_fused_shape_ops_match_torch_chain():
         assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("B,N,H,D", [(8, 257, 16, 88), (3, 257, 16, 88), (2, 288, 4, 96), (2, 33, 2, 64),
+@pytest.mark.parametrize("B,N,H,D", [(8, 257, 16, 88), (3, 257, 16, 88), (20, 257, 16, 88), (40, 257, 16, 88), (2, 288, 4, 72), (2, 220, 3, 96), (2, 33, 2, 64),
                                       (1, 1, 1, 8), (2, 100, 3, 40), (5, 197, 12, 64)])
 def test_vit_attention_kernel_vs_fp32_reference(B, N, H, D):
     """`ecoflap_vit_attention` (plumbing of the EVA ViT-g blocks) vs softmax(q k^T * scale) v in
