@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
     const int busy_last = nt - 4 * (rounds - 1);               // waves with a tile in the last round
     const int nfree = 4 - busy_last;
     const bool overlap = nfree > 0 && (total + 64 * nfree - 1) / (64 * nfree) <= AT_PF;
+    const bool dma = kpitch == 2 * D && ((total + 63) >> 6) * 1024 <= AT_KBYTES;
     // Rows past N: V's must be zero (their probabilities are, and 0 * garbage must stay 0); K's may
     // hold anything readable (those keys are masked).  N is the same for every item: once.
     {
@@ -262,25 +263,42 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const AttnArgs a) {
                     const int key = v / vpr, c = v - key * vpr;
                     pv[j] = *(const u32x4*)(nb + (int64_t)key * row_stride + 8 * c + (int64_t)2 * H * D);
                 }
-#pragma unroll
-                for (int j0 = 0; j0 < AT_PF; j0 += 5) {        // K: through registers into the idle buffer
-                    u32x4 kk[5];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const int v0 = fi + 64 * nfree * (j0 + j);
+                if (dma) {
+                    // K: DMA straight into the idle buffer, no registers (a K image without row
+                    // padding is contiguous: vector v of the head lives at byte 16 v, so a wave's 64
+                    // consecutive vectors are one 1-KiB piece at a wave-uniform LDS address)
+                    const int fw = wave - busy_last;
+                    for (int blk = fw; 64 * blk < total; blk += nfree) {
+                        const int v0 = 64 * blk + lane;
                         const int v = v0 < total ? v0 : total - 1;
                         const int key = v / vpr, c = v - key * vpr;
-                        kk[j] = *(const u32x4*)(nb + (int64_t)key * row_stride + 8 * c + (int64_t)H * D);
+                        const _Float16* src = nb + (int64_t)key * row_stride + 8 * c + (int64_t)H * D;
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)src,
+                            (__attribute__((address_space(3))) void*)(Kn + 1024 * blk), 16, 0, 0);
                     }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const int v = fi + 64 * nfree * (j0 + j);
-                        if (v < total) {
+                    for (int j0 = 0; j0 < AT_PF; j0 += 5) {    // K: through registers into the idle buffer
+                        u32x4 kk[5];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const int v0 = fi + 64 * nfree * (j0 + j);
+                            const int v = v0 < total ? v0 : total - 1;
                             const int key = v / vpr, c = v - key * vpr;
-                            *(u32x4*)(Kn + key * kpitch + 16 * c) = kk[j];
+                            kk[j] = *(const u32x4*)(nb + (int64_t)key * row_stride + 8 * c + (int64_t)H * D);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const int v = fi + 64 * nfree * (j0 + j);
+                            if (v < total) {
+                                const int key = v / vpr, c = v - key * vpr;
+                                *(u32x4*)(Kn + key * kpitch + 16 * c) = kk[j];
+                            }
                         }
                     }
                 }
+                __builtin_amdgcn_s_waitcnt(0);       // the DMA pieces have landed before the barrier
             }
         }
         __syncthreads();                     // every wave is done with this item's LDS image
