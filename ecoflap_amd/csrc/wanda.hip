@@ -1135,6 +1135,13 @@ static __device__ __forceinline__ const float* stage_sq(const float* __restrict_
     __syncthreads();
     return lds;
 }
+// the same, straight from the statistic (sampled-bracket path: no sqrt launch in front of it)
+static __device__ __forceinline__ const float* stage_sqrt(const float* __restrict__ sr, int64_t cols,
+                                                          float* lds) {
+    for (int64_t c = threadIdx.x; c < cols; c += WM_THREADS) lds[c] = __builtin_sqrtf(sr[c]);
+    __syncthreads();
+    return lds;
+}
 static __device__ __forceinline__ u32x4 ld_sq4(const float* sq, int64_t i4) {
     return *(const u32x4*)(sq + 4 * i4);      // LDS or global, 16-byte aligned either way
 }
@@ -1409,25 +1416,6 @@ struct BracketState {
 };
 #define WS_ZERO_WORDS (4 + WS_BINS)
 
-// rank (1-based) -> (bin, rank inside the bin) over an LDS histogram of 2048 bins, 256 threads
-static __device__ __forceinline__ void find_rank_256(const uint32_t* h, uint32_t rank, uint32_t* wave4,
-                                                     uint32_t* out2) {
-    uint32_t c[8], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { c[i] = h[8 * threadIdx.x + i]; sum += c[i]; }
-    uint32_t total;
-    const uint32_t incl = block_scan_256(sum, wave4, total);
-    uint32_t run = incl - sum;
-    if (run < rank && rank <= incl) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (run < rank && rank <= run + c[i]) { out2[0] = 8 * threadIdx.x + i; out2[1] = rank - run; }
-            run += c[i];
-        }
-    }
-    __syncthreads();
-}
-
 struct SampleGroup {
     int n;
     const void* w[WMAX];
@@ -1437,30 +1425,69 @@ struct SampleGroup {
     BracketState* bs[WMAX];
 };
 
+// rank (1-based) -> (bin, rank inside the bin) over an LDS histogram of 2048 bins, WM_THREADS threads
+static __device__ __forceinline__ void find_rank_wm(const uint32_t* h, uint32_t rank, uint32_t* waves,
+                                                    uint32_t* out2) {
+    const uint32_t c0 = h[2 * threadIdx.x], c1 = h[2 * threadIdx.x + 1];
+    uint32_t total;
+    const uint32_t incl = block_scan_wm(c0 + c1, waves, total);
+    const uint32_t excl = incl - (c0 + c1);
+    if (excl < rank && rank <= incl) {
+        const bool second = rank > excl + c0;
+        out2[0] = 2 * threadIdx.x + (second ? 1u : 0u);
+        out2[1] = rank - excl - (second ? c0 : 0u);
+    }
+    __syncthreads();
+}
+
+// One workgroup per matrix: WS_SAMPLE_VECS vectors (one per stride of the matrix, at a
+// pseudo-random place inside its stride: a regular stride can be a multiple of the row length
+// and then sees one column group only), their metrics (sqrt of the statistic taken here: the
+// same correctly rounded value as the table's), two levels of histogram in LDS (11 + 11 bits)
+// -> bracket [lo, hi) at 22-bit resolution.  Also clears the head of the bracket state.
 template <int DT>
-__global__ __launch_bounds__(256) void wanda_matrix_sample_kernel(const SampleGroup g) {
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const SampleGroup g) {
     constexpr int N = Vec<DT>::N;
     constexpr int S = WS_SAMPLE_VECS * N;
+    constexpr int VPT = WS_SAMPLE_VECS / WM_THREADS;          // vectors per thread
     __shared__ uint32_t sb[WS_SAMPLE_VECS * 8];
     __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
-    __shared__ uint32_t wave4[4], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
+    __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
     const int it = blockIdx.x;
     const void* __restrict__ w = g.w[it];
     const float* __restrict__ sr = g.scaler_row[it];
+    BracketState* bs = g.bs[it];
     const int64_t cols = g.cols[it];
     const int64_t vpr = cols / N, nvec = g.rows[it] * vpr;
     const int64_t step = nvec / WS_SAMPLE_VECS;
-    for (int i = threadIdx.x; i < 2048; i += 256) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < WS_SAMPLE_VECS; i += 256) {
+    for (int i = threadIdx.x; i < WS_ZERO_WORDS; i += WM_THREADS) ((uint32_t*)bs)[i] = 0u;
+    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
+    // every load of the thread in flight before the first use
+    u32x4 wv[VPT];
+    float sc[VPT][N];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + WM_THREADS * j;
         const uint32_t jitter = (uint32_t)(((uint64_t)((uint32_t)i * 2654435761u) * (uint64_t)step) >> 32);
         const int64_t v = (int64_t)i * step + jitter;
         const int64_t c0 = (v % vpr) * N;
+        wv[j] = ld16(w, v);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const u32x4 s4 = *(const u32x4*)(sr + c0 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[j][4 * q + e] = __uint_as_float(s4[e]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + WM_THREADS * j;
         float f[N];
-        Vec<DT>::unpack(ld16(w, v), f);
+        Vec<DT>::unpack(wv[j], f);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sr[c0 + e]));
+            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sc[j][e]));
             sb[i * N + e] = b;
             atomicAdd(&h1[b >> 21], 1u);
         }
@@ -1474,17 +1501,17 @@ __global__ __launch_bounds__(256) void wanda_matrix_sample_kernel(const SampleGr
     const bool open_lo = mid - dev < 1.0, open_hi = mid + dev > (double)S;
     const uint32_t r_lo = open_lo ? 1u : (uint32_t)(mid - dev);
     const uint32_t r_hi = open_hi ? (uint32_t)S : (uint32_t)(mid + dev);
-    find_rank_256(h1, r_lo, wave4, o_lo);
-    find_rank_256(h1, r_hi, wave4, o_hi);
+    find_rank_wm(h1, r_lo, waves, o_lo);
+    find_rank_wm(h1, r_hi, waves, o_hi);
     const uint32_t b_lo = o_lo[0], b_hi = o_hi[0];
-    for (int i = threadIdx.x; i < S; i += 256) {
+    for (int i = threadIdx.x; i < S; i += WM_THREADS) {
         const uint32_t b = sb[i];
         if ((b >> 21) == b_lo) atomicAdd(&h2a[(b >> 10) & 2047u], 1u);
         if ((b >> 21) == b_hi) atomicAdd(&h2b[(b >> 10) & 2047u], 1u);
     }
     __syncthreads();
-    find_rank_256(h2a, o_lo[1], wave4, s_lo);
-    find_rank_256(h2b, o_hi[1], wave4, s_hi);
+    find_rank_wm(h2a, o_lo[1], waves, s_lo);
+    find_rank_wm(h2b, o_hi[1], waves, s_hi);
     if (threadIdx.x == 0) {
         const uint32_t lo = open_lo ? 0u : ((b_lo << 21) | (s_lo[0] << 10));
         const uint64_t hi64 = open_hi ? 0x100000000ull
@@ -1493,7 +1520,6 @@ __global__ __launch_bounds__(256) void wanda_matrix_sample_kernel(const SampleGr
         const uint32_t width = hi - lo;
         int shift = 0;
         while (shift < 31 && ((width - 1u) >> shift) >= (uint32_t)WS_BINS) ++shift;
-        BracketState* bs = g.bs[it];
         bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift;
         bs->valid = hi > lo ? 1u : 0u;
     }
@@ -1502,6 +1528,7 @@ __global__ __launch_bounds__(256) void wanda_matrix_sample_kernel(const SampleGr
 struct BracketGroup {
     MatGroup m;
     BracketState* bs[WMAX];
+    const float* sr[WMAX];          // the raw statistic (sqrt taken while staging it into LDS)
 };
 
 template <int DT>
@@ -1520,7 +1547,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const 
     if (!bs->valid) return;
     const uint32_t lo = bs->lo, width = bs->hi - bs->lo, shift = bs->shift;
     for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS) h[i] = 0;
-    sq = stage_sq(sq, cols, sq_lds);
+    sq = stage_sqrt(bg.sr[it], cols, sq_lds);
     __syncthreads();
     uint32_t below = 0;
     const int64_t vpr = cols / N;
@@ -1595,7 +1622,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     const uint32_t lo = bs->lo, hi = bs->hi, shift = bs->shift;
     const uint32_t below = bs->count_below;
     const uint32_t c = threadIdx.x < WS_BINS ? bs->hist[threadIdx.x] : 0u;
-    sq = stage_sq(sq, cols, sq_lds);
+    sq = stage_sqrt(bg.sr[it], cols, sq_lds);
     uint32_t total;
     const uint32_t incl = block_scan_wm(c, wave4, total);
     const bool miss = rank0 <= below || rank0 - below > total;
@@ -1632,9 +1659,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
                 if (cv >= vpr32) cv -= vpr32;
                 if (v >= nvec) continue;
                 float f[N];
-                uint32_t bits[N];
                 Vec<DT>::unpack(wv[j], f);
-                uint32_t lo4 = 0, hi4 = 0, und = 0, pr = 0;
+                uint32_t lo4 = 0, hi4 = 0;
+                bool any = false, open_any = false;
 #pragma unroll
                 for (int q = 0; q < N / 4; ++q) {
                     const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
@@ -1642,42 +1669,40 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
                     for (int i = 0; i < 4; ++i) {
                         const int e = 4 * q + i;
                         const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __uint_as_float(s4[i]));
-                        bits[e] = b;
                         const bool prune = b < binlo;
-                        const bool open = b >= binlo && (b - binlo) < binw;
-                        pr |= (prune ? 1u : 0u) << e;
-                        und |= (open ? 1u : 0u) << e;
+                        open_any |= (b - binlo) < binw;          // (b < binlo wraps to a huge value)
+                        if (prune) { f[e] = 0.0f; any = true; }
                         if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
                         else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
                     }
                 }
-                if (!und) {
-                    if (pr) {
-#pragma unroll
-                        for (int e = 0; e < N; ++e) if ((pr >> e) & 1u) f[e] = 0.0f;
-                        st16(w, v, Vec<DT>::pack(f));
-                    }
+                if (!open_any) {
+                    if (any) st16(w, v, Vec<DT>::pack(f));
                     if (mask_out) {
                         uint8_t* m = mask_out + v * N;
                         *(uint32_t*)m = lo4;
                         if (N == 8) *(uint32_t*)(m + 4) = hi4;
                     }
                 } else {
-                    // a vector with an element of the threshold's bin: element stores only, and
-                    // never the open element's own bytes (the last workgroup may write them)
+                    // a vector with an element of the threshold's bin (a few hundred per matrix):
+                    // element stores only, and never the open element's own bytes (the last
+                    // workgroup may write them).  Metrics again from the untouched vector.
+                    float f0[N];
+                    Vec<DT>::unpack(wv[j], f0);
 #pragma unroll
                     for (int e = 0; e < N; ++e) {
                         const int64_t idx = v * N + e;
-                        if ((und >> e) & 1u) {
+                        const uint32_t b = __float_as_uint(__builtin_fabsf(f0[e]) * sq[c0 + e]);
+                        if ((b - binlo) < binw) {
                             const uint32_t slot = atomicAdd(&bs->list_count, 1u);
                             if (slot < (uint32_t)WS_CAP) {
                                 __hip_atomic_store(&bs->list_idx[slot], (uint32_t)idx, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(&bs->list_bits[slot], bits[e], __ATOMIC_RELAXED,
+                                __hip_atomic_store(&bs->list_bits[slot], b, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
                             }
                         } else {
-                            const bool prune = (pr >> e) & 1u;
+                            const bool prune = b < binlo;
                             if (prune) Vec<DT>::store1(w, idx, 0.0f);
                             if (mask_out) mask_out[idx] = prune ? 1 : 0;
                         }
@@ -1808,7 +1833,18 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     }
     BracketState* bst[WMAX];
     for (int i = 0; i < n_items; ++i) { bst[i] = (BracketState*)p; p += sizeof(BracketState); }
-    {
+    // matrix-mode items big enough to sample one vector per stride take the sampled-bracket path
+    // (it stages sqrt(scaler_row) itself and clears its own state): no sqrt launch for them
+    static const bool force_legacy = getenv("ECOFLAP_WANDA_LEGACY") != nullptr;
+    bool sampled_item[WMAX];
+    for (int i = 0; i < n_items; ++i) {
+        const ecoflap_wanda_item& a = items[i];
+        const int64_t nv = a.rows * a.cols / (a.dtype == ECOFLAP_F32 ? 4 : 8);
+        sampled_item[i] = a.mode == ECOFLAP_WANDA_MATRIX && !force_legacy && item_vector_ok(a, sq[i]) &&
+                          nv >= 8 * WS_SAMPLE_VECS && a.cols <= WM_SQ_LDS &&
+                          (((uintptr_t)a.scaler_row) & 15u) == 0;
+    }
+    auto launch_sqrt = [&](const bool* want) -> int {
         SqrtGroup g;
         g.n = n_items;
         g.zero_words = (int)(sizeof(MatrixSelState) / sizeof(uint32_t));
@@ -1817,11 +1853,19 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         for (int i = 0; i < n_items; ++i) {
             g.src[i] = items[i].scaler_row; g.dst[i] = sq[i]; g.cols[i] = items[i].cols;
             g.zero[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)st[i] : nullptr;
-            g.zero2[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)bst[i] : nullptr;
-            g.start[i + 1] = g.start[i] + (int32_t)((items[i].cols + 255) / 256);
+            g.zero2[i] = nullptr;
+            g.start[i + 1] = g.start[i] + (want[i] ? (int32_t)((items[i].cols + 255) / 256) : 0);
         }
+        if (g.start[n_items] == 0) return 0;
         hipLaunchKernelGGL(sqrt_cols_kernel, dim3((unsigned)g.start[n_items]), dim3(256), 0, s, g);
         ECO_CHECK_LAUNCH();
+        return 0;
+    };
+    {
+        bool want[WMAX];
+        for (int i = 0; i < n_items; ++i) want[i] = !sampled_item[i];
+        const int rc = launch_sqrt(want);
+        if (rc) return rc;
     }
 
     bool done[WMAX];
@@ -1919,7 +1963,8 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         int64_t total_elems = 0;
         for (int j = i; j < n_items; ++j) {
             const ecoflap_wanda_item& b = items[j];
-            if (done[j] || b.dtype != a.dtype || item_vector_ok(b, sq[j]) != vec) continue;
+            if (done[j] || b.dtype != a.dtype || item_vector_ok(b, sq[j]) != vec ||
+                sampled_item[j] != sampled_item[i]) continue;
             members[g.n++] = j;
             total_elems += b.rows * b.cols;
             done[j] = true;
@@ -1956,12 +2001,7 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     } while (0)
         // sampled bracket (2 reads + 1 write) when every matrix of the group is big enough to
         // sample one vector per stride; otherwise / on a flagged matrix the three histograms
-        static const bool force_legacy = getenv("ECOFLAP_WANDA_LEGACY") != nullptr;
-        bool sampled = vec && !force_legacy;
-        for (int q = 0; q < g.n && sampled; ++q) {
-            const int64_t nv = g.rows[q] * g.cols[q] / (a.dtype == ECOFLAP_F32 ? 4 : 8);
-            if (nv < 8 * WS_SAMPLE_VECS || g.cols[q] > WM_SQ_LDS) sampled = false;
-        }
+        const bool sampled = sampled_item[i];
         if (!sampled) {
 #define MATRIX_GO(DT_) MATRIX_LEGACY(DT_, g, grid)
             DT_SWITCH(a.dtype, MATRIX_GO);
@@ -1977,10 +2017,11 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             const ecoflap_wanda_item& b = items[members[q]];
             sg.w[q] = b.w; sg.scaler_row[q] = b.scaler_row; sg.rows[q] = b.rows; sg.cols[q] = b.cols;
             sg.rank0[q] = g.rank0[q]; sg.bs[q] = bst[members[q]]; bg.bs[q] = bst[members[q]];
+            bg.sr[q] = b.scaler_row;
         }
 #define MATRIX_GO(DT_)                                                                              \
     do {                                                                                            \
-        hipLaunchKernelGGL((wanda_matrix_sample_kernel<DT_>), dim3((unsigned)g.n), dim3(256), 0, s, sg); \
+        hipLaunchKernelGGL((wanda_matrix_sample_kernel<DT_>), dim3((unsigned)g.n), blk, 0, s, sg); \
         hipLaunchKernelGGL((wanda_matrix_bracket_kernel<DT_>), grid, blk, 0, s, bg);                \
         hipLaunchKernelGGL((wanda_matrix_apply2_kernel<DT_>), grid, blk, 0, s, bg);                 \
     } while (0)
@@ -2011,6 +2052,11 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             lg.start[z + 1] = lg.start[z] + (g.start[q + 1] - g.start[q]);
         }
         if (lg.n) {
+            bool want[WMAX];
+            for (int z = 0; z < n_items; ++z) want[z] = false;
+            for (int q = 0; q < g.n; ++q) if (flags[q]) want[members[q]] = true;
+            const int rc = launch_sqrt(want);
+            if (rc) return rc;
             const dim3 lgrid((unsigned)lg.start[lg.n]);
 #define MATRIX_GO(DT_) MATRIX_LEGACY(DT_, lg, lgrid)
             DT_SWITCH(a.dtype, MATRIX_GO);
