@@ -1451,6 +1451,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
     constexpr int S = WS_SAMPLE_VECS * N;
     constexpr int VPT = WS_SAMPLE_VECS / WM_THREADS;          // vectors per thread
     __shared__ uint32_t sb[WS_SAMPLE_VECS * 8];
+    // first level: 16 interleaved counters per bin (the top 11 bits of a metric take a few dozen
+    // values: same-address LDS atomics are served one by one); finite metrics have bit 31 clear
+    __shared__ uint32_t h1s[1024 * 16];
     __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
     __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
     const int it = blockIdx.x;
@@ -1462,6 +1465,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
     const int64_t step = nvec / WS_SAMPLE_VECS;
     for (int i = threadIdx.x; i < WS_ZERO_WORDS; i += WM_THREADS) ((uint32_t*)bs)[i] = 0u;
     for (int i = threadIdx.x; i < 2048; i += WM_THREADS) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
+    for (int i = threadIdx.x; i < 1024 * 16; i += WM_THREADS) h1s[i] = 0;
     // every load of the thread in flight before the first use
     u32x4 wv[VPT];
     float sc[VPT][N];
@@ -1489,8 +1493,17 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
         for (int e = 0; e < N; ++e) {
             const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sc[j][e]));
             sb[i * N + e] = b;
-            atomicAdd(&h1[b >> 21], 1u);
+            const uint32_t top = b >> 21;
+            if (top < 1024u) atomicAdd(&h1s[top * 16 + (threadIdx.x & 15)], 1u);
+            else atomicAdd(&h1[top], 1u);                       // (-0 / NaN patterns: rare)
         }
+    }
+    __syncthreads();
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c += h1s[threadIdx.x * 16 + q];
+        h1[threadIdx.x] = c;                                    // WM_THREADS == 1024 bins
     }
     __syncthreads();
     // sample ranks 5 sigma either side of the expected one
@@ -1672,8 +1685,10 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
                         const bool prune = b < binlo;
                         open_any |= (b - binlo) < binw;          // (b < binlo wraps to a huge value)
                         if (prune) { f[e] = 0.0f; any = true; }
-                        if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
-                        else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
+                        if (mask_out) {
+                            if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
+                            else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
+                        }
                     }
                 }
                 if (!open_any) {
