@@ -1443,28 +1443,29 @@ static __device__ __forceinline__ void find_rank_wm(const uint32_t* h, uint32_t 
 // One workgroup per matrix: WS_SAMPLE_VECS vectors (one per stride of the matrix, at a
 // pseudo-random place inside its stride: a regular stride can be a multiple of the row length
 // and then sees one column group only), their metrics (sqrt of the statistic taken here: the
-// same correctly rounded value as the table's) into ONE LDS histogram of the top 12 bits (4
-// interleaved counters per bin: those bits take a few dozen values and same-address LDS atomics
-// are served one by one) -> bracket [lo, hi) = the bins holding the sample ranks 5 sigma either
-// side of the expected one (10-15 % of the elements).  Also clears the head of the bracket state.
+// same correctly rounded value as the table's), two levels of histogram in LDS (11 + 11 bits)
+// -> bracket [lo, hi) at 22-bit resolution.  Also clears the head of the bracket state.
 template <int DT>
 __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const SampleGroup g) {
     constexpr int N = Vec<DT>::N;
     constexpr int S = WS_SAMPLE_VECS * N;
     constexpr int VPT = WS_SAMPLE_VECS / WM_THREADS;          // vectors per thread
-    __shared__ uint32_t hs[2048 * 4];                         // finite metrics: bit 31 clear -> 2048 bins
-    __shared__ uint32_t h1[2048];
-    __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2];
+    __shared__ uint32_t sb[WS_SAMPLE_VECS * 8];
+    // first level: 16 interleaved counters per bin (the top 11 bits of a metric take a few dozen
+    // values: same-address LDS atomics are served one by one); finite metrics have bit 31 clear
+    __shared__ uint32_t h1s[1024 * 16];
+    __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
+    __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
     const int it = blockIdx.x;
     const void* __restrict__ w = g.w[it];
     const float* __restrict__ sr = g.scaler_row[it];
     BracketState* bs = g.bs[it];
     const int64_t cols = g.cols[it];
-    const uint32_t vpr = (uint32_t)(cols / N);
-    const int64_t nvec = g.rows[it] * (int64_t)vpr;
+    const int64_t vpr = cols / N, nvec = g.rows[it] * vpr;
     const int64_t step = nvec / WS_SAMPLE_VECS;
     for (int i = threadIdx.x; i < WS_ZERO_WORDS; i += WM_THREADS) ((uint32_t*)bs)[i] = 0u;
-    for (int i = threadIdx.x; i < 2048 * 4; i += WM_THREADS) hs[i] = 0;
+    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
+    for (int i = threadIdx.x; i < 1024 * 16; i += WM_THREADS) h1s[i] = 0;
     // every load of the thread in flight before the first use
     u32x4 wv[VPT];
     float sc[VPT][N];
@@ -1473,7 +1474,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
         const int i = threadIdx.x + WM_THREADS * j;
         const uint32_t jitter = (uint32_t)(((uint64_t)((uint32_t)i * 2654435761u) * (uint64_t)step) >> 32);
         const int64_t v = (int64_t)i * step + jitter;
-        const int64_t c0 = (int64_t)(uint32_t)(v % vpr) * N;
+        const int64_t c0 = (v % vpr) * N;
         wv[j] = ld16(w, v);
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
@@ -1485,35 +1486,53 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + WM_THREADS * j;
         float f[N];
         Vec<DT>::unpack(wv[j], f);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sc[j][e]));
-            const uint32_t top = b >> 19;                       // sign, exponent, 3 mantissa bits
-            atomicAdd(&hs[(top < 2048u ? top : 2047u) * 4 + (threadIdx.x & 3)], 1u);
+            sb[i * N + e] = b;
+            const uint32_t top = b >> 21;
+            if (top < 1024u) atomicAdd(&h1s[top * 16 + (threadIdx.x & 15)], 1u);
+            else atomicAdd(&h1[top], 1u);                       // (-0 / NaN patterns: rare)
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += WM_THREADS)
-        h1[i] = (hs[4 * i] + hs[4 * i + 1]) + (hs[4 * i + 2] + hs[4 * i + 3]);
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c += h1s[threadIdx.x * 16 + q];
+        h1[threadIdx.x] = c;                                    // WM_THREADS == 1024 bins
+    }
     __syncthreads();
     // sample ranks 5 sigma either side of the expected one
-    const float p = (float)((double)g.rank0[it] / ((double)g.rows[it] * (double)cols));
-    const float mid = p * (float)S;
-    const float dev = 5.0f * __builtin_sqrtf((float)S * p * (1.0f - p)) + 8.0f;
-    const bool open_lo = mid - dev < 1.0f, open_hi = mid + dev > (float)S;
+    const double numel = (double)g.rows[it] * (double)cols;
+    const double p = (double)g.rank0[it] / numel;
+    const double mid = p * S;
+    const double dev = 5.0 * __builtin_sqrt((double)S * p * (1.0 - p)) + 8.0;
+    const bool open_lo = mid - dev < 1.0, open_hi = mid + dev > (double)S;
     const uint32_t r_lo = open_lo ? 1u : (uint32_t)(mid - dev);
     const uint32_t r_hi = open_hi ? (uint32_t)S : (uint32_t)(mid + dev);
     find_rank_wm(h1, r_lo, waves, o_lo);
     find_rank_wm(h1, r_hi, waves, o_hi);
+    const uint32_t b_lo = o_lo[0], b_hi = o_hi[0];
+    for (int i = threadIdx.x; i < S; i += WM_THREADS) {
+        const uint32_t b = sb[i];
+        if ((b >> 21) == b_lo) atomicAdd(&h2a[(b >> 10) & 2047u], 1u);
+        if ((b >> 21) == b_hi) atomicAdd(&h2b[(b >> 10) & 2047u], 1u);
+    }
+    __syncthreads();
+    find_rank_wm(h2a, o_lo[1], waves, s_lo);
+    find_rank_wm(h2b, o_hi[1], waves, s_hi);
     if (threadIdx.x == 0) {
-        const uint32_t lo = open_lo ? 0u : (o_lo[0] << 19);
-        const uint64_t hi64 = (open_hi || o_hi[0] >= 2047u) ? 0x100000000ull : ((uint64_t)(o_hi[0] + 1u) << 19);
+        const uint32_t lo = open_lo ? 0u : ((b_lo << 21) | (s_lo[0] << 10));
+        const uint64_t hi64 = open_hi ? 0x100000000ull
+                                      : ((uint64_t)((b_hi << 21) | (s_hi[0] << 10)) + 1024ull);
         const uint32_t hi = hi64 > 0xffffffffull ? 0xffffffffu : (uint32_t)hi64;
         const uint32_t width = hi - lo;
-        const int top = 32 - __builtin_clz(width - 1u | 1u);    // bits of width - 1
-        const int shift = top > 9 ? top - 9 : 0;                // (width - 1) >> shift < WS_BINS
+        int shift = 0;
+        while (shift < 31 && ((width - 1u) >> shift) >= (uint32_t)WS_BINS) ++shift;
         bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift;
         bs->valid = hi > lo ? 1u : 0u;
     }
