@@ -2109,11 +2109,27 @@ extern "C" int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int6
 // =====================================================================================
 // K8  grad *= mask
 // =====================================================================================
+// 16-byte vectors of the gradient, 8 (4) mask bytes per vector; scalar form for unaligned tails
 template <int DT>
 __global__ __launch_bounds__(256) void mask_mul_kernel(void* g, const uint8_t* __restrict__ keep,
                                                        int64_t n) {
+    constexpr int N = Vec<DT>::N;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const bool vec = (((uintptr_t)g) & 15u) == 0 && (((uintptr_t)keep) & (N - 1)) == 0;
+    const int64_t nvec = vec ? n / N : 0;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        float f[N];
+        Vec<DT>::unpack(ld16(g, v), f);
+        uint32_t m0 = *(const uint32_t*)(keep + v * N), m1 = 0;
+        if (N == 8) m1 = *(const uint32_t*)(keep + v * N + 4);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const uint32_t byte = ((e < 4 ? m0 : m1) >> (8 * (e & 3))) & 0xffu;
+            f[e] = Vec<DT>::round(f[e] * (byte ? 1.0f : 0.0f));      // grad * mask, as the reference multiplies
+        }
+        st16(g, v, Vec<DT>::pack(f));
+    }
+    for (int64_t i = nvec * N + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float m = keep[i] ? 1.0f : 0.0f;
         Vec<DT>::store1(g, i, Vec<DT>::load1(g, i) * m);
     }
@@ -2125,8 +2141,9 @@ extern "C" int ecoflap_mask_mul(void* g, const uint8_t* keep_mask, int64_t n, in
     if (n < 0) return ECOFLAP_ESIZE;
     if (n == 0) return 0;
     if (!g || !keep_mask) return ECOFLAP_ENULL;
-    int64_t b = (n + 256 * 4 - 1) / (256 * 4);
-    if (b > 2048) b = 2048;
+    int64_t b = (n / 8 + 256 * 2 - 1) / (256 * 2);            // ~2 vectors per thread
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ECOFLAP_F32)
         hipLaunchKernelGGL((mask_mul_kernel<ECOFLAP_F32>), dim3((unsigned)b), dim3(256), 0, s, g, keep_mask, n);

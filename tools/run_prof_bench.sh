@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-prof_bench}
 mkdir -p $OUT; rm -rf /tmp/prof_b
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-parity-leg > $OUT/bench_under_rocprof.json 2> $OUT/bench.err
 tr=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1)
 cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 $R/tools/k1_trace_summary.py $tr --bench-json $OUT/bench_under_rocprof.json --out $OUT/k1_trace.csv > $OUT/k1_trace_summary.txt

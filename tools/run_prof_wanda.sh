@@ -8,3 +8,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -- python3 $
 cp $(find /tmp/prof_w -name "*kernel_stats.csv" | head -1) $OUT/wanda_kernel_stats.csv
 cat $OUT/wanda_launches.log | grep -v amdgpu.ids
 grep -i "wanda\|colsq\|sqrt_cols" $OUT/wanda_kernel_stats.csv | cut -c1-170
+# kernel time per call (sum of the call's kernels) of the block-level operations
+tr=$(find /tmp/prof_w -name "*kernel_trace.csv" | head -1)
+echo "--- K7 matrix, sampled-bracket path: kernels per call" >> $OUT/wanda_launches.log
+python3 $R/tools/diag/kernel_groups.py $tr --first wanda_matrix_sample --match wanda_matrix,sqrt_cols >> $OUT/wanda_launches.log
+echo "--- K6, one launch per block" >> $OUT/wanda_launches.log
+python3 $R/tools/diag/kernel_groups.py $tr --first colsq_multi --match colsq_multi >> $OUT/wanda_launches.log
+echo "--- K7 rows, fused grid per block" >> $OUT/wanda_launches.log
+python3 $R/tools/diag/kernel_groups.py $tr --first wanda_rows_fused --match wanda_rows_fused >> $OUT/wanda_launches.log
+tail -12 $OUT/wanda_launches.log
