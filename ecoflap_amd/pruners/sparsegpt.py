@@ -23,6 +23,11 @@ from .wanda import BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPrun
 
 class SparseGPT:
     use_mfma_hessian = True     # False: the reference's fp32 expression through the library GEMM
+    # MFMA path: calibration samples whose inputs are reduced in ONE call.  The reference's
+    # per-sample recurrence (:71-82) unrolls to H_J = (n_0 / n_J) H_0 + (2 / n_J) sum_j X_j^T X_j,
+    # i.e. one update with the samples' tokens concatenated: H (151 MB at 6144 columns) is read
+    # and written once per `samples_per_call` samples instead of once per sample.
+    samples_per_call = 8
 
     def __init__(self, layer, kernels=None):
         self.layer = layer
@@ -35,6 +40,7 @@ class SparseGPT:
         self.nsamples = 0
         self.factor = None          # (dead columns, Hinv) once pruned; shared within a block
         self.kernels = kernels if kernels is not None else _hip.HipKernels()
+        self._pending = []          # (x [tokens, cols], batch) waiting for one MFMA call
 
     def add_batch(self, inp, out):
         """H <- H * n/(n+b) + (sqrt(2/(n+b)) x)^T (sqrt(2/(n+b)) x)   (:71-82)"""
@@ -45,15 +51,28 @@ class SparseGPT:
         if (self.use_mfma_hessian and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
                 and hasattr(self.kernels, "hessian_accum")):
             # fp16 / bf16 activations (the forward under autocast): beta*H + alpha*x^T x on the
-            # matrix cores, upper triangle once (csrc/syrk.hip)
-            self.kernels.hessian_accum(self.H, x if x.is_contiguous() else x.contiguous(),
-                                       self.nsamples, tmp)
-            self.nsamples += tmp
+            # matrix cores, upper triangle once (csrc/syrk.hip), several samples per call
+            self._pending.append((x if x.is_contiguous() else x.contiguous(), tmp))
+            if len(self._pending) >= self.samples_per_call:
+                self.flush()
             return
+        self.flush()
         self.H *= self.nsamples / (self.nsamples + tmp)
         self.nsamples += tmp
         xs = math.sqrt(2 / self.nsamples) * x.float()
         self.H.addmm_(xs.t(), xs)
+
+    def flush(self):
+        """Reduce the buffered samples into H (called when the buffer is full and before H is
+        read: merge across ranks, twin detection, `fasterprune`)."""
+        if not self._pending:
+            return
+        xs = [x for x, _ in self._pending]
+        b = sum(n for _, n in self._pending)
+        self._pending = []
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+        self.kernels.hessian_accum(self.H, x, self.nsamples, b)
+        self.nsamples += b
 
     @staticmethod
     def _clamp_inf(H):
@@ -81,6 +100,7 @@ class SparseGPT:
         if prune_n != 0:
             raise NotImplementedError("N:M sparsity: prune_n is always 0 in the reference "
                                       "(layer_single_base_pruner.py:62)")
+        self.flush()
         W = self.layer.weight.data.clone().float()
         H = self.H
         del self.H

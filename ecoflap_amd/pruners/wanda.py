@@ -435,6 +435,9 @@ class _BlockwiseWanda:
                     outs[j] = call(block, j)
             for h in handles:
                 h.remove()
+            if sparsegpt:
+                for w_ in wrapped.values():
+                    w_.flush()                 # buffered calibration samples -> H
             col, collector[0] = collector[0], None
             for w_ in wrapped.values():
                 w_.sink = None

@@ -240,6 +240,14 @@ int ecoflap_colsq_replay(float* scaler_row, const float* sq, const int64_t* batc
  *                                                   wanda_pruner.py:555-558
  * mask_out (optional): uint8[rows*cols], 1 where zeroed.
  * ------------------------------------------------------------------------- */
+/* Matrix mode runs a sampled-bracket selection (2 reads + 1 write of W): a sample brackets the
+ * threshold, one pass counts below / histograms inside the bracket, the apply pass settles all
+ * but the threshold bin's few hundred elements, which its last workgroup sorts.  Every count is
+ * exact (result identical to the reference's sort); a matrix the pass cannot settle (bracket miss,
+ * massive ties, non-finite threshold) is flagged untouched-or-partially-correct and finished by
+ * the three-histogram path.  For that flag the matrix-mode calls synchronise the stream ONCE
+ * per call (not graph-capturable); ECOFLAP_WANDA_LEGACY=1 in the environment selects the
+ * asynchronous three-histogram path outright. */
 size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols);
 int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
                              int64_t cols, int dtype, int64_t k,

@@ -126,6 +126,10 @@ def main():
         nt = -(-cols // 128)
         flops = 2.0 * tokens * 128 * 128 * nt * (nt + 1) / 2        # tiles actually computed
         flops_rows.append((name, flops, med))
+        # eight calibration samples per call (SparseGPT.samples_per_call): H read / written once
+        x8 = torch.cat([xs[i % 3] for i in range(8)], 0)
+        med8, _ = timed(lambda i: kern.hessian_accum(H, x8, 64 * i, 64), 3)
+        flops_rows.append((name + " x8 samples per call", 8 * flops, med8))
         import math
         xf = [x.float() for x in xs]
         def ref(i):
