@@ -31,6 +31,7 @@ def _get():
         lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_vit_attention.argtypes = [vp, vp, i64, i64, i64, i64, f32, ci, vp]
+        lib.ecoflap_multi_copy.argtypes = [vp, ci, vp]
         _lib = lib
     return _lib
 
@@ -142,3 +143,32 @@ def vit_attention(qkv, heads, scale):
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_vit_attention failed ({rc})")
     return out
+
+
+class _CopyItem(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("bytes", ctypes.c_int64)]
+
+
+def multi_copy(pairs):
+    """[(dst, src)] same-shape, same-dtype, contiguous GPU tensors -> ONE copy launch on the
+    current stream (chunks of 32); anything else falls back to `dst.copy_(src)`."""
+    fast = []
+    for dst, src in pairs:
+        if (dst.device.type == "cuda" and src.device == dst.device and dst.dtype == src.dtype
+                and dst.shape == src.shape and dst.is_contiguous() and src.is_contiguous()):
+            if dst.data_ptr() != src.data_ptr() and dst.numel():
+                fast.append((dst, src))
+        else:
+            dst.copy_(src, non_blocking=True)
+    if len(fast) == 1:
+        fast[0][0].copy_(fast[0][1], non_blocking=True)
+        return
+    for g0 in range(0, len(fast), 32):
+        chunk = fast[g0:g0 + 32]
+        arr = (_CopyItem * len(chunk))()
+        for slot, (dst, src) in zip(arr, chunk):
+            slot.dst, slot.src = dst.data_ptr(), src.data_ptr()
+            slot.bytes = dst.numel() * dst.element_size()
+        rc = _get().ecoflap_multi_copy(arr, len(chunk), _stream())
+        if rc != 0:
+            raise _hip.EcoflapHipError(f"ecoflap_multi_copy failed ({rc})")

@@ -46,6 +46,16 @@ int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias, in
 int ecoflap_vit_attention(const void* qkv, void* out, int64_t batch, int64_t tokens,
                           int64_t heads, int64_t head_dim, float scale, int dtype, void* stream);
 
+/* Up to ECOFLAP_COPY_MAX_ITEMS device-to-device copies (non-overlapping, any alignment) in
+ * one launch: the loop's state hand-overs between static graph buffers. */
+#define ECOFLAP_COPY_MAX_ITEMS 32
+typedef struct {
+    void* dst;
+    const void* src;
+    int64_t bytes;
+} ecoflap_copy_item;
+int ecoflap_multi_copy(const ecoflap_copy_item* items, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

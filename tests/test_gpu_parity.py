@@ -1465,6 +1465,28 @@ def test_vit_attention_kernel_vs_fp32_reference(B, N, H, D):
     assert torch.equal(alone[0], got[0])
 
 
+def test_multi_copy_one_launch_equals_copies():
+    """`ecoflap_multi_copy` (plumbing: a state's tensors handed over in one launch): every size /
+    alignment / dtype lands exactly, neighbours untouched; more than 32 pairs go out in chunks."""
+    from ecoflap_amd.shapes import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pairs, checks = [], []
+    sizes = [1, 7, 16, 17, 4096, 16384, 16385, 100003, 8 * 257 * 1408, 3]
+    for rep in range(4):
+        for i, n in enumerate(sizes):
+            dt = (torch.float16, torch.float32, torch.uint8, torch.int64)[(i + rep) % 4]
+            big = torch.zeros(n + 11, dtype=dt, device="cuda")
+            src_big = (torch.rand(n + 5, device="cuda", generator=g) * 100).to(dt)
+            off = (i + rep) % 5                        # misaligned views
+            dst, src = big[3:3 + n], src_big[off:off + n]
+            pairs.append((dst, src))
+            checks.append((big, dst, src.clone()))
+    fused.multi_copy(pairs)
+    for big, dst, want in checks:
+        assert torch.equal(dst, want)
+        assert int(big[:3].abs().sum()) == 0 and int(big[3 + dst.numel():].abs().sum()) == 0
+
+
 def test_eva_attention_module_takes_the_kernel_on_gpu_fp16():
     from ecoflap_amd.shapes.eva_vit import Attention
     torch.manual_seed(0)
