@@ -189,7 +189,8 @@ class PrefixCachedLoss:
 
     def __init__(self, model, kind="vision_language", batch_len_fn=None, use_graphs=False,
                  two_lanes=False, n_lanes=None, eval_batch=1, verify_batched="entries",
-                 group_batch=4, assume_not_invariant=(), pad_slots=2, batched_advance=True):
+                 group_batch=4, assume_not_invariant=(), pad_slots=2, batched_advance=True,
+                 batch_owner=True):
         self.model = model
         self.use_graphs = bool(use_graphs)
         # eval_batch = k > 1 (graphs only): k evaluations of a layer (theta+/theta- of k/2 units)
@@ -223,6 +224,17 @@ class PrefixCachedLoss:
         if os.environ.get("ECOFLAP_BATCHED_ADVANCE") == "0":       # A/B and end-to-end checks
             batched_advance = False
         self.batched_advance = bool(batched_advance) and self.use_graphs and self.eval_batch > 1
+        # batch_owner: the OWNING stage of the k evaluations also runs once, at batch k*B, with the
+        # perturbed Linear alone applied per slot (one GEMM per evaluation on that slot's rows,
+        # the same call as alone, its weight read straight from K1's scratch: no theta copies, no
+        # per-evaluation graph replays); eager launches (the patched Linear differs per matrix).
+        # Needs the shared pass to start right behind the owning stage; checked bit for bit
+        # against the per-evaluation path on first use of every stage.
+        if os.environ.get("ECOFLAP_BATCH_OWNER") == "0":           # A/B
+            batch_owner = False
+        self.batch_owner = bool(batch_owner) and self.use_graphs and self.eval_batch > 1
+        self._owner_ok = {}         # (family, entry) -> True / False once checked
+        self._owner_in = {}         # (family, entry, width) -> static concatenated input state
         self._fam_B = {}            # family -> batch length (learnt in `_batched`)
         self._adv_bad = set()       # (family, stage) whose batched advance once differed
         self._adv_pending = []      # queued bitwise checks of the batched advance
@@ -665,7 +677,11 @@ class PrefixCachedLoss:
         #    (odd evaluations on the second lane — weight replica, own stream, own graphs — when
         #    there is one: this part is latency-bound at batch B, two streams fill the device)
         outs = []
-        lanes = list(self.extra_lanes) if (self.extra_lanes and captured) else []
+        owner_done = False
+        if (self.batch_owner and captured and S == entry + 1 and width == k and len(evals) == k
+                and self._owner_ok.get((self._fam, entry), True)):
+            owner_done = self._batched_owner(entry, S, evals, states, B, bchain)
+        lanes = list(self.extra_lanes) if (self.extra_lanes and captured and not owner_done) else []
         main = torch.cuda.current_stream()
         for lane in lanes:
             lane.stream.wait_stream(main)        # K1's theta and the previous pass are complete
@@ -675,8 +691,10 @@ class PrefixCachedLoss:
         if g and captured:
             while R < S and self.invariant.get((self._fam, g, R), False):
                 R += 1
-        used_groups = R > entry + 1
-        if used_groups:
+        used_groups = R > entry + 1 and not owner_done
+        if owner_done:
+            evals_iter = []
+        elif used_groups:
             slot_in = bchain.graphs[S][1]
             todo = list(enumerate(zip(evals, states)))
             for gi, a in enumerate(range(0, len(todo), g)):
@@ -840,6 +858,71 @@ class PrefixCachedLoss:
                 self.eval_batch = 1
                 return self._sequential(model, evals, cuda_enabled)
         return losses
+
+    def _batched_owner(self, entry, S, evals, states, B, bchain):
+        """The owning stage of all k evaluations in ONE eager pass at batch k*B; the perturbed
+        Linear runs per slot on its own rows with its own theta (K1's scratch, no copy).  -> True
+        when the shared pass's input now holds the k results; False: the caller takes the
+        per-evaluation path (first-use check failed, or the Linear cannot be patched)."""
+        import torch.nn.functional as F
+        k = len(evals)
+        name = self._pair_name
+        if not name.endswith(".weight"):
+            return False
+        try:
+            mod = self.model.get_submodule(name[:-len(".weight")])
+        except AttributeError:
+            return False
+        if not isinstance(mod, torch.nn.Linear):
+            return False
+        fam = self._fam
+        key = (fam, entry, k)
+        cat_in = self._owner_in.get(key)
+        if cat_in is None:
+            self._owner_in.clear()               # one entry stage at a time: the previous one's buffers go
+            cat_in = self._owner_in[key] = _cat_states([st for _, st in states], B)
+        else:
+            pairs = []
+            for i, (_, st) in enumerate(states):
+                _gather_slot(cat_in, st, i, B, pairs)
+            _flush_copies(pairs)
+        thetas = [theta for _, theta in evals]
+
+        def per_slot(x):
+            rows = x.shape[0] // k
+            assert rows * k == x.shape[0], "the perturbed Linear's input is not batch-leading"
+            return torch.cat([F.linear(x[i * rows:(i + 1) * rows], thetas[i], mod.bias)
+                              for i in range(k)], 0)
+
+        had = "forward" in mod.__dict__
+        old = mod.__dict__.get("forward")
+        mod.forward = per_slot
+        try:
+            with torch.no_grad():
+                out = self.plan[entry][2](cat_in)
+        finally:
+            if had:
+                mod.forward = old
+            else:
+                del mod.forward
+        if (fam, entry) not in self._owner_ok:
+            # first use of this stage as an owner: one slot against the per-evaluation path
+            pick = self.stats.get("owner_checks", 0) % k
+            self._pair_home.copy_(thetas[pick])
+            alone = self.chain.run_stage(entry, states[pick][1])
+            fa, fb = [], []
+            _map_tensors(alone, lambda t: fa.append(t) or t)
+            _map_tensors(_slice_state(out, pick, B, k), lambda t: fb.append(t) or t)
+            same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
+                                              for x, y in zip(fa, fb))
+            self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
+            self._owner_ok[(fam, entry)] = same
+            if not same:
+                self.stats.setdefault("owner_not_batchable", []).append(self.plan[entry][0])
+                return False
+        _copy_tensors(bchain.graphs[S][1], out)
+        self.stats["owner_batched_evals"] = self.stats.get("owner_batched_evals", 0) + k
+        return True
 
     def _run_group(self, lane, entry, R, S, items, slot_in, B):
         """items = [(slot, theta, state)] (at most g): the owning stage per evaluation (its theta

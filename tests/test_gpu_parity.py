@@ -1383,6 +1383,11 @@ def test_batched_suffix_is_exact_at_full_size(kern, k_evals, lanes, force_groups
             assert "batched_disabled_at" not in loss.stats, loss.stats
             bad = loss.stats.get("stages_not_batch_invariant", [])
             assert not any(b.startswith("t5_model") for b in bad), bad
+            if not force_groups and k_evals == 16:
+                # the owning stage itself ran once per chunk (perturbed Linear per slot, theta
+                # straight from K1's scratch), checked against the per-evaluation path per stage
+                assert loss.stats.get("owner_batched_evals", 0) >= 16, loss.stats
+                assert not loss.stats.get("owner_not_batchable"), loss.stats
             if force_groups:
                 # ViT-g blocks declared not shareable at 16: their evaluations ran in groups of 4
                 assert loss.stats.get("grouped_evals", 0) >= k_evals, loss.stats
