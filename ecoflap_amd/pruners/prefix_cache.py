@@ -229,11 +229,11 @@ class PrefixCachedLoss:
         # the same call as alone, its weight read straight from K1's scratch: no theta copies, no
         # per-evaluation graph replays); eager launches (the patched Linear differs per matrix).
         # Needs the shared pass to start right behind the owning stage; checked bit for bit
-        # against the per-evaluation path on first use of every stage.
+        # against the per-evaluation path on first use for every matrix (one rotating slot).
         if os.environ.get("ECOFLAP_BATCH_OWNER") == "0":           # A/B
             batch_owner = False
         self.batch_owner = bool(batch_owner) and self.use_graphs and self.eval_batch > 1
-        self._owner_ok = {}         # (family, entry) -> True / False once checked
+        self._owner_ok = {}         # (family, matrix name) -> True / False once checked
         self._owner_in = {}         # (family, entry, width) -> static concatenated input state
         self._fam_B = {}            # family -> batch length (learnt in `_batched`)
         self._adv_bad = set()       # (family, stage) whose batched advance once differed
@@ -679,7 +679,7 @@ class PrefixCachedLoss:
         outs = []
         owner_done = False
         if (self.batch_owner and captured and S == entry + 1 and width == k and len(evals) == k
-                and self._owner_ok.get((self._fam, entry), True)):
+                and self._owner_ok.get((self._fam, self._pair_name), True)):
             owner_done = self._batched_owner(entry, S, evals, states, B, bchain)
         lanes = list(self.extra_lanes) if (self.extra_lanes and captured and not owner_done) else []
         main = torch.cuda.current_stream()
@@ -888,10 +888,13 @@ class PrefixCachedLoss:
             _flush_copies(pairs)
         thetas = [theta for _, theta in evals]
 
+        class _NotBatchLeading(Exception):
+            pass
+
         def per_slot(x):
-            rows = x.shape[0] // k
-            assert rows * k == x.shape[0], "the perturbed Linear's input is not batch-leading"
-            return torch.cat([F.linear(x[i * rows:(i + 1) * rows], thetas[i], mod.bias)
+            if x.shape[0] != k * B:              # the Linear's input must carry the k slots in front
+                raise _NotBatchLeading()
+            return torch.cat([F.linear(x[i * B:(i + 1) * B], thetas[i], mod.bias)
                               for i in range(k)], 0)
 
         had = "forward" in mod.__dict__
@@ -900,13 +903,17 @@ class PrefixCachedLoss:
         try:
             with torch.no_grad():
                 out = self.plan[entry][2](cat_in)
+        except _NotBatchLeading:
+            self._owner_ok[(fam, name)] = False
+            self.stats.setdefault("owner_not_batchable", []).append(name)
+            return False
         finally:
             if had:
                 mod.forward = old
             else:
                 del mod.forward
-        if (fam, entry) not in self._owner_ok:
-            # first use of this stage as an owner: one slot against the per-evaluation path
+        if (fam, name) not in self._owner_ok:
+            # first use of this MATRIX's per-slot form: one slot against the per-evaluation path
             pick = self.stats.get("owner_checks", 0) % k
             self._pair_home.copy_(thetas[pick])
             alone = self.chain.run_stage(entry, states[pick][1])
@@ -916,9 +923,9 @@ class PrefixCachedLoss:
             same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
                                               for x, y in zip(fa, fb))
             self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
-            self._owner_ok[(fam, entry)] = same
+            self._owner_ok[(fam, name)] = same
             if not same:
-                self.stats.setdefault("owner_not_batchable", []).append(self.plan[entry][0])
+                self.stats.setdefault("owner_not_batchable", []).append(name)
                 return False
         _copy_tensors(bchain.graphs[S][1], out)
         self.stats["owner_batched_evals"] = self.stats.get("owner_batched_evals", 0) + k
