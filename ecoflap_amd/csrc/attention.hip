@@ -343,8 +343,9 @@ extern "C" int ecoflap_vit_attention(const void* qkv, void* out, int64_t batch, 
     a.kpitch = kp;
     a.scale_log2e = scale * 1.4426950408889634f;
     {
-        const char* dbg = getenv("ECOFLAP_ATTN_DEBUG");
-        a.debug = dbg ? atoi(dbg) : 0;
+        // phase-ablation switches of tools/attention_launches.py (read once; 0 in production)
+        static const int debug = [] { const char* d = getenv("ECOFLAP_ATTN_DEBUG"); return d ? atoi(d) : 0; }();
+        a.debug = debug;
     }
     // one persistent workgroup per CU (its LDS image allows no second one) walking the items
     int64_t grid = batch * heads;
