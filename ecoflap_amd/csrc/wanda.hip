@@ -620,57 +620,6 @@ static __device__ __forceinline__ uint32_t wave_count_hi16_ge(const uint32_t (&x
     return wave_sum_dpp(cnt);
 }
 
-// Search state of the high-16-bit threshold: f(c) = #(hi16(m) < c) is monotone, wanted
-// max{c : f(c) < k}, invariant f(lo) < k <= f(hi).  ANY probe strictly inside (lo, hi) keeps the
-// result exact, so the probes are chosen for speed: the metrics of a row crowd the few binades under
-// its maximum (a binade = 128 codes), so the first probes try the windows 512 and 2048 codes under
-// the maximum, then a regula falsi on the counts with the Illinois safeguard (the weight of an
-// end kept twice in a row is halved) — 5-8 probes on weight-like rows instead of the 14 of a
-// bisection from zero (tools: simulation in DESIGN.md section 9's notes); ties fall back towards
-// bisection by themselves.
-struct Hi16Search {
-    uint32_t lo, flo, hi, fhi;
-    float wl, wh;
-    int side, pre;
-};
-static __device__ __forceinline__ Hi16Search hi16_search_init(uint32_t mx, uint32_t all_count, uint32_t cols) {
-    Hi16Search s;
-    const uint32_t mx16 = mx >> 16;
-    s.lo = 0; s.flo = 0; s.hi = 65536u; s.fhi = all_count;
-    if (mx16 < 0xffffu) { s.hi = mx16 + 1; s.fhi = cols; }       // every real element is below
-    s.wl = 1.0f; s.wh = 1.0f; s.side = 0; s.pre = 0;
-    return s;
-}
-static __device__ __forceinline__ uint32_t hi16_search_probe(Hi16Search& s, uint32_t k) {
-    const uint32_t span = s.hi - s.lo;
-    uint32_t mid;
-    if (s.pre == 0 && s.lo == 0 && span > 640u) { s.pre = 1; mid = s.hi - 513u; }
-    else if (s.pre == 1 && s.lo == 0 && span > 1792u) { s.pre = 2; mid = s.hi - 1537u; }
-    else {
-        s.pre = 3;
-        if (span <= 4u || s.fhi <= s.flo) {
-            mid = (s.lo + s.hi) >> 1;
-        } else {
-            const float a = (float)(k - s.flo) * s.wl, b = (float)(s.fhi - k) * s.wh + 0.5f;
-            const float t = a / (a + b);
-            mid = s.lo + (uint32_t)(t * (float)span);
-            mid = mid <= s.lo ? s.lo + 1u : (mid >= s.hi ? s.hi - 1u : mid);
-        }
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)mid);
-}
-static __device__ __forceinline__ void hi16_search_update(Hi16Search& s, uint32_t mid, uint32_t fm, uint32_t k) {
-    if (fm < k) {
-        s.lo = mid; s.flo = fm;
-        if (s.pre == 3) { s.wl = 1.0f; s.wh = s.side > 0 ? s.wh * 0.5f : 1.0f; }
-        s.side = 1;
-    } else {
-        s.hi = mid; s.fhi = fm;
-        if (s.pre == 3) { s.wh = 1.0f; s.wl = s.side < 0 ? s.wl * 0.5f : 1.0f; }
-        s.side = -1;
-    }
-}
-
 // sum (or max) of one wave-uniform value per wave over the workgroup's four waves, result uniform:
 // lane 0 of each wave writes its value, one barrier (double-buffered by call parity), four reads
 static __device__ __forceinline__ uint32_t block_sum4(uint32_t wave_value, uint32_t* lds8, int phase,
@@ -755,16 +704,17 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
             gather_hi16(m, xh);
 #pragma unroll
             for (int w = 0; w < WH; ++w) xg[w] = xh[w] | 0x80008000u;
-            Hi16Search hs = hi16_search_init(mx, ALL, (uint32_t)cols);
-            while (hs.hi - hs.lo > 1) {
-                const uint32_t mid = hi16_search_probe(hs, (uint32_t)k);
-                const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(
-                    ALL - block_sum4(wave_count_hi16_ge<WH, true>(xh, xg, mid), lds8, phase++, wave, lane)));
-                hi16_search_update(hs, mid, fm, (uint32_t)k);
+            const uint32_t mx16 = mx >> 16;
+            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t fm = ALL - block_sum4(wave_count_hi16_ge<WH, true>(xh, xg, mid), lds8, phase++, wave, lane);
+                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
             }
-            prefix = hs.lo << 16;
-            less16 = hs.flo;
-            ncand = hs.fhi - hs.flo;
+            prefix = lo << 16;
+            less16 = flo;
+            ncand = fhi - flo;
         }
         if (ncand <= 128) {                               // block-uniform
             // compact the bucket's elements; ONE wave finishes the low 16 bits on them with
@@ -959,16 +909,17 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
             }
             // f(c) = #(hi16(m) < c) is monotone; wanted: p16 = max{c : f(c) < k}.  Bisection on
             // [lo, hi] with f(lo) < k <= f(hi); the last two values give the bucket's population
-            Hi16Search hs = hi16_search_init(mx, ALL, (uint32_t)cols);
-            while (hs.hi - hs.lo > 1) {
-                const uint32_t mid = hi16_search_probe(hs, (uint32_t)k);
-                const uint32_t fm = (uint32_t)__builtin_amdgcn_readfirstlane(
-                    (int)(ALL - wave_count_hi16_ge<WH, KEEPG>(xh, xg, mid)));
-                hi16_search_update(hs, mid, fm, (uint32_t)k);
+            const uint32_t mx16 = mx >> 16;
+            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }   // every real element is below
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t fm = ALL - wave_count_hi16_ge<WH, KEEPG>(xh, xg, mid);
+                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
             }
-            prefix = hs.lo << 16;
-            less16 = hs.flo;
-            ncand = hs.fhi - hs.flo;
+            prefix = lo << 16;
+            less16 = flo;
+            ncand = fhi - flo;
         }
         constexpr uint32_t CMAX = 2;             // candidates per lane
         if (ncand <= 64 * CMAX) {                // wave-uniform
