@@ -560,40 +560,60 @@ class LayerSparsity:
         # the captured graph bakes in the parameters' storage addresses and the loss closure:
         # a re-pointed `param.data` (model_reset's .type(), the non-static K1 forms) or another
         # loss_func must not replay it
+        n_lanes = max(1, min(int(getattr(self, "grad_lanes", 3)), len(todo)))
         key = (next(iter(sigs)), tuple((id(p), p.data_ptr()) for p in params), id(self.loss_func),
-               id(self.model))
+               id(self.model), n_lanes)
         cache = getattr(self, "_grad_graph_cache", None)
         if cache is None or cache[0] != key:
             first = todo[0]
-            static = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}
-                      if isinstance(first, dict) else
-                      type(first)(v.clone() if torch.is_tensor(v) else v for v in first))
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):             # warm-up off the capture, as torch asks
-                for _ in range(2):
-                    loss, batch_len = self.loss_func(model, static, cuda_enabled)
-                    torch.autograd.grad(loss, params)
-            torch.cuda.current_stream().wait_stream(side)
-            if batch_len != self.batch_len_fn(first):
-                raise RuntimeError("loss_func batch_len differs from batch_len_fn")
-            graph = torch.cuda.CUDAGraph()
-            with capture_graph(graph, capture_error_mode="thread_local"):
-                loss, _ = self.loss_func(model, static, cuda_enabled)
-                grads = torch.autograd.grad(loss, params)
-            assert len(grads) == len(params)
-            # the graph reads the parameters in place: later rounds (Real-*: pruned weights in
-            # the same storage) replay it as is
-            self._grad_graph_cache = cache = (key, graph, static, grads)
-            self.stats_grad_graph = {"captured": 0, "replays": 0}
-            self.stats_grad_graph["captured"] += 1
-        _, graph, static, grads = cache
-        for d in todo:
-            for dst, src in zip(tensors_of(static), tensors_of(d)):
-                dst.copy_(src, non_blocking=True)
-            graph.replay()
+            main = torch.cuda.current_stream()
+            lanes = []
+            self.stats_grad_graph = {"captured": 0, "replays": 0, "lanes": n_lanes}
+            for li in range(n_lanes):
+                # one captured forward + backward per lane, each on its own stream with its own
+                # static inputs and gradient buffers: the batch-1 graph is latency-bound
+                # (thousands of 5-10 us kernels), several of them in flight fill the device
+                static = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in first.items()}
+                          if isinstance(first, dict) else
+                          type(first)(v.clone() if torch.is_tensor(v) else v for v in first))
+                stream = torch.cuda.Stream()
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream):       # warm-up off the capture, as torch asks
+                    for _ in range(2 if li == 0 else 1):
+                        loss, batch_len = self.loss_func(model, static, cuda_enabled)
+                        torch.autograd.grad(loss, params)
+                stream.synchronize()
+                if batch_len != self.batch_len_fn(first):
+                    raise RuntimeError("loss_func batch_len differs from batch_len_fn")
+                graph = torch.cuda.CUDAGraph()
+                with capture_graph(graph, stream=stream, capture_error_mode="thread_local"):
+                    loss, _ = self.loss_func(model, static, cuda_enabled)
+                    grads = torch.autograd.grad(loss, params)
+                assert len(grads) == len(params)
+                lanes.append((graph, static, grads, stream))
+                self.stats_grad_graph["captured"] += 1
+            # the graphs read the parameters in place: later rounds (Real-*: pruned weights in
+            # the same storage) replay them as they are
+            self._grad_graph_cache = cache = (key, lanes)
+        _, lanes = cache
+        main = torch.cuda.current_stream()
+        in_flight = []
+        for i, d in enumerate(todo):
+            graph, static, grads, stream = lanes[i % len(lanes)]
+            stream.wait_stream(main)      # the consumer of this lane's previous gradients is queued on `main`
+            with torch.cuda.stream(stream):
+                for dst, src in zip(tensors_of(static), tensors_of(d)):
+                    dst.copy_(src, non_blocking=True)
+                graph.replay()
             self.stats_grad_graph["replays"] += 1
-            yield d, grads
+            in_flight.append((d, grads, stream))
+            if len(in_flight) == len(lanes):          # oldest first: batch order is kept
+                d0, g0, s0 = in_flight.pop(0)
+                main.wait_stream(s0)
+                yield d0, g0
+        for d0, g0, s0 in in_flight:
+            main.wait_stream(s0)
+            yield d0, g0
 
     def _reduce_pairs(self, params, grads, mode, sums):
         """sums[l] += sum_e f(W_l, g_l): one multi-tensor launch per dtype class."""
