@@ -560,7 +560,9 @@ class LayerSparsity:
         # the captured graph bakes in the parameters' storage addresses and the loss closure:
         # a re-pointed `param.data` (model_reset's .type(), the non-static K1 forms) or another
         # loss_func must not replay it
-        n_lanes = max(1, min(int(getattr(self, "grad_lanes", 3)), len(todo)))
+        import os
+        n_lanes = max(1, min(int(os.environ.get("ECOFLAP_GRAD_LANES", getattr(self, "grad_lanes", 3))),
+                             len(todo)))
         key = (next(iter(sigs)), tuple((id(p), p.data_ptr()) for p in params), id(self.loss_func),
                id(self.model), n_lanes)
         cache = getattr(self, "_grad_graph_cache", None)
