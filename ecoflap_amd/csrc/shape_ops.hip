@@ -257,3 +257,51 @@ extern "C" int ecoflap_multi_copy(const ecoflap_copy_item* items, int n, void* s
     ECO_CHECK_LAUNCH();
     return 0;
 }
+
+// Bitwise comparison of several tensor pairs in ONE launch (the loop's exactness checks compare
+// whole states: a compare + an and-reduce kernel per tensor before): any differing byte sets
+// *flag (never cleared here).  Same grouping as multi_copy_kernel.
+__global__ __launch_bounds__(256) void multi_compare_kernel(const CopyGroup g, int* __restrict__ flag) {
+    int it = 0;
+    while (it + 1 < g.n && (int)blockIdx.x >= g.start[it + 1]) ++it;
+    const int64_t off = (int64_t)(blockIdx.x - g.start[it]) * COPY_CHUNK;
+    int64_t len = g.bytes[it] - off;
+    if (len > COPY_CHUNK) len = COPY_CHUNK;
+    const char* a = (const char*)g.dst[it] + off;
+    const char* b = (const char*)g.src[it] + off;
+    bool diff = false;
+    if (((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0) {
+        const int64_t nv = len >> 4;
+        for (int64_t v = threadIdx.x; v < nv; v += 256) {
+            const u32x4 x = ((const u32x4*)a)[v], y = ((const u32x4*)b)[v];
+            diff |= (x[0] != y[0]) | (x[1] != y[1]) | (x[2] != y[2]) | (x[3] != y[3]);
+        }
+        for (int64_t i = (nv << 4) + threadIdx.x; i < len; i += 256) diff |= a[i] != b[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += 256) diff |= a[i] != b[i];
+    }
+    if (__ballot(diff) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_flag,
+                                     void* stream) {
+    if (n < 0 || n > ECOFLAP_COPY_MAX_ITEMS) return ECOFLAP_ESIZE;
+    if (n == 0) return 0;
+    if (!items || !mismatch_flag) return ECOFLAP_ENULL;
+    CopyGroup g;
+    g.n = 0;
+    g.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].bytes < 0) return ECOFLAP_ESIZE;
+        if (items[i].bytes == 0) continue;
+        if (!items[i].dst || !items[i].src) return ECOFLAP_ENULL;
+        const int z = g.n++;
+        g.dst[z] = items[i].dst; g.src[z] = items[i].src; g.bytes[z] = items[i].bytes;
+        g.start[z + 1] = g.start[z] + (int32_t)((items[i].bytes + COPY_CHUNK - 1) / COPY_CHUNK);
+    }
+    if (g.n == 0) return 0;
+    hipLaunchKernelGGL(multi_compare_kernel, dim3((unsigned)g.start[g.n]), dim3(256), 0,
+                       (hipStream_t)stream, g, mismatch_flag);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}

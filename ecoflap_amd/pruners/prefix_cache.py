@@ -67,6 +67,23 @@ def _flush_copies(pairs):
         d.copy_(s_, non_blocking=True)
 
 
+def _differ_flag(fa, fb, flag=None):
+    """int32[1] device flag, non-zero when the tensor lists differ in any BIT (one fused launch
+    per 32 tensors instead of an eq + an and-reduce kernel per tensor; nothing is read back
+    here).  Bitwise is the right notion for these checks: -0.0 vs 0.0 counts as different."""
+    dev = fa[0].device if fa else torch.device("cpu")
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    if len(fa) != len(fb):
+        return flag.fill_(1)
+    if dev.type != "cuda":           # host tensors (the CPU test doubles): plain torch
+        if not all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(fa, fb)):
+            flag.fill_(1)
+        return flag
+    from ..shapes import fused
+    return fused.multi_compare(list(zip(fa, fb)), flag)
+
+
 def _gather_copies(dst, src, out):
     if torch.is_tensor(dst):
         out.append((dst, src))
@@ -364,10 +381,11 @@ class PrefixCachedLoss:
         bad = False
         import time
         t0 = time.time()
-        for fam, j, fa, fb in pending:
-            same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
-                                              for x, y in zip(fa, fb))
-            if not same:
+        # one fused bitwise-compare launch per check (shapes.fused.multi_compare), ONE read-back
+        flags = [_differ_flag(fa, fb) for _, _, fa, fb in pending]
+        verdict = torch.cat(flags).cpu().tolist() if flags else []
+        for (fam, j, fa, fb), differs in zip(pending, verdict):
+            if differs:
                 self._adv_bad.add((fam, j))
                 self.stats["advance_mismatch_at"] = self.plan[j][0]
                 bad = True
@@ -559,16 +577,14 @@ class PrefixCachedLoss:
             g = self.group_batch if 1 < self.group_batch < k else 0
 
             def slots_equal(both, outs_, width):
-                flat_a = []
+                flat_a, flag = [], None
                 for i, o in enumerate(outs_):
                     got = _slice_state(both, i, B, width)
                     flat_a, flat_b = [], []
                     _map_tensors(o, lambda t: flat_a.append(t) or t)
                     _map_tensors(got, lambda t: flat_b.append(t) or t)
-                    if len(flat_a) != len(flat_b) or not all(
-                            a.shape == b_.shape and torch.equal(a, b_) for a, b_ in zip(flat_a, flat_b)):
-                        return False, flat_a
-                return True, flat_a
+                    flag = _differ_flag(flat_a, flat_b, flag if i else None)
+                return not bool(flag.item()), flat_a
 
             for j in range(entry + 1, n - 1):
                 outs = [self.plan[j][2](x) for x in ins]
@@ -920,8 +936,7 @@ class PrefixCachedLoss:
             fa, fb = [], []
             _map_tensors(alone, lambda t: fa.append(t) or t)
             _map_tensors(_slice_state(out, pick, B, k), lambda t: fb.append(t) or t)
-            same = len(fa) == len(fb) and all(x.shape == y.shape and torch.equal(x, y)
-                                              for x, y in zip(fa, fb))
+            same = not bool(_differ_flag(fa, fb).item())
             self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
             self._owner_ok[(fam, name)] = same
             if not same:

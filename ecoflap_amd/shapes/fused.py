@@ -32,6 +32,7 @@ def _get():
         lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_vit_attention.argtypes = [vp, vp, i64, i64, i64, i64, f32, ci, vp]
         lib.ecoflap_multi_copy.argtypes = [vp, ci, vp]
+        lib.ecoflap_multi_compare.argtypes = [vp, ci, vp, vp]
         _lib = lib
     return _lib
 
@@ -172,3 +173,34 @@ def multi_copy(pairs):
         rc = _get().ecoflap_multi_copy(arr, len(chunk), _stream())
         if rc != 0:
             raise _hip.EcoflapHipError(f"ecoflap_multi_copy failed ({rc})")
+
+
+def multi_compare(pairs, flag=None):
+    """Bitwise `a == b` for all (a, b) pairs (same shape / dtype, contiguous, on the GPU) in one
+    launch per 32 pairs -> int32 device tensor, non-zero when ANY pair differs (pass `flag` to
+    accumulate several calls into one read-back).  Shape / dtype mismatches count as different."""
+    dev = None
+    for a, b in pairs:
+        dev = a.device
+        break
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=dev if dev is not None else "cuda")
+    fast = []
+    for a, b in pairs:
+        if a.shape != b.shape or a.dtype != b.dtype:
+            flag.fill_(1)
+            continue
+        if not (a.is_contiguous() and b.is_contiguous()):
+            a, b = a.contiguous(), b.contiguous()
+        if a.numel():
+            fast.append((a, b))
+    for g0 in range(0, len(fast), 32):
+        chunk = fast[g0:g0 + 32]
+        arr = (_CopyItem * len(chunk))()
+        for slot, (a, b) in zip(arr, chunk):
+            slot.dst, slot.src = a.data_ptr(), b.data_ptr()
+            slot.bytes = a.numel() * a.element_size()
+        rc = _get().ecoflap_multi_compare(arr, len(chunk), flag.data_ptr(), _stream())
+        if rc != 0:
+            raise _hip.EcoflapHipError(f"ecoflap_multi_compare failed ({rc})")
+    return flag

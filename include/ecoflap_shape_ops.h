@@ -55,6 +55,9 @@ typedef struct {
     int64_t bytes;
 } ecoflap_copy_item;
 int ecoflap_multi_copy(const ecoflap_copy_item* items, int n, void* stream);
+/* Bitwise comparison of up to ECOFLAP_COPY_MAX_ITEMS pairs (dst vs src of each item) in one
+ * launch: *mismatch_flag |= 1 when any byte differs (the caller zeroes it). */
+int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1540,6 +1540,47 @@ def test_multi_copy_one_launch_equals_copies():
         assert int(big[:3].abs().sum()) == 0 and int(big[3 + dst.numel():].abs().sum()) == 0
 
 
+def test_multi_compare_flags_any_differing_bit():
+    """`ecoflap_multi_compare` (plumbing: the loop's exactness checks in one launch): equal lists
+    -> 0; one flipped bit anywhere (first / last byte, misaligned views, the 33rd pair) -> 1; the
+    flag accumulates over calls; -0.0 vs 0.0 differs (bitwise), NaN == the same NaN."""
+    from ecoflap_amd.shapes import fused
+    g = torch.Generator(device="cuda").manual_seed(4)
+    sizes = [1, 7, 16, 17, 4096, 16385, 100003, 4 * 257 * 1408, 3]
+
+    def build():
+        pairs = []
+        for rep in range(4):
+            for i, n in enumerate(sizes):
+                dt = (torch.float16, torch.float32, torch.uint8, torch.int64)[(i + rep) % 4]
+                a_big = (torch.rand(n + 7, device="cuda", generator=g) * 100).to(dt)
+                off = (i + rep) % 5
+                a = a_big[off:off + n]
+                b = torch.empty(n + 3, dtype=dt, device="cuda")[3:]
+                b.copy_(a)
+                pairs.append((a, b))
+        return pairs
+
+    pairs = build()
+    assert len(pairs) > 32
+    assert int(fused.multi_compare(pairs)) == 0
+    for which, pos in ((0, 0), (5, -1), (7, 12345), (len(pairs) - 1, -1), (33, 0)):
+        pairs = build()
+        a, b = pairs[which]
+        raw = b.view(torch.uint8) if b.dtype != torch.uint8 else b
+        raw[pos] ^= 1
+        assert int(fused.multi_compare(pairs)) == 1, (which, pos)
+        assert not torch.equal(a, b)
+    flag = fused.multi_compare(build())
+    z = torch.zeros(64, device="cuda")
+    fused.multi_compare([(z, -z)], flag)
+    assert int(flag) == 1                          # accumulated; -0.0 is a different bit pattern
+    nan = torch.full((100,), float("nan"), device="cuda")
+    assert int(fused.multi_compare([(nan, nan.clone())])) == 0
+    assert int(fused.multi_compare([(z, z[:32])])) == 1    # shape mismatch
+    assert int(fused.multi_compare([])) == 0
+
+
 def test_eva_attention_module_takes_the_kernel_on_gpu_fp16():
     from ecoflap_amd.shapes.eva_vit import Attention
     torch.manual_seed(0)
