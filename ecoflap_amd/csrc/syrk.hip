@@ -13,10 +13,20 @@
 // transposed through LDS so both triangles stay filled for the factorisations that follow.
 //   1. syrk_transpose_kernel: X[T, C] -> Xt[C, Kpad] (k contiguous, zero padded to a multiple of
 //      64), so that BOTH operand fragments of Xt * Xt^T are 16-byte row reads.
+//      (syrk_transpose8_kernel for C % 8 == 0: 16-byte loads and stores, two rows paired in
+//      registers so the LDS traffic is dwords — 186 -> 85 us at [16448, 6144]).
 //   2. syrk_kernel: one workgroup (4 waves, 2x2, 64x64 each = 2x2 MFMA tiles) per tile pair,
 //      K in chunks of 64 staged through LDS (rows padded to 144 B: conflict-free ds_read_b128).
+//      Few tiles and long K (C = 1408 at 8 samples per call: 66 tiles of 128 for 256 CUs): 4
+//      K-slices (blockIdx.y) into partial buffers + syrk_combine_kernel (slice order).
+//   3. syrk256_kernel (C > 5632, Kpad >= 4096): 256-wide tiles, 128x128 per wave, one persistent
+//      workgroup per CU; the tiles beyond a whole round are cut into K-slices whose fp32 slabs the
+//      last slice to arrive (ticket) adds up in slice order.
+// Every path sums in a fixed order: the same call gives the same bits, whoever finishes last.
 // MFMA roofline: 2 * T * C * (C + 128) / 2 flops per call against the dense fp16/bf16 peak.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 #define SY_TILE 128
 #define SY_KC 64
@@ -25,6 +35,8 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // X[T, C] (16-bit) -> Xt[C, Kpad], 64x64 tiles through LDS; columns T..Kpad-1 are zero
 __global__ __launch_bounds__(256) void syrk_transpose_kernel(const uint16_t* __restrict__ x,
@@ -44,6 +56,41 @@ __global__ __launch_bounds__(256) void syrk_transpose_kernel(const uint16_t* __r
     }
 }
 
+// The same for C % 8 == 0 (every shape of the models): 16-byte loads along c and 16-byte stores
+// along t — two rows (t, t + 1) are paired in registers, so the LDS traffic is whole dwords
+// (tile[c][t / 2], 33 dwords per row: 2-way conflicts on the writes, none on the reads).
+__global__ __launch_bounds__(256) void syrk_transpose8_kernel(const uint16_t* __restrict__ x,
+                                                              int64_t T, int64_t C, int64_t Kpad,
+                                                              uint16_t* __restrict__ xt) {
+    __shared__ uint32_t tile[64 * 33];
+    const int64_t c0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    {
+        const int p = tid >> 3, cs = tid & 7;                 // rows t0 + 2p, t0 + 2p + 1; columns c0 + 8 cs ..
+        const int64_t t = t0 + 2 * p, c = c0 + 8 * cs;
+        u32x4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+        if (c < C) {
+            if (t < T) lo = *(const u32x4*)(x + t * C + c);
+            if (t + 1 < T) hi = *(const u32x4*)(x + (t + 1) * C + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                          // columns 2j, 2j + 1 of the eight
+            tile[(8 * cs + 2 * j) * 33 + p] = __builtin_amdgcn_perm(hi[j], lo[j], 0x05040100u);
+            tile[(8 * cs + 2 * j + 1) * 33 + p] = __builtin_amdgcn_perm(hi[j], lo[j], 0x07060302u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int cr = (tid >> 3) + 32 * half, ts = tid & 7;   // row c0 + cr of Xt, t0 + 8 ts ..
+        const int64_t c = c0 + cr, t = t0 + 8 * ts;
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = tile[cr * 33 + 4 * ts + i];
+        if (c < C && t < Kpad) *(u32x4*)(xt + c * Kpad + t) = v;
+    }
+}
+
 template <int DT> struct Mfma;
 template <> struct Mfma<ECOFLAP_F16> {
     static __device__ __forceinline__ f32x16 run(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -60,10 +107,15 @@ template <> struct Mfma<ECOFLAP_BF16> {
 
 // WT = MFMA tiles per wave and dimension: workgroup tile = 64*WT (128 for large C; 64 when the
 // 128-tile grid would leave most of the 256 CUs idle, e.g. C = 1408 -> 66 tiles)
+// blockIdx.y = K-slice (few tiles, long K — C = 1408 with 8 samples per call: 66 tiles for 256 CUs):
+// slice y covers k in [y * kslice, min(Kpad, (y + 1) * kslice)) and writes alpha * X_y^T X_y to
+// H + y * hstride (the caller passes beta = 0 and a partial buffer per slice; syrk_combine_kernel adds
+// them up in slice order).  One slice: kslice = Kpad, hstride = 0.
 template <int DT, int WT>
 __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ xt, int64_t C,
                                                    int64_t Kpad, float* __restrict__ H, float beta,
-                                                   float alpha, int ntiles) {
+                                                   float alpha, int ntiles, int64_t kslice,
+                                                   int64_t hstride) {
     constexpr int TILE = 64 * WT;
     constexpr int LD_PER_THREAD = TILE * 8 / 256;       // 16-byte loads per thread and operand
     __shared__ __attribute__((aligned(16))) char lds[2 * SY_TILE * SY_ROWB];
@@ -104,8 +156,11 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
             if (rowB0 + row < C) rb[i] = *(const u32x4*)(xt + (rowB0 + row) * Kpad + k0 + seg * 8);
         }
     };
-    fetch(0);
-    for (int64_t k0 = 0; k0 < Kpad; k0 += SY_KC) {
+    const int64_t kbeg = (int64_t)blockIdx.y * kslice;
+    const int64_t kend = kbeg + kslice < Kpad ? kbeg + kslice : Kpad;
+    H += (int64_t)blockIdx.y * hstride;
+    fetch(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += SY_KC) {
 #pragma unroll
         for (int i = 0; i < LD_PER_THREAD; ++i) {
             const int idx = tid + 256 * i, row = idx >> 3, seg = idx & 7;
@@ -113,7 +168,7 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
             *(u32x4*)(ldsB + row * SY_ROWB + seg * 16) = rb[i];
         }
         __syncthreads();
-        if (k0 + SY_KC < Kpad) fetch(k0 + SY_KC);
+        if (k0 + SY_KC < kend) fetch(k0 + SY_KC);
 #pragma unroll
         for (int kk = 0; kk < SY_KC / 16; ++kk) {
             u32x4 a[WT], b[WT];
@@ -172,11 +227,346 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
     }
 }
 
+// ---- 256x256 tiles (C >= 2048): 4 waves 2x2, each 128x128 = 4x4 MFMA tiles.  With 2x2 tiles per
+// wave (the kernel above) every k-step of 4 MFMAs needs 4 ds_read_b128 — at 4 waves per CU the
+// LDS is as busy as the matrix cores and the loop tops out near 560 TFLOP/s; 4x4 tiles need 8
+// reads for 16 MFMAs.  One workgroup per CU (256 accumulator registers per lane), so the latency
+// hiding is explicit: K in stages of 32, DMA'd global -> LDS (`global_load_lds_dwordx4`, no
+// registers) into FOUR stage buffers of 2 x 16 KB, three stages in flight, counted vmcnt (never
+// drained inside the loop); the MFMA operands of k-step j+1 are read from LDS while the 16 MFMAs
+// of step j run (two register sets, scheduling barriers keep the compiler from folding them).
+// LDS rows are 64 B without padding (a DMA piece is 1 KiB contiguous = 16 rows), the 16-byte
+// k-segment s of row rho sits in slot s ^ ((rho >> 2) & 3): each of ds_read_b128's 16-lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) then covers all 64 banks once.  The swizzle is
+// applied on the GLOBAL side of the DMA (the lane that fills slot p fetches segment p ^ swz).
+#define S2_T 256
+#define S2_KC 32
+#define S2_OPB (S2_T * S2_KC * 2)      // bytes per operand and stage (16 KB)
+#define S2_STG (2 * S2_OPB)
+#define S2_NBUF 2
+#define S2_MIN_COLS 5633   // 256-wide tiles when there are more of them than CUs (MI355X: C > 22 * 256); below, the kernel above
+
+// Work split of one call: the chip runs `G` workgroups (one per CU), the upper triangle has
+// `ntiles` tiles.  `full` = the largest multiple of G tiles are computed whole, one round each;
+// the `left` tiles that would make a nearly empty extra round (C = 6144: 300 tiles on 256 CUs)
+// are cut into `S` K-slices each, one slice per workgroup ahead of its whole tile: the last slice
+// of a tile to finish (ticket) sums the S fp32 slabs IN SLICE ORDER and writes the tile — the
+// result does not depend on who arrives when.
+struct Syrk256Plan {
+    int ntiles, full, left, S, G;
+    float* slabs;            // [left * S][256 * 256] fp32, lane-linear (see s2_slab)
+    unsigned* tickets;       // [left] + 1 (the work counter), zeroed ahead of the launch
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict__ xt, int64_t C,
+                                                      int64_t Kpad, float* __restrict__ H,
+                                                      float beta, float alpha, Syrk256Plan P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[S2_NBUF * S2_STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int nst_all = (int)(Kpad / S2_KC), npairs = nst_all / 2;
+    // this workgroup's items: its slice (if any), then its whole tiles (XCD x = blockIdx % 8 takes a
+    // contiguous range of the column-major tile order: neighbours share panels in ITS L2).  (Tried:
+    // handing the items out through a counter, 8 slices per left-over tile: slower, the slabs'
+    // hand-off costs more than the better balance returns; write-through slab stores instead of
+    // the release fence: 40 % slower.)
+    const int b = (int)blockIdx.x;
+    const int nslices = P.left * P.S;
+    const int per = (P.G + 7) / 8;
+    const int bperm = (b % 8) * per + b / 8;              // a permutation of 0..G-1 when G % 8 == 0
+    for (int item = b < nslices ? -1 : 0;; ++item) {
+        int t, st0 = 0, st1 = nst_all, slab = -1;
+        if (item < 0) {
+            t = P.full + b / P.S;
+            const int sl = b % P.S;
+            st0 = 2 * (int)((int64_t)sl * npairs / P.S);
+            st1 = 2 * (int)((int64_t)(sl + 1) * npairs / P.S);
+            slab = b;
+        } else {
+            t = item * P.G + (P.G % 8 == 0 ? bperm : b);
+            if (t >= P.full) break;
+        }
+        int bj = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((bj + 1) * (bj + 2) / 2 <= t) ++bj;
+        while (bj * (bj + 1) / 2 > t) --bj;
+        const int bi = t - bj * (bj + 1) / 2;
+        const int64_t rowA0 = (int64_t)bi * S2_T, rowB0 = (int64_t)bj * S2_T;
+
+        // global -> LDS image: piece p (16 rows x 64 B) of an operand goes to wave p & 3; lane -> row
+        // 16 p + (lane >> 2), slot lane & 3, which holds segment slot ^ ((row >> 2) & 3)
+        const int q = lane >> 2;
+        const int seg = (lane & 3) ^ ((lane >> 4) & 3);
+        const uint16_t* pa[4];
+        const uint16_t* pb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t ra = rowA0 + 16 * (wave + 4 * i) + q, rb = rowB0 + 16 * (wave + 4 * i) + q;
+            ra = ra < C ? ra : C - 1;            // rows past C: any valid row (their products are dropped)
+            rb = rb < C ? rb : C - 1;
+            pa[i] = xt + ra * Kpad + seg * 8;
+            pb[i] = xt + rb * Kpad + seg * 8;
+        }
+        // (a diagonal tile loads its panel twice: the loop is the same for every tile — 24 of 300)
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+        const int swz = (r >> 2) & 3;
+        const int offA = (wm * 128 + r) * 64, offB = (wn * 128 + r) * 64 + S2_OPB;
+        const int so0 = (h ^ swz) << 4, so1 = ((2 + h) ^ swz) << 4;       // k-steps 0 and 1 of a stage
+        u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+#define S2_READ(FA, FB, BASE, SO)                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                       \
+        FA[i_] = *(const u32x4*)((BASE) + offA + i_ * 2048 + (SO));          \
+        FB[i_] = *(const u32x4*)((BASE) + offB + i_ * 2048 + (SO));          \
+    }
+#define S2_MFMA(FA, FB)                                                      \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                      \
+        _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                  \
+            acc[mi_][ni_] = Mfma<DT>::run(FA[mi_], FB[ni_], acc[mi_][ni_]);
+        // global -> registers -> LDS, two register stages in flight (the loads of stage i + 2 and
+        // i + 3 are outstanding while stage i computes; the compiler's vmcnt is counted, in order)
+        u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+        const int wofs = 1024 * wave + 16 * lane;      // lane-linear image: row 16 p + (lane >> 2), slot lane & 3
+        const int64_t klast = (int64_t)(st1 - 1) * S2_KC;
+#define S2_GLOAD(RA, RB, ST)                                                 \
+    {                                                                        \
+        const int64_t k0_ = (ST) < st1 ? (int64_t)(ST) * S2_KC : klast;      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                   \
+            RA[i_] = *(const u32x4*)(pa[i_] + k0_);                          \
+            RB[i_] = *(const u32x4*)(pb[i_] + k0_);                          \
+        }                                                                    \
+    }
+#define S2_LWRITE(RA, RB, BUF)                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                       \
+        *(u32x4*)((BUF) + wofs + 4096 * i_) = RA[i_];                        \
+        *(u32x4*)((BUF) + S2_OPB + wofs + 4096 * i_) = RB[i_];               \
+    }
+    // all of this wave's LDS traffic is done (its reads of the buffer about to be overwritten next
+    // and its writes), then everybody's; global loads stay in flight (no vmcnt here)
+#define S2_SYNC()                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+    __builtin_amdgcn_s_barrier();                                            \
+    asm volatile("" ::: "memory")
+        // ONE uniform loop over stage PAIRS (no tail code: the 256 accumulators stay put only if
+        // they live through a single loop; stage numbers past the end are clamped, the duplicates
+        // land in a buffer nobody reads again).
+        unsigned char* buf0 = lds;
+        unsigned char* buf1 = lds + S2_STG;
+        __syncthreads();                          // the previous item's epilogue is out of the LDS
+        S2_GLOAD(ra0, rb0, st0);
+        S2_GLOAD(ra1, rb1, st0 + 1);
+        S2_LWRITE(ra0, rb0, buf0);
+        S2_SYNC();
+        S2_READ(fa0, fb0, buf0, so0);
+        S2_GLOAD(ra0, rb0, st0 + 2);
+    // Issue order inside a half stage (16 MFMAs, one wave per SIMD: whatever is not placed in an
+    // MFMA's shadow is paid in full): MFMA, LDS read, {LDS write | global load} for the first 8
+    // MFMAs, then 8 bare MFMAs under which the LDS traffic drains before the barrier / the next
+    // half needs it.
+#define S2_PIPE(SECOND_MASK)                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+        __builtin_amdgcn_sched_group_barrier(SECOND_MASK, 1, 0);             \
+    }                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                       \
+    __builtin_amdgcn_sched_barrier(0)
+#define S2_STAGE(CUR, NXT, RA, RB, ST)                                       \
+    S2_READ(fa1, fb1, CUR, so1);                                             \
+    S2_LWRITE(RA, RB, NXT);                                                  \
+    S2_MFMA(fa0, fb0);                                                       \
+    S2_PIPE(0x200);                                                          \
+    S2_SYNC();                                                               \
+    S2_READ(fa0, fb0, NXT, so0);                                             \
+    S2_GLOAD(RA, RB, (ST) + 3);                                              \
+    S2_MFMA(fa1, fb1);                                                       \
+    S2_PIPE(0x020);
+        for (int i = st0; i < st1; i += 2) {      // an even number of stages
+            S2_STAGE(buf0, buf1, ra1, rb1, i);
+            S2_STAGE(buf1, buf0, ra0, rb0, i + 1);
+        }
+#undef S2_STAGE
+#undef S2_PIPE
+#undef S2_SYNC
+#undef S2_LWRITE
+#undef S2_GLOAD
+#undef S2_READ
+#undef S2_MFMA
+        __syncthreads();
+
+        if (slab >= 0) {
+            // ---- a K-slice: the raw sums go to this slice's slab; the tile's last slice to arrive
+            // adds the slabs up in slice order (hand-off: every wave drains its stores, barrier, ONE
+            // agent-scope release ahead of one lane's ticket; the reducer takes ONE agent-scope acquire
+            // ahead of its plain loads — right for any placement of the slices over CUs / XCDs)
+            float* mine = P.slabs + (int64_t)slab * (S2_T * S2_T);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 v = {acc[mi][ni][4 * e4], acc[mi][ni][4 * e4 + 1], acc[mi][ni][4 * e4 + 2],
+                                   acc[mi][ni][4 * e4 + 3]};
+                        *(f32x4*)(mine + ((((mi * 4 + ni) * 4 + e4) * 256 + tid) << 2)) = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = (unsigned*)lds;                 // (the staging LDS is free now)
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned got = __hip_atomic_fetch_add(&P.tickets[t - P.full], 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+                const bool last = got == (unsigned)(P.S - 1);
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = last ? 1u : 0u;
+            }
+            __syncthreads();
+            const bool last = *flag != 0u;
+            __syncthreads();
+            if (!last) continue;
+            const float* base = P.slabs + (int64_t)(t - P.full) * P.S * (S2_T * S2_T);
+            for (int sl = 0; sl < P.S; ++sl) {
+                const float* src = base + (int64_t)sl * (S2_T * S2_T);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const f32x4 v = *(const f32x4*)(src + ((((mi * 4 + ni) * 4 + e4) * 256 + tid) << 2));
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[mi][ni][4 * e4 + c] = sl == 0 ? v[c] : acc[mi][ni][4 * e4 + c] + v[c];
+                        }
+            }
+        }
+
+        // ---- epilogue (as above): H = beta H + alpha acc, the value kept for the mirror
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int64_t gc = rowB0 + wn * 128 + ni * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t gr = rowA0 + wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    float v = alpha * acc[mi][ni][e];
+                    if (gr < C && gc < C) {
+                        if (beta != 0.f) v += beta * H[gr * C + gc];
+                        H[gr * C + gc] = v;
+                    }
+                    acc[mi][ni][e] = v;
+                }
+            }
+        if (bi == bj) continue;
+        float* ldsT = (float*)lds + wave * (32 * 129);         // per wave [32 cols][128 rows + 1]
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            __syncthreads();                                   // previous column block is out
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    ldsT[r * 129 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[mi][ni][e];
+            __syncthreads();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int row = lane + 64 * half;
+                const int64_t gr = rowA0 + wm * 128 + row;      // original row -> mirrored column
+                for (int c = 0; c < 32; ++c) {
+                    const int64_t gc = rowB0 + wn * 128 + ni * 32 + c;
+                    if (gc < C && gr < C) H[gc * C + gr] = ldsT[c * 129 + row];
+                }
+            }
+        }
+    }
+}
+
+static int syrk_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 256;                       // no device (symbol checks on a CPU box): MI355X's count
+        n = cus;
+    }
+    return n;
+}
+
+// the plan's numbers for `cols` columns and Kpad (slabs / tickets not filled in)
+static Syrk256Plan syrk256_plan(int64_t cols, int64_t kpad) {
+    Syrk256Plan p{};
+    const int64_t n2 = (cols + S2_T - 1) / S2_T;
+    p.ntiles = (int)(n2 * (n2 + 1) / 2);
+    const int cus = syrk_cu_count();
+    const int npairs = (int)(kpad / (2 * S2_KC));
+    p.G = p.ntiles < cus ? p.ntiles : cus;
+    p.full = p.ntiles / p.G * p.G;
+    p.left = p.ntiles - p.full;
+    p.S = 0;
+    if (p.left > 0) {                        // one slice per workgroup at most
+        p.S = p.G / p.left;
+        if (p.S > 8) p.S = 8;
+        if (p.S > npairs) p.S = npairs;
+        if (p.S < 1) p.S = 1;
+    }
+    return p;
+}
+
+// H = beta * H + P[0] + P[1] + ... (slice order), 4 floats per thread
+__global__ __launch_bounds__(256) void syrk_combine_kernel(float* __restrict__ H, const float* __restrict__ P,
+                                                           int64_t n4, int64_t hstride, int S, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = ((const f32x4*)P)[i];
+    for (int y = 1; y < S; ++y) {
+        const f32x4 b = ((const f32x4*)(P + (int64_t)y * hstride))[i];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    if (beta != 0.f) {
+        const f32x4 h = ((const f32x4*)H)[i];
+        a[0] += beta * h[0]; a[1] += beta * h[1]; a[2] += beta * h[2]; a[3] += beta * h[3];
+    }
+    ((f32x4*)H)[i] = a;
+}
+
+// K-slices of the 64 / 128-wide kernel: 4 when the tiles alone would leave most CUs idle and K is long
+static inline int syrk_kslices(int64_t cols, int64_t kpad) {
+    const int64_t nt128 = (cols + 127) / 128;
+    return (cols < 2048 && cols % 4 == 0 && kpad >= 4096 && nt128 * (nt128 + 1) / 2 * 4 >= 200) ? 4 : 1;
+}
+
 static inline int64_t syrk_kpad(int64_t tokens) { return (tokens + SY_KC - 1) / SY_KC * SY_KC; }
+
+static inline size_t syrk_xt_bytes(int64_t tokens, int64_t cols) {
+    return ((size_t)cols * (size_t)syrk_kpad(tokens) * 2 + 255) / 256 * 256;      // Xt, 16-bit
+}
 
 extern "C" size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols) {
     if (tokens <= 0 || cols <= 0) return 0;
-    return (size_t)cols * (size_t)syrk_kpad(tokens) * 2;      // Xt, 16-bit
+    size_t n = syrk_xt_bytes(tokens, cols);
+    const int ks = syrk_kslices(cols, syrk_kpad(tokens));
+    if (ks > 1) n += (size_t)ks * (((size_t)cols * cols * sizeof(float) + 255) / 256 * 256);
+    if (cols >= S2_MIN_COLS && syrk_kpad(tokens) >= 4096) {   // K-slice slabs + tickets of the 256-wide kernel
+        const Syrk256Plan p = syrk256_plan(cols, syrk_kpad(tokens));
+        n += (size_t)p.left * p.S * S2_T * S2_T * sizeof(float) + ((size_t)(p.left + 1) * sizeof(unsigned) + 255) / 256 * 256;
+    }
+    return n;
 }
 
 extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, int64_t cols,
@@ -195,15 +585,55 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
     hipStream_t s = (hipStream_t)stream;
     const int64_t kpad = syrk_kpad(tokens);
     uint16_t* xt = (uint16_t*)workspace;
-    hipLaunchKernelGGL(syrk_transpose_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)(kpad / 64)),
-                       dim3(256), 0, s, (const uint16_t*)x, tokens, cols, kpad, xt);
+    if (cols % 8 == 0 && aligned16(x))
+        hipLaunchKernelGGL(syrk_transpose8_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)(kpad / 64)),
+                           dim3(256), 0, s, (const uint16_t*)x, tokens, cols, kpad, xt);
+    else
+        hipLaunchKernelGGL(syrk_transpose_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)(kpad / 64)),
+                           dim3(256), 0, s, (const uint16_t*)x, tokens, cols, kpad, xt);
     ECO_CHECK_LAUNCH();
     // (:79-81) H *= n/(n+b); n += b; inp = sqrt(2/n) x  ->  alpha = 2/n_new on x^T x
     const float beta = (float)((double)nsamples_before / (double)(nsamples_before + batch));
     const float alpha = (float)(2.0 / (double)(nsamples_before + batch));
+    static const bool no256 = getenv("ECOFLAP_SYRK_NO256") != nullptr;     // A/B switch
+    if (cols >= S2_MIN_COLS && kpad >= 4096 && !no256) {     // (short K: the slabs' hand-off costs more than the balance returns)
+        Syrk256Plan p = syrk256_plan(cols, kpad);
+        char* after = (char*)workspace + syrk_xt_bytes(tokens, cols);
+        p.slabs = (float*)after;
+        p.tickets = (unsigned*)(after + (size_t)p.left * p.S * S2_T * S2_T * sizeof(float));
+        {
+            const hipError_t e = hipMemsetAsync(p.tickets, 0, (size_t)(p.left + 1) * sizeof(unsigned), s);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (dtype == ECOFLAP_F16)
+            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
+        else
+            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
+        ECO_CHECK_LAUNCH();
+        return 0;
+    }
+    const int ks = syrk_kslices(cols, kpad);
+    if (ks > 1) {
+        // few tiles, long K: 128-wide tiles x 4 K-slices into partial buffers, then one combine pass
+        const int64_t n128 = (cols + 127) / 128;
+        const int nt128s = (int)(n128 * (n128 + 1) / 2);
+        const int64_t hstride = (int64_t)(((size_t)cols * cols * sizeof(float) + 255) / 256 * 256 / sizeof(float));
+        float* part = (float*)((char*)workspace + syrk_xt_bytes(tokens, cols));
+        const int64_t kslice = (kpad / SY_KC + ks - 1) / ks * SY_KC;
+        const dim3 g((unsigned)((nt128s + 7) / 8 * 8), (unsigned)ks);
+        if (dtype == ECOFLAP_F16)
+            hipLaunchKernelGGL((syrk_kernel<ECOFLAP_F16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
+        else
+            hipLaunchKernelGGL((syrk_kernel<ECOFLAP_BF16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
+        ECO_CHECK_LAUNCH();
+        const int64_t n4 = cols * cols / 4;
+        hipLaunchKernelGGL(syrk_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, H, part, n4, hstride, ks, beta);
+        ECO_CHECK_LAUNCH();
+        return 0;
+    }
     const int ntiles = (int)(nt * (nt + 1) / 2);
     const dim3 grid((unsigned)((ntiles + 7) / 8 * 8));
-#define SYRK_GO(DT_, WT_) hipLaunchKernelGGL((syrk_kernel<DT_, WT_>), grid, dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, ntiles)
+#define SYRK_GO(DT_, WT_) hipLaunchKernelGGL((syrk_kernel<DT_, WT_>), grid, dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, ntiles, kpad, (int64_t)0)
     if (dtype == ECOFLAP_F16) { if (wt == 2) SYRK_GO(ECOFLAP_F16, 2); else SYRK_GO(ECOFLAP_F16, 1); }
     else { if (wt == 2) SYRK_GO(ECOFLAP_BF16, 2); else SYRK_GO(ECOFLAP_BF16, 1); }
 #undef SYRK_GO

@@ -31,13 +31,15 @@ def main():
         wgs = -(-(numel // 8) // 128)
         wgs = -(-wgs // 8) * 8
         by_grid[wgs * 64] = (name, numel)
-    rows = []
+    rows, others = [], []
     with open(args.trace) as f:
         rd = csv.DictReader(f)
         fields = rd.fieldnames
         for r in rd:
             if "zo_perturb_units_kernel" in r["Kernel_Name"] or "zo_perturb_layers_kernel" in r["Kernel_Name"]:
                 rows.append(r)
+            else:
+                others.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[args.skip:]
     if args.out:
@@ -50,6 +52,18 @@ def main():
         line = [ln for ln in open(args.bench_json).read().splitlines() if ln.startswith("{")][-1]
         per_launch = json.loads(line)["roofline"]["per_launch"]
         rows = rows[len(rows) - len(per_launch):]          # the timed region's launches
+    # what else was on the device while each K1 launch ran (K1 shares HBM with it)
+    for r in rows:
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        hit = {}
+        for s0, s1, nm in others:
+            ov = min(b, s1) - max(a, s0)
+            if ov > 0:
+                hit[nm] = hit.get(nm, 0) + ov
+        tot = sum(hit.values())
+        top = sorted(hit.items(), key=lambda kv: -kv[1])[:3]
+        print(f"K1 launch {(b - a) / 1e3:8.2f} us: other kernels overlapping it {tot / 1e3:8.2f} us"
+              + "".join(f"  [{nm} {v / 1e3:.1f}]" for nm, v in top))
     agg, tot_b, tot_t = {}, 0.0, 0.0
     for i, r in enumerate(rows):
         g = int(r["Grid_Size_X"])
