@@ -86,6 +86,29 @@ __global__ __launch_bounds__(256) void absprod_partial_multi_kernel(
     if (threadIdx.x == 0) partials[(int64_t)layer * gridDim.x + blockIdx.x] = r;
 }
 
+// mixed dtypes in ONE launch (BLIP-2: fp16 ViT-g + bf16 FlanT5 + fp32 Q-Former): rows of four
+// words {w, g, numel, dtype_w | dtype_g << 8}; the dtype switch is uniform per workgroup
+template <int MODE>
+__global__ __launch_bounds__(256) void absprod_partial_mixed_kernel(
+    const int64_t* __restrict__ table, double* __restrict__ partials) {
+    __shared__ double lds4[4];
+    const int layer = blockIdx.y;
+    const void* w = (const void*)table[4 * layer + 0];
+    const void* g = (const void*)table[4 * layer + 1];
+    const int64_t n = table[4 * layer + 2];
+    const int dtw = (int)(table[4 * layer + 3] & 0xff), dtg = (int)((table[4 * layer + 3] >> 8) & 0xff);
+    double r = 0.0;
+#define MIX(DTW_, DTG_) \
+    if (dtw == DTW_ && dtg == DTG_) r = pair_block_sum<DTW_, DTG_, MODE>(w, g, n, blockIdx.x, gridDim.x, lds4);
+    MIX(ECOFLAP_F32, ECOFLAP_F32)
+    else MIX(ECOFLAP_F16, ECOFLAP_F16)
+    else MIX(ECOFLAP_BF16, ECOFLAP_BF16)
+    else MIX(ECOFLAP_F16, ECOFLAP_F32)
+    else MIX(ECOFLAP_BF16, ECOFLAP_F32)
+#undef MIX
+    if (threadIdx.x == 0) partials[(int64_t)layer * gridDim.x + blockIdx.x] = r;
+}
+
 // second stage: out[layer] += sum(partials[layer, 0:count]) in a fixed order
 __global__ __launch_bounds__(64) void absprod_final_kernel(const double* __restrict__ partials,
                                                            int count, double* out) {
@@ -182,6 +205,42 @@ extern "C" int ecoflap_absprod_reduce_multi(const int64_t* table, int n_layers, 
     RED_DISPATCH(hipLaunchKernelGGL((absprod_partial_multi_kernel<DTW, DTG, MODE>), grid, dim3(256),
                                     0, s, table, partials));
     if (!launched) return ECOFLAP_EDTYPE;
+    ECO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(absprod_final_kernel, dim3((unsigned)n_layers), dim3(64), 0, s, partials,
+                       RED_BLOCKS_PER_LAYER, out_accum);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// table_host: the SAME rows as `table` (device), read here to validate the dtype words
+extern "C" int ecoflap_absprod_reduce_mixed(const int64_t* table, const int64_t* table_host, int n_layers,
+                                            int mode, double* out_accum, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    if (n_layers < 0) return ECOFLAP_ESIZE;
+    if (mode < 0 || mode > 4) return ECOFLAP_EMODE;
+    if (n_layers == 0) return 0;
+    if (!table || !table_host || !out_accum || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_absprod_reduce_multi_workspace_bytes(n_layers))
+        return ECOFLAP_EWORKSPACE;
+    for (int l = 0; l < n_layers; ++l) {
+        const int dtw = (int)(table_host[4 * l + 3] & 0xff), dtg = (int)((table_host[4 * l + 3] >> 8) & 0xff);
+        if (table_host[4 * l + 2] < 0) return ECOFLAP_ESIZE;
+        const bool ok = (dtw == dtg && dtype_ok(dtw)) ||
+                        (dtg == ECOFLAP_F32 && (dtw == ECOFLAP_F16 || dtw == ECOFLAP_BF16));
+        if (!ok) return ECOFLAP_EDTYPE;      // (g unused / w unused modes: the caller repeats the used dtype)
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    const dim3 grid(RED_BLOCKS_PER_LAYER, (unsigned)n_layers);
+#define MIXED_GO(MODE_) hipLaunchKernelGGL((absprod_partial_mixed_kernel<MODE_>), grid, dim3(256), 0, s, table, partials)
+    switch (mode) {
+        case ECOFLAP_RED_ABSW_ABSG: MIXED_GO(ECOFLAP_RED_ABSW_ABSG); break;
+        case ECOFLAP_RED_SQW_SQG: MIXED_GO(ECOFLAP_RED_SQW_SQG); break;
+        case ECOFLAP_RED_ABSG: MIXED_GO(ECOFLAP_RED_ABSG); break;
+        case ECOFLAP_RED_ABSW: MIXED_GO(ECOFLAP_RED_ABSW); break;
+        default: MIXED_GO(ECOFLAP_RED_SQW); break;
+    }
+#undef MIXED_GO
     ECO_CHECK_LAUNCH();
     hipLaunchKernelGGL(absprod_final_kernel, dim3((unsigned)n_layers), dim3(64), 0, s, partials,
                        RED_BLOCKS_PER_LAYER, out_accum);

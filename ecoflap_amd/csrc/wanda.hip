@@ -1848,9 +1848,13 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     }
     BracketState* bst[WMAX];
     for (int i = 0; i < n_items; ++i) { bst[i] = (BracketState*)p; p += sizeof(BracketState); }
-    // matrix-mode items big enough to sample one vector per stride take the sampled-bracket path
-    // (it stages sqrt(scaler_row) itself and clears its own state): no sqrt launch for them
-    static const bool force_legacy = getenv("ECOFLAP_WANDA_LEGACY") != nullptr;
+    // The sampled-bracket path (matrix-mode items big enough to sample one vector per stride; it
+    // stages sqrt(scaler_row) itself and clears its own state) is OPT-IN, ECOFLAP_WANDA_SAMPLED=1
+    // (read at every call): its three kernels take 64 us on a ViT-g block against the four of the
+    // three-histogram path's 71, but the flag it hands to the host costs a stream round trip —
+    // 105 us per call measured from the stream (tools/wanda_launches.py), so the asynchronous
+    // three-histogram path is the default.
+    const bool force_legacy = getenv("ECOFLAP_WANDA_SAMPLED") == nullptr;
     bool sampled_item[WMAX];
     for (int i = 0; i < n_items; ++i) {
         const ecoflap_wanda_item& a = items[i];
@@ -2046,14 +2050,37 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         // every count above is exact; a matrix the pass could not settle (bracket miss, a crowded
         // threshold bin, a non-finite threshold) carries a flag and nothing wrongly decided: the
         // three-histogram path finishes it.  One stream sync per block call.
-        uint32_t flags[WMAX];
-        for (int q = 0; q < g.n; ++q) {
-            hipError_t e = hipMemcpyAsync(&flags[q], &bst[members[q]]->fallback, sizeof(uint32_t),
-                                          hipMemcpyDeviceToHost, s);
+        // (into PINNED memory, one strided copy: four 4-byte copies into pageable memory took
+        // longer than the three kernels)
+        static thread_local uint32_t* flags = nullptr;
+        if (!flags && hipHostMalloc((void**)&flags, WMAX * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+            return ECOFLAP_EWORKSPACE;
+        {
+            bool strided = true;
+            for (int q = 1; q < g.n; ++q) strided = strided && members[q] == members[q - 1] + 1;
+            hipError_t e = hipSuccess;
+            if (strided && g.n > 1) {
+                e = hipMemcpy2DAsync(flags, sizeof(uint32_t), &bst[members[0]]->fallback, sizeof(BracketState),
+                                     sizeof(uint32_t), (size_t)g.n, hipMemcpyDeviceToHost, s);
+            } else {
+                for (int q = 0; q < g.n && e == hipSuccess; ++q)
+                    e = hipMemcpyAsync(&flags[q], &bst[members[q]]->fallback, sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, s);
+            }
             if (e != hipSuccess) return (int)e;
         }
         {
-            hipError_t e = hipStreamSynchronize(s);
+            // the host waits here for the flags: a spinning event query (the wake-up out of
+            // hipStreamSynchronize's sleep was 50-90 us of idle GPU on some boxes, as long as the
+            // three launches themselves)
+            static thread_local hipEvent_t ev = nullptr;
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+            hipError_t e = ev ? hipEventRecord(ev, s) : hipErrorUnknown;
+            if (e == hipSuccess) {
+                while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
+            } else {
+                e = hipStreamSynchronize(s);
+            }
             if (e != hipSuccess) return (int)e;
         }
         MatGroup lg;

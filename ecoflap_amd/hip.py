@@ -23,7 +23,7 @@ EXPORTS = [
     "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
-    "ecoflap_absprod_reduce_multi", "ecoflap_colsqnorm_workspace_bytes",
+    "ecoflap_absprod_reduce_multi", "ecoflap_absprod_reduce_mixed", "ecoflap_colsqnorm_workspace_bytes",
     "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev",
     "ecoflap_colsqnorm_multi_workspace_bytes", "ecoflap_colsqnorm_accum_multi", "ecoflap_colsq_replay",
     "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
@@ -94,6 +94,7 @@ def load_library():
     lib.ecoflap_absprod_reduce_multi_workspace_bytes.restype = sz
     lib.ecoflap_absprod_reduce_multi_workspace_bytes.argtypes = [ci]
     lib.ecoflap_absprod_reduce_multi.argtypes = [vp, ci, i64, ci, ci, ci, vp, vp, sz, vp]
+    lib.ecoflap_absprod_reduce_mixed.argtypes = [vp, vp, ci, ci, vp, vp, sz, vp]
     lib.ecoflap_colsqnorm_workspace_bytes.restype = sz
     lib.ecoflap_colsqnorm_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_colsqnorm_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
@@ -330,31 +331,41 @@ class HipKernels:
             "ecoflap_absprod_reduce_multi")
 
     def absprod_reduce_pairs(self, weights, grads, mode, out_accum):
-        """out_accum[l] += sum_e f(weights[l], grads[l]) for every layer l, with one
-        multi-tensor launch per (weight dtype, grad dtype) class of the model."""
+        """out_accum[l] += sum_e f(weights[l], grads[l]) for every layer l: ONE multi-tensor
+        launch for the whole model, whatever its mix of dtypes (ecoflap_absprod_reduce_mixed)."""
         _gpu(out_accum, "out_accum")
-        classes = {}
-        keep_alive = []
-        for i, (w, g) in enumerate(zip(weights, grads)):
+        if out_accum.dtype != torch.float64 or out_accum.numel() != len(weights):
+            raise EcoflapHipError("out_accum must be float64[len(weights)]")
+        keep_alive, rows = [], []
+        for w, g in zip(weights, grads):
             if not g.is_contiguous():
                 g = g.contiguous()
                 keep_alive.append(g)
-            classes.setdefault((w.dtype, g.dtype), []).append((i, _gpu(w, "w"), _gpu(g, "g")))
-        for (dw, dg), items in classes.items():
-            rows = tuple((w.data_ptr(), g.data_ptr(), w.numel()) for _, w, g in items)
-            # the pointer table is the same for every batch when the gradients live in a captured
-            # graph's static buffers: building it afresh is a blocking H2D copy per batch that
-            # stalls the host behind the replay it has just queued
-            cached = self._pair_tables.get((dw, dg))
-            if cached is None or cached[0] != rows or cached[1].device != out_accum.device:
-                cached = (rows,
-                          torch.tensor(rows, dtype=torch.int64, device=out_accum.device),
-                          torch.tensor([i for i, _, _ in items], device=out_accum.device))
-                self._pair_tables[(dw, dg)] = cached
-            _, table, index = cached
-            part = torch.zeros(len(items), dtype=torch.float64, device=out_accum.device)
-            self.absprod_reduce_multi(table, max(r[2] for r in rows), dw, dg, mode, part)
-            out_accum.index_add_(0, index, part)
+            _gpu(w, "w")
+            _gpu(g, "g")
+            if g.numel() != w.numel():
+                raise EcoflapHipError("gradient and weight differ in size")
+            dw, dg = DTYPE_CODE[w.dtype], DTYPE_CODE[g.dtype]
+            if mode >= 3:            # ABSW / SQW: g unused
+                dg = dw
+            elif mode == 2:          # ABSG: w unused
+                dw = dg
+            rows.append((w.data_ptr(), g.data_ptr(), w.numel(), dw | (dg << 8)))
+        rows = tuple(rows)
+        # the pointer table is the same for every batch when the gradients live in a captured
+        # graph's static buffers: building it afresh is a blocking H2D copy per batch that
+        # stalls the host behind the replay it has just queued
+        cached = self._pair_tables.get("mixed")
+        if cached is None or cached[0] != rows or cached[2].device != out_accum.device:
+            host = torch.tensor(rows, dtype=torch.int64)
+            cached = (rows, host, host.to(out_accum.device))
+            self._pair_tables["mixed"] = cached
+        _, host, table = cached
+        nb = self.lib.ecoflap_absprod_reduce_multi_workspace_bytes(len(rows))
+        ws = self.ws.get(nb, out_accum.device)
+        _check(self.lib.ecoflap_absprod_reduce_mixed(
+            _ptr(table), host.data_ptr(), len(rows), int(mode), _ptr(out_accum), _ptr(ws), ws.numel(),
+            _stream()), "ecoflap_absprod_reduce_mixed")
 
     # ---- K6 ---------------------------------------------------------------------------
     def colsqnorm_accum(self, scaler_row, x2d, nsamples_before, batch):

@@ -175,6 +175,14 @@ int ecoflap_absprod_reduce_multi(const int64_t* table, int n_layers,
                                  int mode, double* out_accum, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* The same over matrices of DIFFERENT dtypes in one launch (BLIP-2: fp16 ViT-g, bf16 FlanT5, fp32
+ * Q-Former — the single-dtype form needs one launch per class).  Rows of FOUR words
+ * {w_ptr, g_ptr, numel, dtype_w | dtype_g << 8}; `table_host` is the same table in host memory (the
+ * dtype words are validated there).  Workspace: ecoflap_absprod_reduce_multi_workspace_bytes. */
+int ecoflap_absprod_reduce_mixed(const int64_t* table, const int64_t* table_host, int n_layers,
+                                 int mode, double* out_accum, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K6  Wanda calibration statistic (running mean of per-input-channel sum x^2)
  * replaces WrappedGPT.add_batch   LAVIS/lavis/compression/pruners/wanda_pruner.py:71-84
@@ -240,14 +248,15 @@ int ecoflap_colsq_replay(float* scaler_row, const float* sq, const int64_t* batc
  *                                                   wanda_pruner.py:555-558
  * mask_out (optional): uint8[rows*cols], 1 where zeroed.
  * ------------------------------------------------------------------------- */
-/* Matrix mode runs a sampled-bracket selection (2 reads + 1 write of W): a sample brackets the
- * threshold, one pass counts below / histograms inside the bracket, the apply pass settles all
- * but the threshold bin's few hundred elements, which its last workgroup sorts.  Every count is
- * exact (result identical to the reference's sort); a matrix the pass cannot settle (bracket miss,
- * massive ties, non-finite threshold) is flagged untouched-or-partially-correct and finished by
- * the three-histogram path.  For that flag the matrix-mode calls synchronise the stream ONCE
- * per call (not graph-capturable); ECOFLAP_WANDA_LEGACY=1 in the environment selects the
- * asynchronous three-histogram path outright. */
+/* Matrix mode: three histogram passes (11 + 11 + 10 bits) for the k-th order statistic, then
+ * `metric <= thres`; asynchronous, graph-capturable.  With ECOFLAP_WANDA_SAMPLED=1 in the
+ * environment (read at every call) big matrices take a sampled-bracket selection instead (2 reads
+ * + 1 write of W: a sample brackets the threshold, one pass counts below / histograms inside the
+ * bracket, the apply pass settles all but the threshold bin's few hundred elements, which its last
+ * workgroup sorts; every count exact; a matrix the pass cannot settle — bracket miss, massive
+ * ties, non-finite threshold — is flagged and finished by the three-histogram path).  That flag is
+ * read on the host: ONE stream synchronisation per call, which costs more than the saved pass
+ *  — hence opt-in. */
 size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols);
 int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
                              int64_t cols, int dtype, int64_t k,

@@ -346,6 +346,37 @@ def test_absprod_reduce_multi_vs_oracle(kern, oracle):
     assert abs(acc[0].item() - (acc[1] + acc[2]).item()) <= 1e-9 * acc[0].item()
 
 
+def test_absprod_reduce_pairs_mixed_dtypes_one_launch(kern, oracle):
+    """`ecoflap_absprod_reduce_mixed` (BLIP-2's mix: fp16, bf16 and fp32 matrices, fp32 gradients of
+    16-bit weights included) == the oracle per pair in every mode; accumulates; equals the
+    single-dtype multi-tensor launch bit for bit on the rows of one class."""
+    torch.manual_seed(1)
+    spec = [(1408 * 1408, torch.float16, torch.float16), (2048 * 2048 + 3, torch.bfloat16, torch.bfloat16),
+            (768 * 768, torch.float32, torch.float32), (7, torch.float16, torch.float32),
+            (5120 * 2048, torch.bfloat16, torch.float32), (1, torch.float32, torch.float32),
+            (6144 * 1408, torch.float16, torch.float16)]
+    ws = [gpu((torch.randn(n) * 0.05).to(dw)) for n, dw, _ in spec]
+    gs = [gpu((torch.randn(n) * 0.01).to(dg)) for n, _, dg in spec]
+    for mode in range(5):
+        out = torch.zeros(len(spec), dtype=torch.float64, device="cuda")
+        kern.absprod_reduce_pairs(ws, gs, mode, out)
+        kern.absprod_reduce_pairs(ws, gs, mode, out)
+        for i, (w, g) in enumerate(zip(ws, gs)):
+            want = 2 * oracle.absprod_reduce(w.cpu(), g.cpu(), mode)
+            assert abs(out[i].item() - want) <= 1e-6 * abs(want) + 1e-300, (mode, i)
+    rows = [i for i, (_, dw, dg) in enumerate(spec) if dw == dg == torch.float16]
+    table = torch.tensor([[ws[i].data_ptr(), gs[i].data_ptr(), ws[i].numel()] for i in rows],
+                         dtype=torch.int64, device="cuda")
+    one = torch.zeros(len(rows), dtype=torch.float64, device="cuda")
+    kern.absprod_reduce_multi(table, max(ws[i].numel() for i in rows), torch.float16, torch.float16, 0, one)
+    mixed = torch.zeros(len(spec), dtype=torch.float64, device="cuda")
+    kern.absprod_reduce_pairs(ws, gs, 0, mixed)
+    assert torch.equal(one, mixed[rows])
+    with pytest.raises(Exception):
+        kern.absprod_reduce_pairs([ws[2]], [gs[0][:ws[2].numel()]], 0,
+                                  torch.zeros(1, dtype=torch.float64, device="cuda"))   # fp32 W, fp16 g
+
+
 # ------------------------------------------------------------------------------ K6
 def test_colsqnorm_reference_goldens(kern, golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_wrapped_gpt.npz"))
@@ -558,12 +589,19 @@ def test_wanda_full_size_properties(kern):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", ["normal_0.5", "normal_0.37", "normal_0.9", "ties", "k0", "klast",
                                   "half_zero", "nan_column", "heavy_tail"])
-def test_wanda_matrix_sampled_bracket_path_equals_sort(kern, dt, case):
-    """Matrices big enough for the sampled-bracket selection (2 reads + 1 write) against the
+@pytest.mark.parametrize("path", ["sampled", "histograms"])
+def test_wanda_matrix_sampled_bracket_path_equals_sort(kern, dt, case, path, monkeypatch):
+    """Both matrix-mode selections (the default three histogram passes; ECOFLAP_WANDA_SAMPLED=1,
+    read at every call: the sampled bracket) on the same cases.
+    Matrices big enough for the sampled-bracket selection (2 reads + 1 write) against the
     reference's own expression on the GPU (`thres = sort(metric.flatten())[k]; metric <= thres`,
     wanda_pruner.py:555-558): ordinary data, and the cases the pass flags and hands to the
     three-histogram path (massive ties, a threshold at zero, the extremes of k) or must keep out
     of the threshold (NaN metrics)."""
+    if path == "sampled":
+        monkeypatch.setenv("ECOFLAP_WANDA_SAMPLED", "1")
+    else:
+        monkeypatch.delenv("ECOFLAP_WANDA_SAMPLED", raising=False)
     rows, cols = 512, 1408
     g = torch.Generator(device="cuda").manual_seed(len(case) * 7 + 1)
     w = torch.randn(rows, cols, device="cuda", generator=g) * 0.02

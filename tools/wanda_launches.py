@@ -112,6 +112,17 @@ def main():
             [(w, sr, mode, k, None) for w, sr, k in zip(wsets[i], srs, ks)])
         med, mn = timed(fn, sets, fresh=True)
         res.append((f"K7 {mode} block", name, nbytes, med, mn))
+        if mode == "matrix":
+            # the opt-in sampled-bracket selection (one stream round trip per call for its flag)
+            os.environ["ECOFLAP_WANDA_SAMPLED"] = "1"
+            wsets2 = [[(torch.randn(r, c, device="cuda") * 0.02).to(dt) for r, c in shapes]
+                      for _ in range(sets)]
+            fn2 = lambda i: kern.wanda_prune_block(                              # noqa: E731
+                [(w, sr, mode, k, None) for w, sr, k in zip(wsets2[i], srs, ks)])
+            med, mn = timed(fn2, sets, fresh=True)
+            del os.environ["ECOFLAP_WANDA_SAMPLED"]
+            res.append((f"K7 {mode} block", name + " ECOFLAP_WANDA_SAMPLED=1", nbytes, med, mn))
+            del wsets2
         del wsets
     # SparseGPT Hessian (MFMA SYRK): flops against the dense fp16 / bf16 peak
     flops_rows = []
