@@ -2134,6 +2134,60 @@ extern "C" int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int6
 }
 
 // =====================================================================================
+// K7, structured n:m branch (wanda_pruner.py:265-270 = :546-551): in every group of m consecutive
+// columns of a row the n smallest metrics are zeroed (`topk(..., largest=False)`: a NaN counts as
+// the largest; equal metrics: the lower column first).  HBM-bound, one pass: 2*s*numel + 4*cols.
+// One thread per group: the group's metrics as integer keys (non-negative floats order as their
+// bits, NaN -> 0xffffffff), each element's rank by counting.
+template <int DT>
+__global__ __launch_bounds__(256) void wanda_nm_kernel(void* __restrict__ w, const float* __restrict__ scaler_row,
+                                                       int64_t rows, int64_t cols, int n, int m,
+                                                       uint8_t* __restrict__ mask_out) {
+    const int64_t gpr = (cols + m - 1) / m;                    // groups per row
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= rows * gpr) return;
+    const int64_t r = g / gpr, c0 = (g - r * gpr) * m;
+    const int len = (int)(cols - c0 < m ? cols - c0 : m);
+    uint32_t key[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        key[j] = 0xffffffffu;
+        if (j < len) {
+            const float v = __builtin_fabsf(Vec<DT>::load1(w, r * cols + c0 + j)) * __builtin_sqrtf(scaler_row[c0 + j]);
+            key[j] = v != v ? 0xffffffffu : __float_as_uint(v);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= len) break;
+        int rank = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < len && i != j && (key[i] < key[j] || (key[i] == key[j] && i < j))) ++rank;
+        const bool z = rank < n;
+        if (z) Vec<DT>::store1(w, r * cols + c0 + j, 0.0f);
+        if (mask_out) mask_out[r * cols + c0 + j] = z ? 1 : 0;
+    }
+}
+
+extern "C" int ecoflap_wanda_prune_nm(void* w, const float* scaler_row, int64_t rows, int64_t cols,
+                                      int dtype, int n, int m, uint8_t* mask_out, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (rows < 0 || cols < 0 || n <= 0 || m < n || m > 16) return ECOFLAP_ESIZE;
+    if (cols % m != 0 && cols % m < n) return ECOFLAP_ESIZE;       // (topk raises on the short slice)
+    if (rows == 0 || cols == 0) return 0;
+    if (!w || !scaler_row) return ECOFLAP_ENULL;
+    const int64_t groups = rows * ((cols + m - 1) / m);
+    if ((groups + 255) / 256 > 0x7fffffffLL) return ECOFLAP_ESIZE;
+    const dim3 grid((unsigned)((groups + 255) / 256));
+#define NM_GO(DT_) hipLaunchKernelGGL((wanda_nm_kernel<DT_>), grid, dim3(256), 0, (hipStream_t)stream, w, scaler_row, rows, cols, n, m, mask_out)
+    DT_SWITCH(dtype, NM_GO);
+#undef NM_GO
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// =====================================================================================
 // K8  grad *= mask
 // =====================================================================================
 // 16-byte vectors of the gradient, 8 (4) mask bytes per vector; scalar form for unaligned tails

@@ -27,7 +27,8 @@ EXPORTS = [
     "ecoflap_colsqnorm_accum", "ecoflap_colsqnorm_accum_dev",
     "ecoflap_colsqnorm_multi_workspace_bytes", "ecoflap_colsqnorm_accum_multi", "ecoflap_colsq_replay",
     "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
-    "ecoflap_wanda_prune_matrix", "ecoflap_wanda_block_workspace_bytes", "ecoflap_wanda_prune_block",
+    "ecoflap_wanda_prune_matrix", "ecoflap_wanda_prune_nm", "ecoflap_wanda_block_workspace_bytes",
+    "ecoflap_wanda_prune_block",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
     "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
@@ -107,6 +108,7 @@ def load_library():
     lib.ecoflap_wanda_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
     lib.ecoflap_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, sz, vp]
+    lib.ecoflap_wanda_prune_nm.argtypes = [vp, vp, i64, i64, ci, ci, ci, vp, vp]
     lib.ecoflap_wanda_block_workspace_bytes.restype = sz
     lib.ecoflap_wanda_block_workspace_bytes.argtypes = [vp, ci]
     lib.ecoflap_wanda_prune_block.argtypes = [vp, ci, vp, sz, vp]
@@ -469,6 +471,20 @@ class HipKernels:
     def wanda_prune_matrix(self, w, scaler_row, k, mask_out=None):
         self._wanda(self.lib.ecoflap_wanda_prune_matrix, "ecoflap_wanda_prune_matrix", w,
                     scaler_row, k, mask_out)
+
+    def wanda_prune_nm(self, w, scaler_row, n, m, mask_out=None):
+        """Structured n:m selection (wanda_pruner.py:265-270): in every group of m consecutive
+        columns of a row the n smallest metrics are zeroed, in place."""
+        _gpu(w, "w")
+        _gpu(scaler_row, "scaler_row")
+        if scaler_row.dtype != torch.float32:
+            raise EcoflapHipError("scaler_row must be float32")
+        if mask_out is not None:
+            _gpu(mask_out, "mask_out")
+        rows, cols = w.shape
+        _check(self.lib.ecoflap_wanda_prune_nm(_ptr(w), _ptr(scaler_row), rows, cols, DTYPE_CODE[w.dtype],
+                                               int(n), int(m), _ptr(mask_out) if mask_out is not None else None,
+                                               _stream()), "ecoflap_wanda_prune_nm")
 
     def wanda_prune_block(self, items):
         """items: [(w, scaler_row, mode, k, mask_out_or_None)], mode "rows" / "matrix": all

@@ -473,6 +473,9 @@ class _BlockwiseWanda:
                                               blocksize=128,
                                               same_hessian_as=wrapped.get(twins.get(name)))
                     wrapped[name].H = None
+                elif getattr(self.owner, "prune_n", 0) != 0:   # structured n:m (:265-270 / :546-551)
+                    self.kernels.wanda_prune_nm(weight, wrapped[name].scaler_row,
+                                                self.owner.prune_n, self.owner.prune_m)
                 elif mode == "rows":      # per output row, k smallest by stable order (:272-279)
                     block_items.append((weight, wrapped[name].scaler_row, "rows",
                                         int(weight.shape[1] * ratio), None))

@@ -267,6 +267,15 @@ int ecoflap_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows,
                                uint8_t* mask_out, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Structured n:m branch of both Wanda pruners (wanda_pruner.py:265-270, :546-551; dead in the
+ * reference's shipped configs, prune_n = 0): in every group of m consecutive columns of a row the n
+ * smallest |W| * sqrt(scaler_row) are zeroed (`torch.topk(..., largest=False)`: NaN counts as the
+ * largest; equal metrics: the lower column first).  0 < n <= m <= 16; a ragged last group
+ * (cols % m != 0) is selected among its own elements and must hold at least n (the reference's topk
+ * raises otherwise: ECOFLAP_ESIZE).  No workspace, asynchronous. */
+int ecoflap_wanda_prune_nm(void* w, const float* scaler_row, int64_t rows, int64_t cols, int dtype,
+                           int n, int m, uint8_t* mask_out, void* stream);
+
 /* Block-level form: every Linear of one transformer block in ONE call (the reference prunes
  * them one after another inside its per-block loop, wanda_pruner.py:253-283 / :534-562; the
  * selections are independent).  Same results as n_items single calls, bit for bit; the launches

@@ -50,6 +50,7 @@ class Oracle:
         L.oracle_colsq_replay.argtypes = [vp, vp, vp, i64, i64, i64, i64]
         L.oracle_wanda_prune_rows.argtypes = [vp, vp, i64, i64, ci, i64, vp]
         L.oracle_wanda_prune_matrix.argtypes = [vp, vp, i64, i64, ci, i64, vp]
+        L.oracle_wanda_prune_nm.argtypes = [vp, vp, i64, i64, ci, ci, ci, vp]
         L.oracle_mask_mul.argtypes = [vp, vp, i64, ci]
         L.oracle_round_array.argtypes = [vp, i64, ci]
         L.oracle_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp]
@@ -128,6 +129,16 @@ class Oracle:
         mask = torch.zeros(rows, cols, dtype=torch.uint8) if want_mask else None
         self.lib.oracle_wanda_prune_matrix(_p(w), _p(scaler_row), rows, cols, DT[w.dtype], k,
                                            _p(mask) if want_mask else None)
+        return mask
+
+    def wanda_prune_nm(self, w, scaler_row, n, m, want_mask=True):
+        _cpu(w), _cpu(scaler_row)
+        rows, cols = w.shape
+        if not 0 < n <= m <= 64 or (cols % m and cols % m < n):
+            raise ValueError("n:m selection needs 0 < n <= m <= 64 and no group shorter than n")
+        mask = torch.zeros(rows, cols, dtype=torch.uint8) if want_mask else None
+        self.lib.oracle_wanda_prune_nm(_p(w), _p(scaler_row), rows, cols, DT[w.dtype], n, m,
+                                       _p(mask) if want_mask else None)
         return mask
 
     def mask_mul(self, g, keep):

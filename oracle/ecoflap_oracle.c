@@ -362,6 +362,38 @@ void oracle_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows, i
     free(m); free(s); free(sq);
 }
 
+/* ------------------------------------------------------------------ K7, structured n:m branch
+ * LAVIS/lavis/compression/pruners/wanda_pruner.py:265-270 (= :546-551): for every group of m
+ * consecutive columns, `torch.topk(W_metric[:, ii:ii+m].float(), n, dim=1, largest=False)` picks
+ * the n smallest metrics of each row's group (a NaN counts as the largest), those weights are
+ * zeroed.  Equal metrics: the lower column first (torch leaves the order among ties to the
+ * implementation; the parity fixtures hold no ties inside a group, the tie rule is this build's).
+ * A ragged last group (cols % m != 0) is selected among its own elements, as the slice is; the
+ * caller rejects one shorter than n (topk raises there). */
+void oracle_wanda_prune_nm(void* w, const float* scaler_row, int64_t rows, int64_t cols, int dt,
+                           int n, int m, uint8_t* mask) {
+    float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
+    for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c0 = 0; c0 < cols; c0 += m) {
+            int len = (int)((cols - c0) < m ? (cols - c0) : m);
+            float met[64];
+            for (int j = 0; j < len; ++j) met[j] = wanda_metric(w, r * cols + c0 + j, dt, sq[c0 + j]);
+            for (int j = 0; j < len; ++j) {
+                int rank = 0;
+                for (int i = 0; i < len; ++i) {
+                    if (i == j) continue;
+                    int less = cmp_f(&met[i], &met[j]);
+                    if (less < 0 || (less == 0 && i < j)) ++rank;
+                }
+                int z = rank < n;
+                if (z) store_dt(w, r * cols + c0 + j, dt, 0.0f);
+                if (mask) mask[r * cols + c0 + j] = (uint8_t)z;
+            }
+        }
+    free(sq);
+}
+
 /* ------------------------------------------------------------------ K8 (UPop/ecoflap_compression_vqa.py:124-129) */
 void oracle_mask_mul(void* g, const uint8_t* keep, int64_t n, int dt) {
     for (int64_t i = 0; i < n; ++i)

@@ -375,6 +375,47 @@ def golden_end_to_end(registry):
     save("g7_end_to_end.npz", **out)
 
 
+# --------------------------------------------------------------------------- G16: n:m branch
+def golden_nm(registry):
+    """The structured n:m branch of both Wanda pruners (wanda_pruner.py:265-270 rows pruner, :546-551
+    matrix pruner).  prune_n is hard-wired to 0 in the constructor (layer_single_base_pruner.py:62),
+    so the branch is reached by setting the attributes on the built pruner — the only way a
+    reference user can reach it either."""
+    out = {}
+
+    def run(tag, name, model, batches, cfg, n, m):
+        for k, v in model.state_dict().items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        pruner = registry.get_pruner_class(name)(model=model, data_loader=batches, **cfg)
+        pruner.prune_n, pruner.prune_m = n, m
+        model2, _ = pruner.prune()
+        for k, v in model2.state_dict().items():
+            out[f"{tag}_final::{k}"] = bits(v)
+        out[f"{tag}_nm"] = np.array([n, m])
+
+    base = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1,
+                num_noise=1, noise_eps=1e-3)
+    torch.manual_seed(31)
+    run("vit_2_4", "vit_wanda_pruner", vit_toy().eval(),
+        S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5),
+        dict(base, prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+             max_sparsity_per_layer=0.6, score_method="MEZO-GradOnly_sum", num_data_first_stage=8), 2, 4)
+    t5cfg = t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, vocab_size=96)
+    t5_batches = S.image_text_batches(8, 2, img_size=4, vocab=96, in_len=6, out_len=4, seed=8)
+    torch.manual_seed(32)
+    run("t5_2_4", "t5_wanda_pruner", T5(t5cfg, dtype=None, init_std=0.2).eval(), t5_batches,
+        dict(base, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+             max_sparsity_per_layer=0.7, score_method="MEZO-GradOnly_avg", num_data_first_stage=4), 2, 4)
+    torch.manual_seed(33)
+    run("t5_1_8", "t5_wanda_pruner", T5(t5cfg, dtype=None, init_std=0.2).eval(), t5_batches,
+        dict(base, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+             max_sparsity_per_layer=0.7, score_method="MEZO-GradOnly_avg", num_data_first_stage=4), 1, 8)
+    save("g16_wanda_nm.npz", **out)
+
+
 # --------------------------------------------------------------------------- G9: UPop BLIP-BERT
 def golden_upop():
     """The reference's UPop pruner AS SHIPPED on the toy BLIP-VQA shape: stage 1 degenerates to
@@ -767,7 +808,7 @@ if __name__ == "__main__":
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
     only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global",
-                            "protected", "clip"]
+                            "protected", "clip", "nm"]
     if "clip" in only:
         golden_clip()
     if "k1" in only:
@@ -780,6 +821,8 @@ if __name__ == "__main__":
         golden_scoring(lavis["layer_single_base_pruner"].LayerSparsity, lavis)
     if "e2e" in only:
         golden_end_to_end(registry)
+    if "nm" in only:
+        golden_nm(registry)
     if "names" in only:
         golden_names()
     if "upop" in only:

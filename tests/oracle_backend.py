@@ -95,6 +95,13 @@ class OracleKernels:
         if mask_out is not None:
             mask_out.copy_(m)
 
+    def wanda_prune_nm(self, w, scaler_row, n, m, mask_out=None):
+        h = self._host(w)
+        mk = self.o.wanda_prune_nm(h, self._host(scaler_row), n, m, want_mask=True)
+        w.copy_(h)
+        if mask_out is not None:
+            mask_out.copy_(mk)
+
     def wanda_prune_block(self, items):
         for w, scaler_row, mode, k, mask_out in items:
             (self.wanda_prune_rows if mode == "rows" else self.wanda_prune_matrix)(

@@ -533,6 +533,56 @@ def test_wanda_rows_vs_oracle(kern, oracle, dt, rows, cols, frac, levels):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,cols,n,m,levels", [
+    (7, 64, 2, 4, None), (5, 100, 1, 4, 4), (33, 1408, 2, 4, None), (16, 5120, 4, 8, None),
+    (9, 30, 3, 16, 8), (4, 258, 2, 4, None), (6, 96, 4, 4, None), (2048, 2048, 2, 4, None)])
+def test_wanda_n_m_vs_oracle(kern, oracle, dt, rows, cols, n, m, levels):
+    """`ecoflap_wanda_prune_nm` (wanda_pruner.py:265-270): mask and weights equal the oracle's bit
+    for bit — ties (quantised weights), a NaN metric (counts as the largest), a ragged last group
+    (258 = 64 * 4 + 2) — and every full group holds exactly n zeros."""
+    torch.manual_seed(rows * cols + n)
+    w = torch.randn(rows, cols) * 0.05
+    if levels:
+        w = _ties(w, levels * 10)
+    w = w.to(dt)
+    s = torch.rand(cols) + 0.1
+    if levels:
+        s = torch.round(s * 2) / 2 + 0.5
+    if cols >= 100:
+        s[7] = float("nan")                     # a whole column of NaN metrics
+    wg = gpu(w.clone())
+    mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    kern.wanda_prune_nm(wg, gpu(s), n, m, mask)
+    wr = w.clone()
+    mref = oracle.wanda_prune_nm(wr, s, n, m)
+    assert torch.equal(mask.cpu(), mref)
+    assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8))
+    full = cols // m * m
+    assert (mask[:, :full].reshape(rows, -1, m).sum(-1) == n).all()
+    if cols >= 100 and m == 4 and n == 2:
+        assert int(mask[:, 7].sum()) == 0       # three finite neighbours: the NaN is never among the 2 smallest
+    if m >= 3:          # a ragged last group shorter than n: the reference's topk raises there
+        with pytest.raises(Exception):
+            kern.wanda_prune_nm(gpu(w[:, :m + 1].contiguous()), gpu(s[:m + 1].contiguous()), 2, m)
+
+
+@pytest.mark.parametrize("tag", ["vit_2_4", "t5_2_4", "t5_1_8"])
+def test_structured_n_m_pruner_hip_equals_oracle(kern, golden_dir, tag):
+    """The pruners with prune_n / prune_m set, same GPU forward on both sides, HIP kernels vs the
+    oracle's arithmetic: pruned weights bit for bit (the oracle side against the reference's own
+    output: tests/test_host_parity.py::test_structured_n_m_branch_matches_reference)."""
+    from oracle_backend import OracleKernels
+    from test_host_parity import run_nm
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels())):
+        _, model = run_nm(tag, golden_dir, backend, device="cuda")
+        res[name] = {k: v.cpu() for k, v in model.state_dict().items()}
+    for k in res["hip"]:
+        assert torch.equal(res["hip"][k], res["oracle"][k]), k
+    assert sum(int((v == 0).sum()) for k, v in res["hip"].items() if v.dim() == 2 and ".block" in k) > 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("rows,cols,frac,levels", [
     (7, 64, 0.5, None), (5, 100, 0.37, 4), (3, 1, 0.5, None), (64, 1408, 0.5, None),
     (33, 300, 0.61, 8), (4, 257, 0.0, None), (12, 96, 0.999, 2)])

@@ -189,6 +189,53 @@ def test_end_to_end_matches_reference(golden_dir, tag):
         assert np.array_equal(to_bits(v).ravel(), want.ravel()), k
 
 
+NM = {
+    "vit_2_4": ("vit_wanda_pruner", "vit", dict(
+        BASE, prune_spec="3-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+        max_sparsity_per_layer=0.6, score_method="MEZO-GradOnly_sum", num_data_first_stage=8)),
+    "t5_2_4": ("t5_wanda_pruner", "t5", dict(
+        BASE, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+        max_sparsity_per_layer=0.7, score_method="MEZO-GradOnly_avg", num_data_first_stage=4)),
+    "t5_1_8": ("t5_wanda_pruner", "t5", dict(
+        BASE, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity=None,
+        max_sparsity_per_layer=0.7, score_method="MEZO-GradOnly_avg", num_data_first_stage=4)),
+}
+
+
+def run_nm(tag, golden_dir, kernels, device="cpu"):
+    g = np.load(os.path.join(golden_dir, "g16_wanda_nm.npz"))
+    name, kind, cfg = NM[tag]
+    model, batches = build_e2e(kind)
+    load_state(model, g, f"{tag}_init")
+    model.to(device)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    pruner = load_pruner(name, model, batches,
+                         cfg=dict(cfg, kernels=kernels, z_source=torch_cpu_normal))
+    pruner.prune_n, pruner.prune_m = (int(x) for x in g[f"{tag}_nm"])
+    model2, _ = pruner.prune()
+    return g, model2
+
+
+@pytest.mark.parametrize("tag", list(NM))
+def test_structured_n_m_branch_matches_reference(golden_dir, tag):
+    """wanda_pruner.py:265-270 / :546-551 with prune_n, prune_m set on the built pruner (the
+    constructor wires 0; the reference's own pruners produced g16 the same way): every weight of
+    the pruned model bit for bit, and exactly n zeros per group of m in the pruned matrices."""
+    g, model2 = run_nm(tag, golden_dir, OracleKernels())
+    n, m = (int(x) for x in g[f"{tag}_nm"])
+    checked = 0
+    for k, v in model2.state_dict().items():
+        want = g[f"{tag}_final::{k}"]
+        assert np.array_equal(to_bits(v).ravel(), want.ravel()), k
+        init = g[f"{tag}_init::{k}"]
+        if v.dim() == 2 and not np.array_equal(init.ravel(), want.ravel()) and v.shape[1] % m == 0:
+            assert torch.equal((v.reshape(v.shape[0], -1, m) == 0).sum(-1),
+                               torch.full((v.shape[0], v.shape[1] // m), n)), k
+            checked += 1
+    assert checked >= 4
+
+
 def test_prunable_key_set_matches_reference_artifact(golden_dir):
     """The 588 sparsity-table keys of BLIP-2 (FlanT5-XL), in the order the reference stored
     them in LAVIS/importance_scores/cc3m-blipt5_wanda_pruner_0.5-1.0-1.0.pth."""
