@@ -28,6 +28,7 @@ all-reduce of the loss table.
 """
 import os
 os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")   # before the first GEMM (ecoflap_amd/blas_guard.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL between processes: dmabuf IPC only on this pool
 import argparse
 import json
 import os
