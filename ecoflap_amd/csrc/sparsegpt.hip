@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void sgpt_sweep_kernel(float* W, int64_t rows,
                                                          int64_t i1, int count, uint32_t rank0,
                                                          const SgptSelState* st, int use_thresh,
                                                          const uint8_t* __restrict__ mask_in,
-                                                         float* __restrict__ Err, uint8_t* mask_out) {
+                                                         float* __restrict__ Err, uint8_t* mask_out,
+                                                         int nm_n, int nm_m) {
     // upper triangle of Hinv1, packed: row i starts at i*count - i*(i-1)/2, holds j = i..count-1
     extern __shared__ __attribute__((aligned(16))) float Hs[];
     __shared__ uint32_t wave4[4];
@@ -144,13 +145,43 @@ __global__ __launch_bounds__(256) void sgpt_sweep_kernel(float* W, int64_t rows,
                 const float d = HS(j, j);
                 mk[t] = __uint_as_float(sg_metric_bits(w[t], d)) <= thresh;     // tmp <= thresh (:188)
             } else {
-                mk[t] = mask_in[row * count + j] != 0;
+                mk[t] = mask_in ? mask_in[row * count + j] != 0 : false;    // (n:m: filled in during the sweep)
             }
         } else {
             mk[t] = false;
         }
     }
     for (int i = 0; i < count; ++i) {
+        if (nm_n != 0 && i % nm_m == 0) {
+            // n:m (:196-198): the n smallest W1[:, i:i+m]**2 / diag**2 of this row, on the sweep's
+            // current values, join the mask; ranks by counting over the group's lanes
+            const int len = count - i < nm_m ? count - i : nm_m;
+            uint32_t myk[2];
+            bool in[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = lane + 64 * t;
+                in[t] = j >= i && j < i + len;
+                myk[t] = 0xffffffffu;
+                if (in[t]) {
+                    const uint32_t b = sg_metric_bits(w[t], HS(j, j));
+                    myk[t] = (b & 0x7fffffffu) > 0x7f800000u ? 0xffffffffu : b;      // NaN: the largest
+                }
+            }
+            int rank[2] = {0, 0};
+            for (int p = 0; p < len; ++p) {
+                const int jj = i + p;
+                const uint32_t kp = (jj < 64) ? __shfl(myk[0], jj & 63, 64) : __shfl(myk[1], jj & 63, 64);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int j = lane + 64 * t;
+                    if (in[t] && jj != j && (kp < myk[t] || (kp == myk[t] && jj < j))) ++rank[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (in[t] && rank[t] < nm_n) mk[t] = true;
+        }
         const int src = i & 63;
         const float wi = (i < 64) ? __shfl(w[0], src, 64) : __shfl(w[1], src, 64);
         const int mi = (i < 64) ? __shfl((int)mk[0], src, 64) : __shfl((int)mk[1], src, 64);
@@ -212,7 +243,25 @@ extern "C" int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, cons
     const size_t lds = ((size_t)count * (count + 1) / 2) * sizeof(float);   // <= 33 KB
     hipLaunchKernelGGL(sgpt_sweep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds, s, W, rows,
                        ldw, Hinv, ldh, i1, count, rank0, st, mask_in ? 0 : 1, mask_in, err_out,
-                       mask_out);
+                       mask_out, 0, 0);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same block step under n:m (sparsegpt_pruner.py:190, :196-198; dead in the reference's shipped
+// configs): no threshold, the mask grows during the sweep.  0 < n <= m <= 16; a group cut short by
+// the block's end must hold at least n columns (the reference's topk raises otherwise).
+extern "C" int ecoflap_sparsegpt_block_nm(float* W, int64_t rows, int64_t ldw, const float* Hinv,
+                                          int64_t ldh, int64_t i1, int count, int n, int m,
+                                          float* err_out, uint8_t* mask_out, void* stream) {
+    if (rows <= 0 || count <= 0 || count > 128 || ldw < i1 + count || ldh < i1 + count || i1 < 0)
+        return ECOFLAP_ESIZE;
+    if (n <= 0 || m < n || m > 16 || (count % m != 0 && count % m < n)) return ECOFLAP_ESIZE;
+    if (!W || !Hinv || !err_out) return ECOFLAP_ENULL;
+    const size_t lds = ((size_t)count * (count + 1) / 2) * sizeof(float);
+    hipLaunchKernelGGL(sgpt_sweep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), lds,
+                       (hipStream_t)stream, W, rows, ldw, Hinv, ldh, i1, count, 0u,
+                       (const SgptSelState*)nullptr, 0, (const uint8_t*)nullptr, err_out, mask_out, n, m);
     ECO_CHECK_LAUNCH();
     return 0;
 }

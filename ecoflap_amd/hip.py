@@ -30,7 +30,7 @@ EXPORTS = [
     "ecoflap_wanda_prune_matrix", "ecoflap_wanda_prune_nm", "ecoflap_wanda_block_workspace_bytes",
     "ecoflap_wanda_prune_block",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
-    "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block",
+    "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block", "ecoflap_sparsegpt_block_nm",
     "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_global_prune_protected_workspace_bytes",
@@ -122,6 +122,7 @@ def load_library():
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
+    lib.ecoflap_sparsegpt_block_nm.argtypes = [vp, i64, i64, vp, i64, i64, ci, ci, ci, vp, vp, vp]
     lib.ecoflap_hessian_workspace_bytes.restype = sz
     lib.ecoflap_hessian_workspace_bytes.argtypes = [i64, i64]
     lib.ecoflap_hessian_accum.argtypes = [vp, vp, i64, i64, ci, i64, i64, vp, sz, vp]
@@ -584,6 +585,15 @@ class HipKernels:
             _ptr(W), W.shape[0], W.stride(0), _ptr(Hinv), Hinv.stride(0), int(i1), int(count),
             int(k), None, _ptr(err_out), _ptr(mask_out), _ptr(ws), ws.numel(), _stream()),
             "ecoflap_sparsegpt_block")
+
+    def sparsegpt_block_nm(self, W, Hinv, i1, count, n, m, err_out, mask_out=None):
+        """The block step under n:m sparsity (sparsegpt_pruner.py:196-198)."""
+        _gpu(W, "W"), _gpu(Hinv, "Hinv"), _gpu(err_out, "err_out")
+        if W.dtype != torch.float32 or Hinv.dtype != torch.float32:
+            raise EcoflapHipError("SparseGPT works on fp32 copies, as the reference does")
+        _check(self.lib.ecoflap_sparsegpt_block_nm(
+            _ptr(W), W.shape[0], W.stride(0), _ptr(Hinv), Hinv.stride(0), int(i1), int(count),
+            int(n), int(m), _ptr(err_out), _ptr(mask_out), _stream()), "ecoflap_sparsegpt_block_nm")
 
     # ---- K8 ---------------------------------------------------------------------------
     def hessian_accum(self, H, x2d, nsamples_before, batch):

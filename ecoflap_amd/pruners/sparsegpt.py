@@ -97,9 +97,6 @@ class SparseGPT:
         wi_0/wi_1, cross-attention k/v: bit-identical H, checked by the caller) and has already
         been pruned — its dead-column mask and factor Hinv depend on H only and are reused
         instead of being recomputed (two Cholesky factorisations and an inverse each)."""
-        if prune_n != 0:
-            raise NotImplementedError("N:M sparsity: prune_n is always 0 in the reference "
-                                      "(layer_single_base_pruner.py:62)")
         self.flush()
         W = self.layer.weight.data.clone().float()
         H = self.H
@@ -124,8 +121,11 @@ class SparseGPT:
             i2 = min(i1 + blocksize, self.columns)
             count = i2 - i1
             err = torch.empty((self.rows, count), dtype=torch.float32, device=W.device)
-            k = int(self.rows * count * sparsity)                 # int(tmp.numel() * sparsity) (:187)
-            self.kernels.sparsegpt_block(W, Hinv, i1, count, k, err)
+            if prune_n != 0:                                      # n:m, mask grown in the sweep (:190, :196-198)
+                self.kernels.sparsegpt_block_nm(W, Hinv, i1, count, prune_n, prune_m, err)
+            else:
+                k = int(self.rows * count * sparsity)             # int(tmp.numel() * sparsity) (:187)
+                self.kernels.sparsegpt_block(W, Hinv, i1, count, k, err)
             if i2 < self.columns:
                 W[:, i2:] -= err.matmul(Hinv[i1:i2, i2:])         # (:216)
         self.layer.weight.data = W.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)

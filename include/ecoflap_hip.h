@@ -317,6 +317,15 @@ int ecoflap_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hi
                             const uint8_t* mask_in, float* err_out, uint8_t* mask_out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same block step under n:m (sparsegpt_pruner.py:190, :196-198; `prune_n` is 0 in every shipped
+ * config): no threshold — at every block column i with i % m == 0 the n smallest
+ * W1[:, i:i+m]**2 / diag(Hinv1)[i:i+m]**2 of each row, taken on the sweep's CURRENT values, join
+ * the mask (`torch.topk(..., largest=False)`: NaN counts as the largest; equal values: the lower
+ * column first).  0 < n <= m <= 16; no workspace. */
+int ecoflap_sparsegpt_block_nm(float* W, int64_t rows, int64_t ldw, const float* Hinv, int64_t ldh,
+                               int64_t i1, int count, int n, int m, float* err_out,
+                               uint8_t* mask_out, void* stream);
+
 /* SparseGPT Hessian accumulation, the path's one GEMM-shaped
  * contraction, on the matrix cores:
  * replaces SparseGPT.add_batch   LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:71-82

@@ -54,6 +54,7 @@ class Oracle:
         L.oracle_mask_mul.argtypes = [vp, vp, i64, ci]
         L.oracle_round_array.argtypes = [vp, i64, ci]
         L.oracle_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp]
+        L.oracle_sparsegpt_block_nm.argtypes = [vp, i64, i64, vp, i64, i64, ci, ci, ci, vp, vp]
 
     def zo_perturb(self, w, scaling_factor, zo_eps, z):
         _cpu(w), _cpu(z)
@@ -152,6 +153,15 @@ class Oracle:
         self.lib.oracle_sparsegpt_block(_p(W), W.shape[0], W.stride(0), _p(Hinv), Hinv.stride(0),
                                         i1, count, k, _p(err_out),
                                         _p(mask_out) if mask_out is not None else None)
+
+    def sparsegpt_block_nm(self, W, Hinv, i1, count, n, m, err_out, mask_out=None):
+        assert W.dtype == torch.float32 and Hinv.dtype == torch.float32
+        assert W.stride(1) == 1 and Hinv.stride(1) == 1
+        if not 0 < n <= m <= 64 or (count % m and count % m < n):
+            raise ValueError("n:m needs 0 < n <= m <= 64 and no group shorter than n")
+        self.lib.oracle_sparsegpt_block_nm(_p(W), W.shape[0], W.stride(0), _p(Hinv), Hinv.stride(0),
+                                           i1, count, n, m, _p(err_out),
+                                           _p(mask_out) if mask_out is not None else None)
 
     def round_array(self, x, dtype):
         _cpu(x)

@@ -439,3 +439,49 @@ void oracle_sparsegpt_block(float* W, int64_t rows, int64_t ldw, const float* Hi
     }
     free(tmp); free(srt); free(w1);
 }
+
+/* The same block step under n:m (sparsegpt_pruner.py:190, :196-198): no threshold; at every block
+ * column i with i % m == 0 the n smallest `W1[:, i:i+m]**2 / diag(Hinv1)[i:i+m]**2` of each row —
+ * on the CURRENT values of the sweep — join the mask (`torch.topk(..., largest=False)`: NaN counts
+ * as the largest; equal values: the lower column first, this build's rule).  A group cut short by
+ * the block's end is selected among its own columns; the caller rejects one shorter than n. */
+void oracle_sparsegpt_block_nm(float* W, int64_t rows, int64_t ldw, const float* Hinv, int64_t ldh,
+                               int64_t i1, int count, int n, int m, float* err_out, uint8_t* mask_out) {
+    float* w1 = (float*)malloc(sizeof(float) * (size_t)count);
+    uint8_t* mk = (uint8_t*)malloc((size_t)count);
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int c = 0; c < count; ++c) { w1[c] = W[r * ldw + i1 + c]; mk[c] = 0; }
+        for (int i = 0; i < count; ++i) {
+            if (i % m == 0) {
+                int len = count - i < m ? count - i : m;
+                float t[64];
+                for (int p = 0; p < len; ++p) {
+                    float w = w1[i + p], d = Hinv[(i1 + i + p) * ldh + i1 + i + p];
+                    float a = w * w, b = d * d;
+                    t[p] = a / b;
+                }
+                for (int p = 0; p < len; ++p) {
+                    int rank = 0;
+                    for (int q = 0; q < len; ++q) {
+                        if (q == p) continue;
+                        int less = cmp_f(&t[q], &t[p]);
+                        if (less < 0 || (less == 0 && q < p)) ++rank;
+                    }
+                    if (rank < n) mk[i + p] = 1;
+                }
+            }
+            int masked = mk[i];
+            float wi = w1[i], d = Hinv[(i1 + i) * ldh + i1 + i];
+            float q = masked ? 0.0f : wi;
+            float err = (wi - q) / d;
+            for (int j = i; j < count; ++j) {
+                float p = err * Hinv[(i1 + i) * ldh + i1 + j];
+                w1[j] = w1[j] - p;
+            }
+            W[r * ldw + i1 + i] = q;
+            err_out[r * count + i] = err;
+            if (mask_out) mask_out[r * count + i] = (uint8_t)masked;
+        }
+    }
+    free(w1); free(mk);
+}

@@ -565,6 +565,48 @@ def golden_sparsegpt(registry):
              sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum"))
     save("g10_sparsegpt.npz", **out)
 
+    # ---- g17: the n:m branch of the same object / pruner (sparsegpt_pruner.py:190, :196-198)
+    out = {}
+    g = torch.Generator().manual_seed(78)
+    cases = []
+    for tag, rows, cols, n, m, dead in [("a", 40, 300, 2, 4, False), ("b", 24, 128, 1, 4, False),
+                                        ("c", 16, 200, 4, 8, True)]:
+        lin = nn.Linear(cols, rows, bias=False)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(rows, cols, generator=g) * 0.1)
+        sg = mod.SparseGPT(lin)
+        out[f"{tag}_w0"] = bits(lin.weight.data)
+        for bi in range(3):
+            x = torch.randn(2, 9, cols, generator=g)
+            if dead:
+                x[..., 5] = 0
+                x[..., 77] = 0
+            out[f"{tag}_x{bi}"] = bits(x)
+            sg.add_batch(x, None)
+        sg.fasterprune(0.5, prune_n=n, prune_m=m, percdamp=0.01, blocksize=128)
+        out[f"{tag}_w1"] = bits(lin.weight.data)
+        cases.append(f"{tag}|{rows}|{cols}|{n}|{m}")
+    out["cases"] = np.array(cases)
+
+    def run_nm(tag, pname, model, batches, cfg, n, m):
+        for k, v in model.state_dict().items():
+            out[f"{tag}_init::{k}"] = bits(v)
+        np.random.seed(42)
+        torch.manual_seed(42)
+        pruner = registry.get_pruner_class(pname)(model=model, data_loader=batches, **cfg)
+        pruner.prune_n, pruner.prune_m = n, m          # (the constructor wires 0: :62)
+        model2, sp = pruner.prune()
+        for k, v in model2.state_dict().items():
+            out[f"{tag}_final::{k}"] = bits(v)
+        out[f"{tag}_nm"] = np.array([n, m])
+
+    torch.manual_seed(44)
+    run_nm("vit", "vit_sparsegpt_pruner", vit_toy().eval(),
+           S.image_label_batches(8, 1, img_size=32, num_classes=5, seed=5),
+           dict(cfgbase, prune_spec="3-0.5-1.0-1.0", sparsity_ratio_granularity=None,
+                score_method="MEZO-GradOnly_sum"), 2, 4)
+    save("g17_sparsegpt_nm.npz", **out)
+
 
 # --------------------------------------------------------------------------- G11: Real-* scoring
 def golden_real(LayerSparsity, lavis, registry):

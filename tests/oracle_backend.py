@@ -154,6 +154,16 @@ class OracleKernels:
         if mask_out is not None:
             mask_out.copy_(m)
 
+    def sparsegpt_block_nm(self, W, Hinv, i1, count, n, m, err_out, mask_out=None):
+        h = self._host(W)
+        e = torch.empty(err_out.shape, dtype=torch.float32)
+        mk = torch.zeros(err_out.shape, dtype=torch.uint8) if mask_out is not None else None
+        self.o.sparsegpt_block_nm(h, self._host(Hinv), i1, count, n, m, e, mk)
+        W.copy_(h)
+        err_out.copy_(e)
+        if mask_out is not None:
+            mask_out.copy_(mk)
+
     def mask_mul(self, g, keep_mask):
         h = self._host(g)
         self.o.mask_mul(h, self._host(keep_mask))

@@ -1160,6 +1160,54 @@ def test_sparsegpt_block_vs_oracle(kern, oracle, rows, cols, i1, count, frac):
     assert int(mr.sum()) >= k + 1
 
 
+@pytest.mark.parametrize("rows,cols,i1,count,n,m", [(40, 300, 0, 128, 2, 4), (40, 300, 256, 44, 1, 4),
+                                                    (6144, 1408, 128, 128, 2, 4), (7, 128, 0, 128, 4, 8),
+                                                    (2048, 5120, 4992, 128, 3, 16), (9, 200, 128, 70, 2, 4)])
+def test_sparsegpt_block_n_m_vs_oracle(kern, oracle, rows, cols, i1, count, n, m):
+    """The block step under n:m (sparsegpt_pruner.py:196-198; the mask grows during the sweep, on
+    the sweep's current values): weights, Err1 and mask bit-exact against the oracle, n per full
+    group, a group cut short by the block's end (70 = 17 * 4 + 2), equal metrics (duplicated
+    columns) and a zero diagonal entry's inf / NaN metrics included."""
+    torch.manual_seed(rows + cols + n)
+    W = torch.randn(rows, cols) * 0.05
+    W[:, i1 + 5] = W[:, i1 + 4]                  # ties inside a group
+    W[0, i1 + 8:i1 + 12] = 0.0
+    A = torch.randn(cols, cols) * 0.1
+    Hinv = torch.linalg.cholesky(A @ A.t() + torch.eye(cols), upper=True).contiguous()
+    Wg, Hg = gpu(W.clone()), gpu(Hinv)
+    err = torch.empty(rows, count, device="cuda")
+    mask = torch.zeros(rows, count, dtype=torch.uint8, device="cuda")
+    kern.sparsegpt_block_nm(Wg, Hg, i1, count, n, m, err, mask)
+    Wr = W.clone()
+    er = torch.empty(rows, count)
+    mr = torch.zeros(rows, count, dtype=torch.uint8)
+    oracle.sparsegpt_block_nm(Wr, Hinv, i1, count, n, m, er, mr)
+    assert torch.equal(mask.cpu(), mr)
+    assert torch.equal(Wg.cpu().view(torch.int32), Wr.view(torch.int32))
+    assert torch.equal(err.cpu().view(torch.int32), er.view(torch.int32))
+    full = count // m * m
+    assert (mr[:, :full].reshape(rows, -1, m).sum(-1) == n).all()
+    if count % m:
+        assert (mr[:, full:].sum(-1) == n).all()
+    if m > 2:           # a group of one column at the block's end, n = 2: the reference's topk raises
+        with pytest.raises(Exception):
+            kern.sparsegpt_block_nm(Wg, Hg, i1, m + 1, 2, m, err[:, :m + 1].contiguous())
+
+
+def test_sparsegpt_pruner_n_m_hip_equals_oracle(kern, golden_dir, monkeypatch):
+    from oracle_backend import OracleKernels
+    from test_sparsegpt_parity import run_sparsegpt_nm_e2e
+    from ecoflap_amd.pruners.sparsegpt import SparseGPT
+    monkeypatch.setattr(SparseGPT, "use_mfma_hessian", False)
+    res = {}
+    for name, backend in (("hip", kern), ("oracle", OracleKernels())):
+        _, model = run_sparsegpt_nm_e2e(golden_dir, backend, device="cuda")
+        res[name] = {k: v.cpu() for k, v in model.state_dict().items()}
+    for k, v in res["hip"].items():
+        assert torch.equal(v, res["oracle"][k]), k
+    assert sum(int((v == 0).sum()) for k, v in res["hip"].items() if v.dim() == 2 and ".block" in k) > 0
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tokens,cols", [(8 * 257, 1408), (37, 130), (64, 128), (200, 257), (128, 2048),
                                          (8 * 257, 6144), (100, 2100), (8 * 384, 5120), (70, 2305),

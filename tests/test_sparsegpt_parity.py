@@ -84,3 +84,47 @@ def test_sparsegpt_pruners_end_to_end(golden_dir, tag):
     g, model, _ = run_sparsegpt_e2e(tag, golden_dir, OracleKernels())
     for k, v in model.state_dict().items():
         assert np.array_equal(to_bits(v).ravel(), g[f"{tag}_final::{k}"].ravel()), k
+
+
+# ---------------------------------------------------------------- the n:m branch (:190, :196-198)
+def test_sparsegpt_object_n_m_matches_reference(golden_dir):
+    """`fasterprune(prune_n, prune_m)`: the reference's own SparseGPT object produced g17 — pruned
+    weights bit for bit, and exactly n zeros in every full group of m columns."""
+    g = np.load(os.path.join(golden_dir, "g17_sparsegpt_nm.npz"))
+    for case in g["cases"]:
+        tag, rows, cols, n, m = str(case).split("|")
+        rows, cols, n, m = int(rows), int(cols), int(n), int(m)
+        lin = nn.Linear(cols, rows, bias=False)
+        lin.weight.data = from_bits(g[f"{tag}_w0"], torch.float32).reshape(rows, cols).clone()
+        sg = SparseGPT(lin, kernels=OracleKernels())
+        for bi in range(3):
+            sg.add_batch(from_bits(g[f"{tag}_x{bi}"], torch.float32), None)
+        sg.fasterprune(0.5, prune_n=n, prune_m=m, percdamp=0.01, blocksize=128)
+        got = lin.weight.data
+        assert np.array_equal(to_bits(got).ravel(), g[f"{tag}_w1"].ravel()), tag
+        full = cols // m * m
+        zeros = (got[:, :full].reshape(rows, -1, m) == 0).sum(-1)
+        assert int(zeros.min()) >= n, tag            # (dead columns add zeros of their own)
+
+
+def run_sparsegpt_nm_e2e(golden_dir, kernels, device="cpu"):
+    g = np.load(os.path.join(golden_dir, "g17_sparsegpt_nm.npz"))
+    name, make_model, make_batches, cfg = E2E["vit"]
+    model = make_model()
+    sd = {k: from_bits(g[f"vit_init::{k}"], v.dtype).reshape(v.shape).clone()
+          for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model.to(device)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    pruner = load_pruner(name, model, make_batches(),
+                         cfg=dict(cfg, kernels=kernels, z_source=torch_cpu_normal))
+    pruner.prune_n, pruner.prune_m = (int(x) for x in g["vit_nm"])
+    model, _ = pruner.prune()
+    return g, model
+
+
+def test_sparsegpt_pruner_n_m_end_to_end(golden_dir):
+    g, model = run_sparsegpt_nm_e2e(golden_dir, OracleKernels())
+    for k, v in model.state_dict().items():
+        assert np.array_equal(to_bits(v).ravel(), g[f"vit_final::{k}"].ravel()), k
