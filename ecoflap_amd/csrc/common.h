@@ -83,9 +83,11 @@ template <> struct Vec<ECOFLAP_F16> {
     static __device__ __forceinline__ float round(float x) { return h2f(f2h(x)); }
     // round two values with ONE packed convert; returns the packed pair (ready to store)
     static __device__ __forceinline__ uint32_t round_pair(float x0, float x1, float& r0, float& r1) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
         const uint32_t pk = f2h_pk(x0, x1);
-        r0 = h2f(pk & 0xffffu);
-        r1 = h2f(pk >> 16);
+        const h2_t h = __builtin_bit_cast(h2_t, pk);     // (element extracts: a consumer's fma can take the half directly)
+        r0 = (float)h[0];
+        r1 = (float)h[1];
         return pk;
     }
     static __device__ __forceinline__ float load1(const void* p, int64_t i) {

@@ -177,8 +177,14 @@ static __device__ __forceinline__ void unit_update(u32x4& st, const float* z, fl
     } else if constexpr (FAST && DT == ECOFLAP_F16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t u1 = Vec<DT>::f2h_pk(z[2 * i] * eps, z[2 * i + 1] * eps);
-            const uint32_t u2 = Vec<DT>::f2h_pk((z[2 * i] * -2.0f) * eps, (z[2 * i + 1] * -2.0f) * eps);
+            // z is an f16 value held as f32: fma(z, eps, -0) = z * eps bit for bit (also for a zero
+            // product's sign) and lets the f16 -> f32 convert fold into the multiply
+            // (v_fma_mix_f32); (z * -2) * eps = z * (-2 eps): both scalings by two are exact.
+            const float m2eps = -2.0f * eps;
+            const uint32_t u1 = Vec<DT>::f2h_pk(__builtin_fmaf(z[2 * i], eps, -0.0f),
+                                                __builtin_fmaf(z[2 * i + 1], eps, -0.0f));
+            const uint32_t u2 = Vec<DT>::f2h_pk(__builtin_fmaf(z[2 * i], m2eps, -0.0f),
+                                                __builtin_fmaf(z[2 * i + 1], m2eps, -0.0f));
             const half2_t h1 = __builtin_bit_cast(half2_t, u1), h2 = __builtin_bit_cast(half2_t, u2);
             const uint32_t cur = st[i];   // (bit_cast of a vector-element lvalue reads lane 0)
             const half2_t p = __builtin_bit_cast(half2_t, cur) + h1;
