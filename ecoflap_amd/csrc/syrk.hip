@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
 #define S2_OPB (S2_T * S2_KC * 2)      // bytes per operand and stage (16 KB)
 #define S2_STG (2 * S2_OPB)
 #define S2_NBUF 2
+#ifndef S2_W8_FREE
+#define S2_W8_FREE 0     // experiment: 1 = no issue-order constraints inside a half stage of the 8-wave form
+#endif
 #define S2_MIN_COLS 5633   // 256-wide tiles when there are more of them than CUs (MI355X: C > 22 * 256); below, the kernel above
 
 // Work split of one call: the chip runs `G` workgroups (one per CU), the upper triangle has
@@ -258,21 +261,29 @@ struct Syrk256Plan {
     unsigned* tickets;       // [left] + 1 (the work counter), zeroed ahead of the launch
 };
 
-template <int DT>
-__global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict__ xt, int64_t C,
-                                                      int64_t Kpad, float* __restrict__ H,
-                                                      float beta, float alpha, Syrk256Plan P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[S2_NBUF * S2_STG];
+// NW = 4: waves 2 x 2, 128x128 each, one per SIMD.  NW = 8: waves 2 x 4, 128x64 each, TWO per SIMD
+// (128 accumulator registers): one wave's barrier / LDS wait is the other's MFMA time, at 6 LDS
+// reads per 8 MFMAs instead of 8 per 16.
+template <int DT, int NW>
+__global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __restrict__ xt, int64_t C,
+                                                          int64_t Kpad, float* __restrict__ H,
+                                                          float beta, float alpha, Syrk256Plan P) {
+    constexpr int NI = NW == 4 ? 4 : 2;              // MFMA tiles per wave along the columns
+    constexpr int NP = 16 / NW;                      // 1-KiB pieces per wave, operand and stage
+    constexpr int NT = 64 * NW;
+    constexpr int MIRROR_BYTES = NW * 32 * 65 * 4;   // per wave [32 cols][64 rows + 1] floats
+    __shared__ __attribute__((aligned(16))) unsigned char
+        lds[S2_NBUF * S2_STG > MIRROR_BYTES ? S2_NBUF * S2_STG : MIRROR_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
     const int r = lane & 31, h = lane >> 5;
     const int nst_all = (int)(Kpad / S2_KC), npairs = nst_all / 2;
     // this workgroup's items: its slice (if any), then its whole tiles (XCD x = blockIdx % 8 takes a
     // contiguous range of the column-major tile order: neighbours share panels in ITS L2).  (Tried:
-    // handing the items out through a counter, 8 slices per left-over tile: slower, the slabs'
-    // hand-off costs more than the better balance returns; write-through slab stores instead of
-    // the release fence: 40 % slower.)
+    // tiles first and the slices drawn from a counter, 4 / 5 / 8 slices per left-over tile, with 4
+    // and with 8 waves: 5-15 % slower every time — the slices and their reducers then sit at the
+    // END of the launch; write-through slab stores instead of the release fence: 40 % slower.)
     const int b = (int)blockIdx.x;
     const int nslices = P.left * P.S;
     const int per = (P.G + 7) / 8;
@@ -299,11 +310,11 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
         // 16 p + (lane >> 2), slot lane & 3, which holds segment slot ^ ((row >> 2) & 3)
         const int q = lane >> 2;
         const int seg = (lane & 3) ^ ((lane >> 4) & 3);
-        const uint16_t* pa[4];
-        const uint16_t* pb[4];
+        const uint16_t* pa[NP];
+        const uint16_t* pb[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t ra = rowA0 + 16 * (wave + 4 * i) + q, rb = rowB0 + 16 * (wave + 4 * i) + q;
+        for (int i = 0; i < NP; ++i) {
+            int64_t ra = rowA0 + 16 * (wave + NW * i) + q, rb = rowB0 + 16 * (wave + NW * i) + q;
             ra = ra < C ? ra : C - 1;            // rows past C: any valid row (their products are dropped)
             rb = rb < C ? rb : C - 1;
             pa[i] = xt + ra * Kpad + seg * 8;
@@ -311,44 +322,44 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
         }
         // (a diagonal tile loads its panel twice: the loop is the same for every tile — 24 of 300)
 
-        f32x16 acc[4][4];
+        f32x16 acc[4][NI];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
         const int swz = (r >> 2) & 3;
-        const int offA = (wm * 128 + r) * 64, offB = (wn * 128 + r) * 64 + S2_OPB;
+        const int offA = (wm * 128 + r) * 64, offB = (wn * (32 * NI) + r) * 64 + S2_OPB;
         const int so0 = (h ^ swz) << 4, so1 = ((2 + h) ^ swz) << 4;       // k-steps 0 and 1 of a stage
-        u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+        u32x4 fa0[4], fb0[NI], fa1[4], fb1[NI];
 #define S2_READ(FA, FB, BASE, SO)                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                         \
         FA[i_] = *(const u32x4*)((BASE) + offA + i_ * 2048 + (SO));          \
-        FB[i_] = *(const u32x4*)((BASE) + offB + i_ * 2048 + (SO));          \
-    }
+    _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_)                        \
+        FB[i_] = *(const u32x4*)((BASE) + offB + i_ * 2048 + (SO));
 #define S2_MFMA(FA, FB)                                                      \
     _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                      \
-        _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                  \
+        _Pragma("unroll") for (int ni_ = 0; ni_ < NI; ++ni_)                 \
             acc[mi_][ni_] = Mfma<DT>::run(FA[mi_], FB[ni_], acc[mi_][ni_]);
         // global -> registers -> LDS, two register stages in flight (the loads of stage i + 2 and
         // i + 3 are outstanding while stage i computes; the compiler's vmcnt is counted, in order)
-        u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+        u32x4 ra0[NP], rb0[NP], ra1[NP], rb1[NP];
         const int wofs = 1024 * wave + 16 * lane;      // lane-linear image: row 16 p + (lane >> 2), slot lane & 3
         const int64_t klast = (int64_t)(st1 - 1) * S2_KC;
 #define S2_GLOAD(RA, RB, ST)                                                 \
     {                                                                        \
         const int64_t k0_ = (ST) < st1 ? (int64_t)(ST) * S2_KC : klast;      \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                  \
             RA[i_] = *(const u32x4*)(pa[i_] + k0_);                          \
             RB[i_] = *(const u32x4*)(pb[i_] + k0_);                          \
         }                                                                    \
     }
 #define S2_LWRITE(RA, RB, BUF)                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                       \
-        *(u32x4*)((BUF) + wofs + 4096 * i_) = RA[i_];                        \
-        *(u32x4*)((BUF) + S2_OPB + wofs + 4096 * i_) = RB[i_];               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                      \
+        *(u32x4*)((BUF) + wofs + 1024 * NW * i_) = RA[i_];                   \
+        *(u32x4*)((BUF) + S2_OPB + wofs + 1024 * NW * i_) = RB[i_];          \
     }
     // all of this wave's LDS traffic is done (its reads of the buffer about to be overwritten next
     // and its writes), then everybody's; global loads stay in flight (no vmcnt here)
@@ -373,12 +384,12 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
     // MFMAs, then 8 bare MFMAs under which the LDS traffic drains before the barrier / the next
     // half needs it.
 #define S2_PIPE(SECOND_MASK)                                                 \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                       \
+    if (NW == 4 || !S2_W8_FREE) _Pragma("unroll") for (int g_ = 0; g_ < 4 + NI; ++g_) { \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
-        __builtin_amdgcn_sched_group_barrier(SECOND_MASK, 1, 0);             \
+        if (g_ < 2 * NP) __builtin_amdgcn_sched_group_barrier(SECOND_MASK, 1, 0); \
     }                                                                        \
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                       \
+    if (NW == 4 || !S2_W8_FREE) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI - (4 + NI), 0); \
     __builtin_amdgcn_sched_barrier(0)
 #define S2_STAGE(CUR, NXT, RA, RB, ST)                                       \
     S2_READ(fa1, fb1, CUR, so1);                                             \
@@ -412,12 +423,12 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         f32x4 v = {acc[mi][ni][4 * e4], acc[mi][ni][4 * e4 + 1], acc[mi][ni][4 * e4 + 2],
                                    acc[mi][ni][4 * e4 + 3]};
-                        *(f32x4*)(mine + ((((mi * 4 + ni) * 4 + e4) * 256 + tid) << 2)) = v;
+                        *(f32x4*)(mine + ((((mi * NI + ni) * 4 + e4) * NT + tid) << 2)) = v;
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -444,10 +455,10 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) {
-                            const f32x4 v = *(const f32x4*)(src + ((((mi * 4 + ni) * 4 + e4) * 256 + tid) << 2));
+                            const f32x4 v = *(const f32x4*)(src + ((((mi * NI + ni) * 4 + e4) * NT + tid) << 2));
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
                                 acc[mi][ni][4 * e4 + c] = sl == 0 ? v[c] : acc[mi][ni][4 * e4 + c] + v[c];
@@ -459,8 +470,8 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int64_t gc = rowB0 + wn * 128 + ni * 32 + r;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t gc = rowB0 + wn * (32 * NI) + ni * 32 + r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t gr = rowA0 + wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -473,26 +484,24 @@ __global__ __launch_bounds__(256) void syrk256_kernel(const uint16_t* __restrict
                 }
             }
         if (bi == bj) continue;
-        float* ldsT = (float*)lds + wave * (32 * 129);         // per wave [32 cols][128 rows + 1]
+        float* ldsT = (float*)lds + wave * (32 * 65);          // per wave [32 cols][64 rows + 1]
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            __syncthreads();                                   // previous column block is out
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int hm = 0; hm < 2; ++hm) {                   // rows 64 hm .. 64 hm + 63 of the wave's 128
+                __syncthreads();                               // the previous part is out
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    ldsT[r * 129 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[mi][ni][e];
-            __syncthreads();
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int row = lane + 64 * half;
-                const int64_t gr = rowA0 + wm * 128 + row;      // original row -> mirrored column
+                    for (int e = 0; e < 16; ++e)
+                        ldsT[r * 65 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[2 * hm + mi][ni][e];
+                __syncthreads();
+                const int64_t gr = rowA0 + wm * 128 + 64 * hm + lane;      // original row -> mirrored column
                 for (int c = 0; c < 32; ++c) {
-                    const int64_t gc = rowB0 + wn * 128 + ni * 32 + c;
-                    if (gc < C && gr < C) H[gc * C + gr] = ldsT[c * 129 + row];
+                    const int64_t gc = rowB0 + wn * (32 * NI) + ni * 32 + c;
+                    if (gc < C && gr < C) H[gc * C + gr] = ldsT[c * 65 + lane];
                 }
             }
-        }
     }
 }
 
@@ -557,12 +566,20 @@ static inline size_t syrk_xt_bytes(int64_t tokens, int64_t cols) {
     return ((size_t)cols * (size_t)syrk_kpad(tokens) * 2 + 255) / 256 * 256;      // Xt, 16-bit
 }
 
+// 256-wide tiles: when the upper triangle has more of them than CUs and K is long (short K: the
+// slabs' hand-off costs more than the balance returns)
+static inline bool syrk_use256(int64_t cols, int64_t kpad) {
+    static const int64_t min_cols = getenv("ECOFLAP_SYRK_MINCOLS") ? atoll(getenv("ECOFLAP_SYRK_MINCOLS")) : S2_MIN_COLS;
+    static const int64_t min_k = getenv("ECOFLAP_SYRK_MINK") ? atoll(getenv("ECOFLAP_SYRK_MINK")) : 4096;
+    return cols >= min_cols && kpad >= min_k;
+}
+
 extern "C" size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols) {
     if (tokens <= 0 || cols <= 0) return 0;
     size_t n = syrk_xt_bytes(tokens, cols);
     const int ks = syrk_kslices(cols, syrk_kpad(tokens));
     if (ks > 1) n += (size_t)ks * (((size_t)cols * cols * sizeof(float) + 255) / 256 * 256);
-    if (cols >= S2_MIN_COLS && syrk_kpad(tokens) >= 4096) {   // K-slice slabs + tickets of the 256-wide kernel
+    if (syrk_use256(cols, syrk_kpad(tokens))) {              // K-slice slabs + tickets of the 256-wide kernel
         const Syrk256Plan p = syrk256_plan(cols, syrk_kpad(tokens));
         n += (size_t)p.left * p.S * S2_T * S2_T * sizeof(float) + ((size_t)(p.left + 1) * sizeof(unsigned) + 255) / 256 * 256;
     }
@@ -596,7 +613,7 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
     const float beta = (float)((double)nsamples_before / (double)(nsamples_before + batch));
     const float alpha = (float)(2.0 / (double)(nsamples_before + batch));
     static const bool no256 = getenv("ECOFLAP_SYRK_NO256") != nullptr;     // A/B switch
-    if (cols >= S2_MIN_COLS && kpad >= 4096 && !no256) {     // (short K: the slabs' hand-off costs more than the balance returns)
+    if (syrk_use256(cols, kpad) && !no256) {     // (short K: the slabs' hand-off costs more than the balance returns)
         Syrk256Plan p = syrk256_plan(cols, kpad);
         char* after = (char*)workspace + syrk_xt_bytes(tokens, cols);
         p.slabs = (float*)after;
@@ -605,10 +622,16 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
             const hipError_t e = hipMemsetAsync(p.tickets, 0, (size_t)(p.left + 1) * sizeof(unsigned), s);
             if (e != hipSuccess) return (int)e;
         }
-        if (dtype == ECOFLAP_F16)
-            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
+        static const bool w8 = getenv("ECOFLAP_SYRK_W8") != nullptr;          // A/B: 8 waves of 128x64
+        if (w8) {
+            if (dtype == ECOFLAP_F16)
+                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16, 8>), dim3((unsigned)p.G), dim3(512), 0, s, xt, cols, kpad, H, beta, alpha, p);
+            else
+                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16, 8>), dim3((unsigned)p.G), dim3(512), 0, s, xt, cols, kpad, H, beta, alpha, p);
+        } else if (dtype == ECOFLAP_F16)
+            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16, 4>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
         else
-            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
+            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16, 4>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
         ECO_CHECK_LAUNCH();
         return 0;
     }

@@ -15,7 +15,7 @@ import csv, sys, collections
 for path in sys.argv[1:]:
     disp = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
-        if "syrk256_kernel<1>" in r["Kernel_Name"]:
+        if "syrk256_kernel<1" in r["Kernel_Name"]:
             disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
     rows = list(disp.values())
     key = "SQ_WAVE_CYCLES" if "SQ_WAVE_CYCLES" in rows[0] else "GRBM_GUI_ACTIVE"
