@@ -19,9 +19,12 @@
 //      K in chunks of 64 staged through LDS (rows padded to 144 B: conflict-free ds_read_b128).
 //      Few tiles and long K (C = 1408 at 8 samples per call: 66 tiles of 128 for 256 CUs): 4
 //      K-slices (blockIdx.y) into partial buffers + syrk_combine_kernel (slice order).
-//   3. syrk256_kernel (C > 5632, Kpad >= 4096): 256-wide tiles, 128x128 per wave, one persistent
-//      workgroup per CU; the tiles beyond a whole round are cut into K-slices whose fp32 slabs the
-//      last slice to arrive (ticket) adds up in slice order.
+//   3. syrk256_kernel (C > 4096 and a long K): 256-wide tiles, one persistent workgroup per CU of
+//      8 waves (two per SIMD, 128x64 each), reading X AS IT LIES — no transposed copy: token-major
+//      stages in LDS, MFMA operands through ds_read_b64_tr_b16.  Tiles beyond a whole round are cut
+//      into K-slices whose fp32 slabs the last slice to arrive (ticket) adds up in slice order.
+//      (ECOFLAP_SYRK_FORM=1: the same on the transposed copy — taken when C % 8 != 0 —, =0: 4 waves
+//      of 128x128 on the transposed copy; A/B switches.)
 // Every path sums in a fixed order: the same call gives the same bits, whoever finishes last.
 // MFMA roofline: 2 * T * C * (C + 128) / 2 flops per call against the dense fp16/bf16 peak.
 #include "common.h"
@@ -244,10 +247,6 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
 #define S2_OPB (S2_T * S2_KC * 2)      // bytes per operand and stage (16 KB)
 #define S2_STG (2 * S2_OPB)
 #define S2_NBUF 2
-#ifndef S2_W8_FREE
-#define S2_W8_FREE 0     // experiment: 1 = no issue-order constraints inside a half stage of the 8-wave form
-#endif
-#define S2_MIN_COLS 5633   // 256-wide tiles when there are more of them than CUs (MI355X: C > 22 * 256); below, the kernel above
 
 // Work split of one call: the chip runs `G` workgroups (one per CU), the upper triangle has
 // `ntiles` tiles.  `full` = the largest multiple of G tiles are computed whole, one round each;
@@ -258,27 +257,39 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
 struct Syrk256Plan {
     int ntiles, full, left, S, G;
     float* slabs;            // [left * S][256 * 256] fp32, lane-linear (see s2_slab)
-    unsigned* tickets;       // [left] + 1 (the work counter), zeroed ahead of the launch
+    unsigned* tickets;       // [left], zeroed ahead of the launch
+    const void* zero16;      // 16 zero bytes (the zeroed words after the tickets)
 };
 
 // NW = 4: waves 2 x 2, 128x128 each, one per SIMD.  NW = 8: waves 2 x 4, 128x64 each, TWO per SIMD
 // (128 accumulator registers): one wave's barrier / LDS wait is the other's MFMA time, at 6 LDS
 // reads per 8 MFMAs instead of 8 per 16.
-template <int DT, int NW>
+// TRX: X is read as it lies, [tokens][C] — no transposed copy.  A stage is then 32 token rows of
+// 256 columns per operand (full 512-byte runs from memory), staged token-major in LDS with rows
+// of 576 B (4 consecutive rows cover all 64 banks once for the 8-byte transposed reads), and the
+// MFMA operands (8 consecutive k of one column per lane) come from `ds_read_b64_tr_b16`: lane
+// 4q + p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and receives
+// column (lane & 15) of the 4 rows.  `xt` = X, `Kpad` = the token count (any), rows past it and
+// 16-byte column runs past C are read from P.zero16.
+#define S2_TRP 576                                    // LDS bytes per token row of an operand (512 + 64)
+template <int DT, int NW, bool TRX>
 __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __restrict__ xt, int64_t C,
                                                           int64_t Kpad, float* __restrict__ H,
                                                           float beta, float alpha, Syrk256Plan P) {
     constexpr int NI = NW == 4 ? 4 : 2;              // MFMA tiles per wave along the columns
-    constexpr int NP = 16 / NW;                      // 1-KiB pieces per wave, operand and stage
+    constexpr int NP = 16 / NW;                      // loads per thread, operand and stage
     constexpr int NT = 64 * NW;
     constexpr int MIRROR_BYTES = NW * 32 * 65 * 4;   // per wave [32 cols][64 rows + 1] floats
+    constexpr int OPB = TRX ? S2_KC * S2_TRP : S2_OPB;        // bytes per operand and stage
+    constexpr int STG = 2 * OPB;
     __shared__ __attribute__((aligned(16))) unsigned char
-        lds[S2_NBUF * S2_STG > MIRROR_BYTES ? S2_NBUF * S2_STG : MIRROR_BYTES];
+        lds[S2_NBUF * STG > MIRROR_BYTES ? S2_NBUF * STG : MIRROR_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
     const int r = lane & 31, h = lane >> 5;
-    const int nst_all = (int)(Kpad / S2_KC), npairs = nst_all / 2;
+    const int nst_all = TRX ? 2 * (int)((Kpad + 2 * S2_KC - 1) / (2 * S2_KC)) : (int)(Kpad / S2_KC);
+    const int npairs = nst_all / 2;
     // this workgroup's items: its slice (if any), then its whole tiles (XCD x = blockIdx % 8 takes a
     // contiguous range of the column-major tile order: neighbours share panels in ITS L2).  (Tried:
     // tiles first and the slices drawn from a counter, 4 / 5 / 8 slices per left-over tile, with 4
@@ -306,19 +317,32 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
         const int bi = t - bj * (bj + 1) / 2;
         const int64_t rowA0 = (int64_t)bi * S2_T, rowB0 = (int64_t)bj * S2_T;
 
-        // global -> LDS image: piece p (16 rows x 64 B) of an operand goes to wave p & 3; lane -> row
-        // 16 p + (lane >> 2), slot lane & 3, which holds segment slot ^ ((row >> 2) & 3)
+        // global -> LDS image.  Transposed copy: piece p (16 rows x 64 B) of an operand goes to wave
+        // p % NW; lane -> row 16 p + (lane >> 2), slot lane & 3, which holds segment
+        // slot ^ ((row >> 2) & 3).  TRX: thread -> token row (tid >> 5) of a pass of NT / 32 rows,
+        // 16-byte column run tid & 31 of the operand's 256 columns.
         const int q = lane >> 2;
         const int seg = (lane & 3) ^ ((lane >> 4) & 3);
         const uint16_t* pa[NP];
         const uint16_t* pb[NP];
+        bool colA = true, colB = true;
+        if (TRX) {
+            colA = rowA0 + 8 * (tid & 31) + 8 <= C;
+            colB = rowB0 + 8 * (tid & 31) + 8 <= C;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            int64_t ra = rowA0 + 16 * (wave + NW * i) + q, rb = rowB0 + 16 * (wave + NW * i) + q;
-            ra = ra < C ? ra : C - 1;            // rows past C: any valid row (their products are dropped)
-            rb = rb < C ? rb : C - 1;
-            pa[i] = xt + ra * Kpad + seg * 8;
-            pb[i] = xt + rb * Kpad + seg * 8;
+            for (int i = 0; i < NP; ++i) {
+                pa[i] = xt + (int64_t)(i * (NT / 32) + (tid >> 5)) * C + rowA0 + 8 * (tid & 31);
+                pb[i] = xt + (int64_t)(i * (NT / 32) + (tid >> 5)) * C + rowB0 + 8 * (tid & 31);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                int64_t ra = rowA0 + 16 * (wave + NW * i) + q, rb = rowB0 + 16 * (wave + NW * i) + q;
+                ra = ra < C ? ra : C - 1;        // rows past C: any valid row (their products are dropped)
+                rb = rb < C ? rb : C - 1;
+                pa[i] = xt + ra * Kpad + seg * 8;
+                pb[i] = xt + rb * Kpad + seg * 8;
+            }
         }
         // (a diagonal tile loads its panel twice: the loop is the same for every tile — 24 of 300)
 
@@ -331,14 +355,29 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
         const int swz = (r >> 2) & 3;
-        const int offA = (wm * 128 + r) * 64, offB = (wn * (32 * NI) + r) * 64 + S2_OPB;
-        const int so0 = (h ^ swz) << 4, so1 = ((2 + h) ^ swz) << 4;       // k-steps 0 and 1 of a stage
+        // transposed copy: row-major operand rows, k-steps 0 / 1 of a stage are segments h, 2 + h;
+        // TRX: token rows 8 h + q (+ 4) of k-step 0 / 16 + the same of k-step 1, columns
+        // 16 (group & 1) + 4 p of the fragment's 32
+        const int trl = (8 * h + ((lane & 15) >> 2)) * S2_TRP + 2 * (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+        const int offA = TRX ? 2 * (wm * 128) + trl : (wm * 128 + r) * 64;
+        const int offB = TRX ? 2 * (wn * (32 * NI)) + trl + OPB : (wn * (32 * NI) + r) * 64 + OPB;
+        const int so0 = TRX ? 0 : (h ^ swz) << 4, so1 = TRX ? 16 * S2_TRP : ((2 + h) ^ swz) << 4;
         u32x4 fa0[4], fb0[NI], fa1[4], fb1[NI];
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#define S2_TR(ADDR) __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ADDR)))
+#define S2_READ1(F, ADDR_ROWMAJOR, ADDR_TR)                                  \
+    if (TRX) {                                                               \
+        const uint2 x0_ = S2_TR(ADDR_TR), x1_ = S2_TR((ADDR_TR) + 4 * S2_TRP); \
+        F = u32x4{x0_.x, x0_.y, x1_.x, x1_.y};                               \
+    } else {                                                                 \
+        F = *(const u32x4*)(ADDR_ROWMAJOR);                                  \
+    }
 #define S2_READ(FA, FB, BASE, SO)                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                         \
-        FA[i_] = *(const u32x4*)((BASE) + offA + i_ * 2048 + (SO));          \
+        S2_READ1(FA[i_], (BASE) + offA + i_ * 2048 + (SO), (BASE) + offA + i_ * 64 + (SO)) \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_)                        \
-        FB[i_] = *(const u32x4*)((BASE) + offB + i_ * 2048 + (SO));
+        S2_READ1(FB[i_], (BASE) + offB + i_ * 2048 + (SO), (BASE) + offB + i_ * 64 + (SO))
 #define S2_MFMA(FA, FB)                                                      \
     _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                      \
         _Pragma("unroll") for (int ni_ = 0; ni_ < NI; ++ni_)                 \
@@ -346,20 +385,30 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
         // global -> registers -> LDS, two register stages in flight (the loads of stage i + 2 and
         // i + 3 are outstanding while stage i computes; the compiler's vmcnt is counted, in order)
         u32x4 ra0[NP], rb0[NP], ra1[NP], rb1[NP];
-        const int wofs = 1024 * wave + 16 * lane;      // lane-linear image: row 16 p + (lane >> 2), slot lane & 3
+        // lane-linear image of the transposed copy (row 16 p + (lane >> 2), slot lane & 3) / TRX:
+        // token row (tid >> 5) of the pass, 16-byte run tid & 31
+        const int wofs = TRX ? (tid >> 5) * S2_TRP + 16 * (tid & 31) : 1024 * wave + 16 * lane;
+        constexpr int WSTRIDE = TRX ? (NT / 32) * S2_TRP : 1024 * NW;        // LDS bytes between a thread's loads
         const int64_t klast = (int64_t)(st1 - 1) * S2_KC;
+        const uint16_t* zero16 = (const uint16_t*)P.zero16;
 #define S2_GLOAD(RA, RB, ST)                                                 \
     {                                                                        \
         const int64_t k0_ = (ST) < st1 ? (int64_t)(ST) * S2_KC : klast;      \
         _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                  \
-            RA[i_] = *(const u32x4*)(pa[i_] + k0_);                          \
-            RB[i_] = *(const u32x4*)(pb[i_] + k0_);                          \
+            if (TRX) {                                                       \
+                const bool tok_ = k0_ + i_ * (NT / 32) + (tid >> 5) < Kpad;  \
+                RA[i_] = *(const u32x4*)(tok_ && colA ? pa[i_] + k0_ * C : zero16); \
+                RB[i_] = *(const u32x4*)(tok_ && colB ? pb[i_] + k0_ * C : zero16); \
+            } else {                                                         \
+                RA[i_] = *(const u32x4*)(pa[i_] + k0_);                      \
+                RB[i_] = *(const u32x4*)(pb[i_] + k0_);                      \
+            }                                                                \
         }                                                                    \
     }
 #define S2_LWRITE(RA, RB, BUF)                                               \
     _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                      \
-        *(u32x4*)((BUF) + wofs + 1024 * NW * i_) = RA[i_];                   \
-        *(u32x4*)((BUF) + S2_OPB + wofs + 1024 * NW * i_) = RB[i_];          \
+        *(u32x4*)((BUF) + wofs + WSTRIDE * i_) = RA[i_];                     \
+        *(u32x4*)((BUF) + OPB + wofs + WSTRIDE * i_) = RB[i_];               \
     }
     // all of this wave's LDS traffic is done (its reads of the buffer about to be overwritten next
     // and its writes), then everybody's; global loads stay in flight (no vmcnt here)
@@ -371,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
         // they live through a single loop; stage numbers past the end are clamped, the duplicates
         // land in a buffer nobody reads again).
         unsigned char* buf0 = lds;
-        unsigned char* buf1 = lds + S2_STG;
+        unsigned char* buf1 = lds + STG;
         __syncthreads();                          // the previous item's epilogue is out of the LDS
         S2_GLOAD(ra0, rb0, st0);
         S2_GLOAD(ra1, rb1, st0 + 1);
@@ -379,17 +428,17 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
         S2_SYNC();
         S2_READ(fa0, fb0, buf0, so0);
         S2_GLOAD(ra0, rb0, st0 + 2);
-    // Issue order inside a half stage (16 MFMAs, one wave per SIMD: whatever is not placed in an
-    // MFMA's shadow is paid in full): MFMA, LDS read, {LDS write | global load} for the first 8
-    // MFMAs, then 8 bare MFMAs under which the LDS traffic drains before the barrier / the next
-    // half needs it.
+    // Issue order inside a half stage (4 NI MFMAs; whatever is not placed in an MFMA's shadow is
+    // paid in full, also with two waves per SIMD: left to the compiler the 8-wave form runs 990 us
+    // instead of 867): MFMA, LDS read, {LDS write | global load} while there are any, then bare
+    // MFMAs under which the LDS traffic drains before the barrier / the next half needs it.
 #define S2_PIPE(SECOND_MASK)                                                 \
-    if (NW == 4 || !S2_W8_FREE) _Pragma("unroll") for (int g_ = 0; g_ < 4 + NI; ++g_) { \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4 + NI; ++g_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
         if (g_ < 2 * NP) __builtin_amdgcn_sched_group_barrier(SECOND_MASK, 1, 0); \
     }                                                                        \
-    if (NW == 4 || !S2_W8_FREE) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI - (4 + NI), 0); \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI - (4 + NI), 0);       \
     __builtin_amdgcn_sched_barrier(0)
 #define S2_STAGE(CUR, NXT, RA, RB, ST)                                       \
     S2_READ(fa1, fb1, CUR, so1);                                             \
@@ -411,6 +460,8 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
 #undef S2_LWRITE
 #undef S2_GLOAD
 #undef S2_READ
+#undef S2_READ1
+#undef S2_TR
 #undef S2_MFMA
         __syncthreads();
 
@@ -566,12 +617,16 @@ static inline size_t syrk_xt_bytes(int64_t tokens, int64_t cols) {
     return ((size_t)cols * (size_t)syrk_kpad(tokens) * 2 + 255) / 256 * 256;      // Xt, 16-bit
 }
 
-// 256-wide tiles: when the upper triangle has more of them than CUs and K is long (short K: the
-// slabs' hand-off costs more than the balance returns)
+// 256-wide tiles: wide matrices with a long K.  More tiles than CUs (C = 6144: 300) need the
+// K-sliced left-overs, whose slabs only pay at kpad >= 4096; at most one tile per CU (C = 5120:
+// 210) nothing is sliced and kpad >= 2048 is enough.  (Measured, us per call old / new kernel:
+// [16448, 6144] 1224 / 793, [3072, 5120] 177 / 152, [2056, 6144] 200 / 218, [384, 5120] 74 / 78.)
 static inline bool syrk_use256(int64_t cols, int64_t kpad) {
-    static const int64_t min_cols = getenv("ECOFLAP_SYRK_MINCOLS") ? atoll(getenv("ECOFLAP_SYRK_MINCOLS")) : S2_MIN_COLS;
-    static const int64_t min_k = getenv("ECOFLAP_SYRK_MINK") ? atoll(getenv("ECOFLAP_SYRK_MINK")) : 4096;
-    return cols >= min_cols && kpad >= min_k;
+    static const int64_t min_cols = getenv("ECOFLAP_SYRK_MINCOLS") ? atoll(getenv("ECOFLAP_SYRK_MINCOLS")) : 4097;
+    static const int64_t min_k = getenv("ECOFLAP_SYRK_MINK") ? atoll(getenv("ECOFLAP_SYRK_MINK")) : 2048;
+    if (cols < min_cols || kpad < min_k) return false;
+    const int64_t n2 = (cols + S2_T - 1) / S2_T;
+    return n2 * (n2 + 1) / 2 <= syrk_cu_count() || kpad >= 2 * min_k;
 }
 
 extern "C" size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols) {
@@ -581,7 +636,7 @@ extern "C" size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols) 
     if (ks > 1) n += (size_t)ks * (((size_t)cols * cols * sizeof(float) + 255) / 256 * 256);
     if (syrk_use256(cols, syrk_kpad(tokens))) {              // K-slice slabs + tickets of the 256-wide kernel
         const Syrk256Plan p = syrk256_plan(cols, syrk_kpad(tokens));
-        n += (size_t)p.left * p.S * S2_T * S2_T * sizeof(float) + ((size_t)(p.left + 1) * sizeof(unsigned) + 255) / 256 * 256;
+        n += (size_t)p.left * p.S * S2_T * S2_T * sizeof(float) + (16 + (size_t)(p.left + 1) * sizeof(unsigned) + 255) / 256 * 256;
     }
     return n;
 }
@@ -602,7 +657,12 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
     hipStream_t s = (hipStream_t)stream;
     const int64_t kpad = syrk_kpad(tokens);
     uint16_t* xt = (uint16_t*)workspace;
-    if (cols % 8 == 0 && aligned16(x))
+    static const bool form2 = !getenv("ECOFLAP_SYRK_FORM") || atoi(getenv("ECOFLAP_SYRK_FORM")) == 2;
+    static const bool no256_ = getenv("ECOFLAP_SYRK_NO256") != nullptr;
+    const bool direct = form2 && !no256_ && cols % 8 == 0 && aligned16(x) && syrk_use256(cols, kpad);
+    if (direct) {
+        // the 256-wide kernel reads X as it lies (no transposed copy)
+    } else if (cols % 8 == 0 && aligned16(x))
         hipLaunchKernelGGL(syrk_transpose8_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)(kpad / 64)),
                            dim3(256), 0, s, (const uint16_t*)x, tokens, cols, kpad, xt);
     else
@@ -617,21 +677,24 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
         Syrk256Plan p = syrk256_plan(cols, kpad);
         char* after = (char*)workspace + syrk_xt_bytes(tokens, cols);
         p.slabs = (float*)after;
-        p.tickets = (unsigned*)(after + (size_t)p.left * p.S * S2_T * S2_T * sizeof(float));
+        char* zt = after + (size_t)p.left * p.S * S2_T * S2_T * sizeof(float);
+        p.zero16 = zt;                                   // 16 zero bytes, then the tickets: one memset
+        p.tickets = (unsigned*)(zt + 16);
         {
-            const hipError_t e = hipMemsetAsync(p.tickets, 0, (size_t)(p.left + 1) * sizeof(unsigned), s);
+            const hipError_t e = hipMemsetAsync(zt, 0, 16 + (size_t)(p.left + 1) * sizeof(unsigned), s);
             if (e != hipSuccess) return (int)e;
         }
-        static const bool w8 = getenv("ECOFLAP_SYRK_W8") != nullptr;          // A/B: 8 waves of 128x64
-        if (w8) {
-            if (dtype == ECOFLAP_F16)
-                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16, 8>), dim3((unsigned)p.G), dim3(512), 0, s, xt, cols, kpad, H, beta, alpha, p);
-            else
-                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16, 8>), dim3((unsigned)p.G), dim3(512), 0, s, xt, cols, kpad, H, beta, alpha, p);
-        } else if (dtype == ECOFLAP_F16)
-            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16, 4>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
-        else
-            hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16, 4>), dim3((unsigned)p.G), dim3(256), 0, s, xt, cols, kpad, H, beta, alpha, p);
+        static const int form = getenv("ECOFLAP_SYRK_FORM") ? atoi(getenv("ECOFLAP_SYRK_FORM")) : 2;   // A/B: 0 = 4 waves, 1 = 8 waves, 2 (default) = 8 waves on X as it lies
+        const uint16_t* xin = (const uint16_t*)x;
+#define S2_GO(DT_, NW_, TRX_, SRC_, K_) hipLaunchKernelGGL((syrk256_kernel<DT_, NW_, TRX_>), dim3((unsigned)p.G), dim3(64 * NW_), 0, s, SRC_, cols, K_, H, beta, alpha, p)
+        if (form == 2 && direct) {
+            if (dtype == ECOFLAP_F16) S2_GO(ECOFLAP_F16, 8, true, xin, tokens); else S2_GO(ECOFLAP_BF16, 8, true, xin, tokens);
+        } else if (form >= 1) {
+            if (dtype == ECOFLAP_F16) S2_GO(ECOFLAP_F16, 8, false, xt, kpad); else S2_GO(ECOFLAP_BF16, 8, false, xt, kpad);
+        } else {
+            if (dtype == ECOFLAP_F16) S2_GO(ECOFLAP_F16, 4, false, xt, kpad); else S2_GO(ECOFLAP_BF16, 4, false, xt, kpad);
+        }
+#undef S2_GO
         ECO_CHECK_LAUNCH();
         return 0;
     }

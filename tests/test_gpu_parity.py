@@ -1211,15 +1211,18 @@ def test_sparsegpt_pruner_n_m_hip_equals_oracle(kern, golden_dir, monkeypatch):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tokens,cols", [(8 * 257, 1408), (37, 130), (64, 128), (200, 257), (128, 2048),
                                          (8 * 257, 6144), (100, 2100), (8 * 384, 5120), (70, 2305),
-                                         (4200, 1408), (4104, 1540), (4 * 2056, 6144), (4100, 5900)])
+                                         (4200, 1408), (4104, 1540), (4 * 2056, 6144), (4100, 5900),
+                                         (4099, 4104), (2050, 4360)])
 def test_hessian_mfma_syrk_vs_reference_expression(kern, dt, tokens, cols):
     """ecoflap_hessian_accum (MFMA SYRK, upper triangle mirrored) against the reference's own
     fp32 expression (sparsegpt_pruner.py:79-82) over three accumulating batches: 1e-5 of the
     Hessian's scale element-wise (products of 16-bit values are exact in fp32; only the order of
-    the fp32 sums differs), exactly symmetric, partial tiles and K tails included.  The last four
-    shapes take the K-sliced forms (tokens >= 4096: 4 slices + combine pass below 2048 columns,
-    256-wide tiles with slabs handed to the last slice above 5632), and every shape must give the
-    SAME bits when the whole sequence is run again (fixed summation order, whoever arrives last)."""
+    the fp32 sums differs), exactly symmetric, partial tiles and K tails included.  The last
+    shapes take the K-sliced forms (tokens >= 4096: 4 slices + combine pass below 2048 columns) and
+    the 256-wide kernel (above 4096 columns: 8 waves on X as it lies, transposed LDS reads, token
+    and column tails read as zeros; 5900 columns = not a multiple of 8 -> through the transposed
+    copy; more tiles than CUs -> slabs handed to the last slice), and every shape must give the SAME
+    bits when the whole sequence is run again (fixed summation order, whoever arrives last)."""
     import math
     torch.manual_seed(tokens + cols)
     H = torch.zeros(cols, cols, device="cuda")
