@@ -171,3 +171,37 @@ def test_argument_errors_of_the_round2_entry_points():
     assert lay(n=-1) == -3 and lay(rows=-4) == -3 and lay(rows=1 << 31) == -3
     assert lay(table=None) == -2
     assert lay(ev0=vp(16)) == -2                                                 # half an event pair
+
+
+def test_argument_errors_and_workspace_sizes_of_this_rounds_entry_points():
+    """n:m selection, the mixed-dtype reduce and the multi-compare reject bad arguments without a
+    GPU; the Hessian workspace covers the transposed copy, plus the K-slice slabs where the
+    256-wide kernel cuts left-over tiles (C = 6144 at 8 samples per call: 44 tiles x 5 slices x
+    256 KB on a 256-CU part) or the four partial Hessians of the K-split small shapes."""
+    from ecoflap_amd import hip
+    lib = hip.load_library()
+    vp = ctypes.c_void_p
+    p = vp(4096)
+    assert lib.ecoflap_wanda_prune_nm(p, p, 4, 8, 0, 0, 4, None, None) == -3          # n = 0
+    assert lib.ecoflap_wanda_prune_nm(p, p, 4, 8, 0, 3, 2, None, None) == -3          # m < n
+    assert lib.ecoflap_wanda_prune_nm(p, p, 4, 8, 0, 2, 32, None, None) == -3         # m > 16
+    assert lib.ecoflap_wanda_prune_nm(p, p, 4, 9, 0, 2, 4, None, None) == -3          # ragged group of 1 < n
+    assert lib.ecoflap_wanda_prune_nm(None, p, 4, 8, 0, 2, 4, None, None) == -2
+    assert lib.ecoflap_wanda_prune_nm(p, p, 0, 8, 0, 2, 4, None, None) == 0            # empty
+    assert lib.ecoflap_sparsegpt_block_nm(p, 4, 128, p, 128, 0, 128, 2, 32, p, None, None) == -3
+    assert lib.ecoflap_sparsegpt_block_nm(p, 4, 128, p, 128, 0, 5, 2, 4, p, None, None) == -3
+    assert lib.ecoflap_sparsegpt_block_nm(None, 4, 128, p, 128, 0, 128, 2, 4, p, None, None) == -2
+    host = (ctypes.c_int64 * 4)(4096, 4096, 16, 1 | (2 << 8))                         # fp16 W, bf16 g
+    assert lib.ecoflap_absprod_reduce_mixed(p, host, 1, 0, p, p, 1 << 20, None) == -1
+    assert lib.ecoflap_absprod_reduce_mixed(p, host, 1, 9, p, p, 1 << 20, None) == -4
+    assert lib.ecoflap_absprod_reduce_mixed(p, host, 0, 0, p, p, 1 << 20, None) == 0
+    lib.ecoflap_hessian_workspace_bytes.restype = ctypes.c_size_t
+    lib.ecoflap_hessian_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    xt = lambda t, c: c * ((t + 63) // 64 * 64) * 2                                   # noqa: E731
+    one = lib.ecoflap_hessian_workspace_bytes(2056, 6144)
+    eight = lib.ecoflap_hessian_workspace_bytes(8 * 2056, 6144)
+    assert xt(2056, 6144) <= one < xt(2056, 6144) + 4096                              # 128-wide kernel: the copy only
+    assert eight >= xt(8 * 2056, 6144) + 44 * 5 * 256 * 256 * 4                       # + the slabs
+    small = lib.ecoflap_hessian_workspace_bytes(8 * 2056, 1408)
+    assert small >= xt(8 * 2056, 1408) + 4 * 1408 * 1408 * 4                          # + four partial Hessians
+    assert lib.ecoflap_hessian_workspace_bytes(0, 6144) == 0
