@@ -17,12 +17,14 @@
 //      registers so the LDS traffic is dwords — 186 -> 85 us at [16448, 6144]).
 //   2. syrk_kernel: one workgroup (4 waves, 2x2, 64x64 each = 2x2 MFMA tiles) per tile pair,
 //      K in chunks of 64 staged through LDS (rows padded to 144 B: conflict-free ds_read_b128).
-//      Few tiles and long K (C = 1408 at 8 samples per call: 66 tiles of 128 for 256 CUs): 4
-//      K-slices (blockIdx.y) into partial buffers + syrk_combine_kernel (slice order).
+//      Few tiles, long K and C % 8 != 0: 4 K-slices (blockIdx.y) into partial buffers +
+//      syrk_combine_kernel (slice order).
 //   3. syrk256_kernel (C > 4096 and a long K): 256-wide tiles, one persistent workgroup per CU of
 //      8 waves (two per SIMD, 128x64 each), reading X AS IT LIES — no transposed copy: token-major
 //      stages in LDS, MFMA operands through ds_read_b64_tr_b16.  Tiles beyond a whole round are cut
 //      into K-slices whose fp32 slabs the last slice to arrive (ticket) adds up in slice order.
+//      Few tiles and a long K (C = 1408 at 8 samples per call: 21 tiles for 256 CUs): every tile
+//      cut into K-slices that write partial Hessians, syrk_combine_kernel adds them up.
 //      (ECOFLAP_SYRK_FORM=1: the same on the transposed copy — taken when C % 8 != 0 —, =0: 4 waves
 //      of 128x128 on the transposed copy; A/B switches.)
 // Every path sums in a fixed order: the same call gives the same bits, whoever finishes last.
@@ -259,6 +261,13 @@ struct Syrk256Plan {
     float* slabs;            // [left * S][256 * 256] fp32, lane-linear (see s2_slab)
     unsigned* tickets;       // [left], zeroed ahead of the launch
     const void* zero16;      // 16 zero bytes (the zeroed words after the tickets)
+    // "partials" form (few tiles, long K — C = 1408: 21 tiles for 256 CUs): part_S > 0, every tile is
+    // cut into part_S K-slices, item t = tile * part_S + slice writes alpha * X_s^T X_s of its tile
+    // (beta = 0, mirror included) to the slice's OWN Hessian at part + slice * part_stride — no
+    // hand-off; syrk_combine_kernel adds the partial Hessians up in slice order afterwards
+    int part_S;
+    float* part;
+    int64_t part_stride;
 };
 
 // NW = 4: waves 2 x 2, 128x128 each, one per SIMD.  NW = 8: waves 2 x 4, 128x64 each, TWO per SIMD
@@ -311,10 +320,21 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
             t = item * P.G + (P.G % 8 == 0 ? bperm : b);
             if (t >= P.full) break;
         }
-        int bj = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while ((bj + 1) * (bj + 2) / 2 <= t) ++bj;
-        while (bj * (bj + 1) / 2 > t) --bj;
-        const int bi = t - bj * (bj + 1) / 2;
+        float* Hout = H;
+        float beta_l = beta;
+        int tile = t;
+        if (P.part_S) {
+            tile = t / P.part_S;
+            const int sl = t - tile * P.part_S;
+            st0 = 2 * (int)((int64_t)sl * npairs / P.part_S);
+            st1 = 2 * (int)((int64_t)(sl + 1) * npairs / P.part_S);
+            Hout = P.part + (int64_t)sl * P.part_stride;
+            beta_l = 0.f;
+        }
+        int bj = (int)((__builtin_sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        while ((bj + 1) * (bj + 2) / 2 <= tile) ++bj;
+        while (bj * (bj + 1) / 2 > tile) --bj;
+        const int bi = tile - bj * (bj + 1) / 2;
         const int64_t rowA0 = (int64_t)bi * S2_T, rowB0 = (int64_t)bj * S2_T;
 
         // global -> LDS image.  Transposed copy: piece p (16 rows x 64 B) of an operand goes to wave
@@ -528,8 +548,8 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
                     const int64_t gr = rowA0 + wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     float v = alpha * acc[mi][ni][e];
                     if (gr < C && gc < C) {
-                        if (beta != 0.f) v += beta * H[gr * C + gc];
-                        H[gr * C + gc] = v;
+                        if (beta_l != 0.f) v += beta_l * Hout[gr * C + gc];
+                        Hout[gr * C + gc] = v;
                     }
                     acc[mi][ni][e] = v;
                 }
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(64 * NW) void syrk256_kernel(const uint16_t* __rest
                 const int64_t gr = rowA0 + wm * 128 + 64 * hm + lane;      // original row -> mirrored column
                 for (int c = 0; c < 32; ++c) {
                     const int64_t gc = rowB0 + wn * (32 * NI) + ni * 32 + c;
-                    if (gc < C && gr < C) H[gc * C + gr] = ldsT[c * 65 + lane];
+                    if (gc < C && gr < C) Hout[gc * C + gr] = ldsT[c * 65 + lane];
                 }
             }
     }
@@ -605,10 +625,15 @@ __global__ __launch_bounds__(256) void syrk_combine_kernel(float* __restrict__ H
     ((f32x4*)H)[i] = a;
 }
 
-// K-slices of the 64 / 128-wide kernel: 4 when the tiles alone would leave most CUs idle and K is long
+// Few tiles and a long K (C = 1408 at 8 samples per call): K-slices into partial Hessians + one combine
+// pass.  -> number of slices (1 = none): as many as give every CU a 256-wide tile's slice, at most 16
 static inline int syrk_kslices(int64_t cols, int64_t kpad) {
-    const int64_t nt128 = (cols + 127) / 128;
-    return (cols < 2048 && cols % 4 == 0 && kpad >= 4096 && nt128 * (nt128 + 1) / 2 * 4 >= 200) ? 4 : 1;
+    if (!(cols >= 1024 && cols < 2048 && cols % 4 == 0 && kpad >= 4096)) return 1;
+    const int64_t n2 = (cols + 255) / 256, nt = n2 * (n2 + 1) / 2;
+    int S = (int)(syrk_cu_count() / nt);
+    if (S > 16) S = 16;
+    if (S > (int)(kpad / 128)) S = (int)(kpad / 128);
+    return S < 2 ? 1 : S;
 }
 
 static inline int64_t syrk_kpad(int64_t tokens) { return (tokens + SY_KC - 1) / SY_KC * SY_KC; }
@@ -633,7 +658,7 @@ extern "C" size_t ecoflap_hessian_workspace_bytes(int64_t tokens, int64_t cols) 
     if (tokens <= 0 || cols <= 0) return 0;
     size_t n = syrk_xt_bytes(tokens, cols);
     const int ks = syrk_kslices(cols, syrk_kpad(tokens));
-    if (ks > 1) n += (size_t)ks * (((size_t)cols * cols * sizeof(float) + 255) / 256 * 256);
+    if (ks > 1) n += 256 + (size_t)ks * (((size_t)cols * cols * sizeof(float) + 255) / 256 * 256);
     if (syrk_use256(cols, syrk_kpad(tokens))) {              // K-slice slabs + tickets of the 256-wide kernel
         const Syrk256Plan p = syrk256_plan(cols, syrk_kpad(tokens));
         n += (size_t)p.left * p.S * S2_T * S2_T * sizeof(float) + (16 + (size_t)(p.left + 1) * sizeof(unsigned) + 255) / 256 * 256;
@@ -659,7 +684,8 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
     uint16_t* xt = (uint16_t*)workspace;
     static const bool form2 = !getenv("ECOFLAP_SYRK_FORM") || atoi(getenv("ECOFLAP_SYRK_FORM")) == 2;
     static const bool no256_ = getenv("ECOFLAP_SYRK_NO256") != nullptr;
-    const bool direct = form2 && !no256_ && cols % 8 == 0 && aligned16(x) && syrk_use256(cols, kpad);
+    const bool direct = form2 && !no256_ && cols % 8 == 0 && aligned16(x) &&
+                        (syrk_use256(cols, kpad) || syrk_kslices(cols, kpad) > 1);
     if (direct) {
         // the 256-wide kernel reads X as it lies (no transposed copy)
     } else if (cols % 8 == 0 && aligned16(x))
@@ -700,17 +726,38 @@ extern "C" int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, in
     }
     const int ks = syrk_kslices(cols, kpad);
     if (ks > 1) {
-        // few tiles, long K: 128-wide tiles x 4 K-slices into partial buffers, then one combine pass
-        const int64_t n128 = (cols + 127) / 128;
-        const int nt128s = (int)(n128 * (n128 + 1) / 2);
+        // few tiles, long K: K-slices into partial Hessians, then one combine pass (slice order)
         const int64_t hstride = (int64_t)(((size_t)cols * cols * sizeof(float) + 255) / 256 * 256 / sizeof(float));
-        float* part = (float*)((char*)workspace + syrk_xt_bytes(tokens, cols));
-        const int64_t kslice = (kpad / SY_KC + ks - 1) / ks * SY_KC;
-        const dim3 g((unsigned)((nt128s + 7) / 8 * 8), (unsigned)ks);
-        if (dtype == ECOFLAP_F16)
-            hipLaunchKernelGGL((syrk_kernel<ECOFLAP_F16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
-        else
-            hipLaunchKernelGGL((syrk_kernel<ECOFLAP_BF16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
+        char* after = (char*)workspace + syrk_xt_bytes(tokens, cols);
+        float* part = (float*)(after + 256);                       // (16 zero bytes first)
+        const bool direct8 = direct;
+        if (direct8) {
+            // the 8-wave 256-wide kernel on X as it lies, one (tile, slice) per workgroup
+            const hipError_t e = hipMemsetAsync(after, 0, 16, s);
+            if (e != hipSuccess) return (int)e;
+            Syrk256Plan p{};
+            const int64_t n2 = (cols + S2_T - 1) / S2_T;
+            p.ntiles = (int)(n2 * (n2 + 1) / 2);
+            p.G = p.ntiles * ks;
+            p.full = p.G;
+            p.zero16 = after;
+            p.part_S = ks;
+            p.part = part;
+            p.part_stride = hstride;
+            if (dtype == ECOFLAP_F16)
+                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_F16, 8, true>), dim3((unsigned)p.G), dim3(512), 0, s, (const uint16_t*)x, cols, tokens, H, beta, alpha, p);
+            else
+                hipLaunchKernelGGL((syrk256_kernel<ECOFLAP_BF16, 8, true>), dim3((unsigned)p.G), dim3(512), 0, s, (const uint16_t*)x, cols, tokens, H, beta, alpha, p);
+        } else {
+            const int64_t n128 = (cols + 127) / 128;
+            const int nt128s = (int)(n128 * (n128 + 1) / 2);
+            const int64_t kslice = (kpad / SY_KC + ks - 1) / ks * SY_KC;
+            const dim3 g((unsigned)((nt128s + 7) / 8 * 8), (unsigned)ks);
+            if (dtype == ECOFLAP_F16)
+                hipLaunchKernelGGL((syrk_kernel<ECOFLAP_F16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
+            else
+                hipLaunchKernelGGL((syrk_kernel<ECOFLAP_BF16, 2>), g, dim3(256), 0, s, xt, cols, kpad, part, 0.f, alpha, nt128s, kslice, hstride);
+        }
         ECO_CHECK_LAUNCH();
         const int64_t n4 = cols * cols / 4;
         hipLaunchKernelGGL(syrk_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, H, part, n4, hstride, ks, beta);
