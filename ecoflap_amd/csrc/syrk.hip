@@ -232,18 +232,21 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
     }
 }
 
-// ---- 256x256 tiles (C >= 2048): 4 waves 2x2, each 128x128 = 4x4 MFMA tiles.  With 2x2 tiles per
-// wave (the kernel above) every k-step of 4 MFMAs needs 4 ds_read_b128 — at 4 waves per CU the
-// LDS is as busy as the matrix cores and the loop tops out near 560 TFLOP/s; 4x4 tiles need 8
-// reads for 16 MFMAs.  One workgroup per CU (256 accumulator registers per lane), so the latency
-// hiding is explicit: K in stages of 32, DMA'd global -> LDS (`global_load_lds_dwordx4`, no
-// registers) into FOUR stage buffers of 2 x 16 KB, three stages in flight, counted vmcnt (never
-// drained inside the loop); the MFMA operands of k-step j+1 are read from LDS while the 16 MFMAs
-// of step j run (two register sets, scheduling barriers keep the compiler from folding them).
-// LDS rows are 64 B without padding (a DMA piece is 1 KiB contiguous = 16 rows), the 16-byte
-// k-segment s of row rho sits in slot s ^ ((rho >> 2) & 3): each of ds_read_b128's 16-lane groups
-// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) then covers all 64 banks once.  The swizzle is
-// applied on the GLOBAL side of the DMA (the lane that fills slot p fetches segment p ^ swz).
+// ---- 256x256 tiles (wide matrices, long K): with 2x2 MFMA tiles per wave (the kernel above) every
+// k-step of 4 MFMAs needs 4 ds_read_b128 — at 4 waves per CU the LDS is as busy as the matrix
+// cores and the loop tops out near 560 TFLOP/s.  Here a wave owns 128x64 (8 waves per workgroup,
+// two per SIMD: 6 reads per 8 MFMAs, and one wave's barrier / LDS wait is the other's MFMA time)
+// or 128x128 (4 waves, one per SIMD: 8 reads per 16 MFMAs — kept for A/B: it pays every wait in
+// full and ends up slower).  One persistent workgroup per CU.  K in stages of 32: global ->
+// registers (two stages of loads in flight, the compiler's counted vmcnt) -> one of TWO LDS stage
+// buffers; the MFMA operands of k-step j+1 are read from LDS while the MFMAs of step j run (two
+// register sets), with the issue order of MFMAs / LDS reads / LDS writes / global loads fixed by
+// sched_group_barrier.  (LDS-DMA into four stage buffers with counted vmcnt was tried first: the
+// same speed, `profiles/r03_secondary/syrk_notes.md`.)
+// Transposed-copy form (TRX = false): LDS rows are 64 B without padding, the 16-byte k-segment s
+// of row rho sits in slot s ^ ((rho >> 2) & 3): each of ds_read_b128's 16-lane groups ({0-3,12-15,
+// 20-27}, {4-11,16-19,28-31}, + 32) then covers all 64 banks once; the swizzle is applied on the
+// GLOBAL side (the lane that fills slot p fetches segment p ^ swz).
 #define S2_T 256
 #define S2_KC 32
 #define S2_OPB (S2_T * S2_KC * 2)      // bytes per operand and stage (16 KB)
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void syrk_kernel(const uint16_t* __restrict__ 
 // result does not depend on who arrives when.
 struct Syrk256Plan {
     int ntiles, full, left, S, G;
-    float* slabs;            // [left * S][256 * 256] fp32, lane-linear (see s2_slab)
+    float* slabs;            // [left * S][256 * 256] fp32, in the accumulators' (tile, register, thread) order
     unsigned* tickets;       // [left], zeroed ahead of the launch
     const void* zero16;      // 16 zero bytes (the zeroed words after the tickets)
     // "partials" form (few tiles, long K — C = 1408: 21 tiles for 256 CUs): part_S > 0, every tile is
