@@ -49,9 +49,10 @@ def run(task, argv=None):
     ap.add_argument("--toy", action="store_true")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--save", default="")
-    ap.add_argument("--z_source", default="philox", choices=["philox", "torch"],
-                    help="torch: draw z as the reference does (torch.manual_seed + torch.normal "
-                         "on the parameter's device); philox: in-register stream (default)")
+    ap.add_argument("--z_source", default="torch", choices=["torch", "philox"],
+                    help="torch (default): draw z as the reference does (torch.manual_seed + "
+                         "torch.normal on the parameter's device); philox: the build's in-register "
+                         "stream (opt-in)")
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     torch.manual_seed(42)

@@ -36,18 +36,16 @@ def configure():
     os.environ.setdefault(ENV, "1")
 
 
-def verify(device=None):
-    """True when the library runs its Stream-K kernels data-parallel in THIS process (probed
-    once per device); raises otherwise (a warning under ECOFLAP_ALLOW_STREAMK=1)."""
+def _refuse(msg):
+    if os.environ.get("ECOFLAP_ALLOW_STREAMK") == "1":
+        warnings.warn(msg)
+    else:
+        raise RuntimeError(msg)
+
+
+def _probe(dev):
+    """(batch invariant at 16 evaluations, reproducible call to call) of the ViT-g qkv GEMM."""
     import torch
-    if not torch.cuda.is_available():
-        return True
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if dev.type != "cuda":
-        return True
-    key = (dev.index if dev.index is not None else torch.cuda.current_device())
-    if key in _verified:
-        return _verified[key]
     import torch.nn.functional as F
     g = torch.Generator(device=dev).manual_seed(1234)
     rows = 2056                                   # one evaluation of the ViT-g qkv Linear: 8 x 257 tokens
@@ -55,19 +53,61 @@ def verify(device=None):
     x = (torch.randn(16 * rows, 1408, device=dev, generator=g) * 0.7).half()
     with torch.no_grad():
         whole = F.linear(x, w)
+        again = F.linear(x, w)
         alone_first = F.linear(x[:rows].contiguous(), w)
         alone_last = F.linear(x[15 * rows:].contiguous(), w)
-    ok = bool(torch.equal(whole[:rows], alone_first) and torch.equal(whole[15 * rows:], alone_last))
-    del whole, alone_first, alone_last, x, w
-    _verified[key] = ok
-    if not ok:
-        msg = (f"{ENV}=1 is not in effect in this process (environment: "
-               f"{os.environ.get(ENV)!r}): hipBLASLt's Stream-K kernels are then neither "
-               "reproducible call to call nor batch invariant (ecoflap_amd/blas_guard.py). "
-               f"Export {ENV}=1 before the first GEMM of the process (import ecoflap_amd before "
-               "running any torch matmul), or set ECOFLAP_ALLOW_STREAMK=1 to run anyway.")
-        if os.environ.get("ECOFLAP_ALLOW_STREAMK") == "1":
-            warnings.warn(msg)
-        else:
-            raise RuntimeError(msg)
-    return ok
+    invariant = bool(torch.equal(whole[:rows], alone_first)
+                     and torch.equal(whole[15 * rows:], alone_last))
+    repeatable = bool(torch.equal(whole, again))
+    return invariant, repeatable
+
+
+def verify(device=None, need_batch_invariance=True):
+    """True when the library runs its Stream-K kernels data-parallel in THIS process; raises
+    otherwise (a warning under ECOFLAP_ALLOW_STREAMK=1) — every time it is asked, not only the
+    first: only a PASSED probe is cached per device, so a run that follows a caught refusal in
+    the same process (a test session, a retry loop, a second pruner) is refused again.
+
+    Two properties are told apart.  `TENSILE_STREAMK_DATA_PARALLEL` not being 1 in the
+    environment means the kernels' hand-off of partial tiles is on: call-to-call results can
+    differ (about one call in 30 000), which no single probe can show — that is refused on the
+    variable alone.  Batch invariance (slots 0 and 15 of a 16-evaluation qkv GEMM equal to the
+    same GEMM alone) is what the shared-suffix evaluation needs on top; a caller that never
+    concatenates evaluations passes `need_batch_invariance=False` and is then not refused for a
+    library version whose tile choice differs between M = 2056 and M = 32 896."""
+    import torch
+    if not torch.cuda.is_available():
+        return True
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        return True
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    state = _verified.get(key)
+    if state is None:
+        state = _probe(dev)
+        if all(state) and os.environ.get(ENV) == "1":
+            _verified[key] = state           # successes only
+    invariant, repeatable = state
+    env = os.environ.get(ENV)
+    if env != "1" or not repeatable:
+        _refuse(f"{ENV}=1 is not in effect in this process (environment: {env!r}; probe: "
+                f"batch invariant at 16 evaluations = {invariant}, same bits on a repeated call = "
+                f"{repeatable}): hipBLASLt's Stream-K kernels are then not reproducible call to "
+                "call (ecoflap_amd/blas_guard.py). "
+                f"Export {ENV}=1 before the first GEMM of the process (import ecoflap_amd before "
+                "running any torch matmul), or set ECOFLAP_ALLOW_STREAMK=1 to run anyway.")
+        return False
+    if not invariant and need_batch_invariance:
+        _refuse(f"{ENV}=1 is in the environment, but the GEMM library is not batch invariant here "
+                "(a 16-evaluation ViT-g qkv GEMM differs from the same rows alone; same bits on a "
+                f"repeated call = {repeatable}).  Either the variable was set after this process's "
+                "first GEMM (the library reads it once: import ecoflap_amd before any torch "
+                "matmul), or this hipBLASLt picks different kernels for M = 2056 and M = 32896.  "
+                "Evaluations cannot share a pass then: run with eval_batch=1, or set "
+                "ECOFLAP_ALLOW_STREAMK=1 to let the loop's own per-stage probe decide.")
+        return False
+    if not invariant:
+        warnings.warn(f"{ENV}=1 is in the environment but the batch-invariance probe failed; "
+                      "this run does not concatenate evaluations, so it goes ahead — whether the "
+                      "setting is live in this process could not be confirmed.")
+    return True

@@ -54,12 +54,12 @@ def build_parser():
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--out_dir", type=str, default=".")
     # build-side: where the zeroth-order perturbation z comes from
-    p.add_argument("--z_source", default="philox", choices=["philox", "torch"],
-                   help="philox (default): z generated in registers by the K1 kernel, never in "
-                        "memory — the build's own stream, no reference run can equal its table; "
-                        "torch: torch.manual_seed(seed) + torch.normal on the parameter's device, "
-                        "the reference's own draw (layer_single_base_pruner.py:482-485) — the "
-                        "parity mode: the table the reference's arithmetic gives on this GPU")
+    p.add_argument("--z_source", default="torch", choices=["torch", "philox"],
+                   help="torch (default): torch.manual_seed(seed) + torch.normal on the parameter's "
+                        "device, the reference's own draw (layer_single_base_pruner.py:482-485): the "
+                        "table the reference's arithmetic gives on this GPU; "
+                        "philox: z generated in registers by the K1 kernel, never in memory — the "
+                        "build's own stream (opt-in: no reference run can equal its table)")
     p.add_argument("--k1_form", default="block", choices=["block", "units", "triple", "single"],
                    help="K1 launch form (bit-identical results): one launch per transformer block "
                         "(default), per layer, per unit, or the reference's three in-place passes")
@@ -133,6 +133,16 @@ def load_pruned_checkpoints(model, t5_pruned_checkpoint=None, vit_pruned_checkpo
     return model
 
 
+def checkpoint_to_save(state_dict, shape):
+    """What `--save_pruned_model` writes: the whole `state_dict` for BLIP-2 and T5
+    (LAVIS/evaluate_blip.py:442-445, evaluate_t5.py:371); for the EVA-CLIP entry point only the
+    vision tower's keys, and of those none of `blocks.39` — the block EVA-ViT-g drops when it
+    serves as BLIP-2's encoder (LAVIS/evaluate_eva_clip.py:414-424: substring tests, as there)."""
+    if shape != "vit":
+        return state_dict
+    return {k: v for k, v in state_dict.items() if "blocks.39" not in k and "visual." in k}
+
+
 def config_dict(args):
     """Keys and values of LAVIS/evaluate_blip.py:399-418 (t5/eva_clip variants use prune_spec)."""
     cfg = {
@@ -150,7 +160,7 @@ def config_dict(args):
         "sparsity_dict": args.sparsity_dict,
         "prune_per_model": args.prune_per_model,
         "iteration": args.iteration,
-        "z_source": getattr(args, "z_source", "philox"),      # build-side extras (kw-only)
+        "z_source": getattr(args, "z_source", "torch"),      # build-side extras (kw-only)
         "k1_form": getattr(args, "k1_form", "block"),
         "eval_batch": getattr(args, "eval_batch", 16),
         "n_lanes": getattr(args, "lanes", 2),
@@ -178,19 +188,22 @@ def main(argv=None, kernels=None):
     torch.manual_seed(args.seed)
     model, loader = build_model_and_loader(args, device)
     load_pruned_checkpoints(model, args.t5_pruned_checkpoint, args.vit_pruned_checkpoint)
-    orig_total = sum((p != 0).float().sum() for p in model.parameters())
+    # the EVA-CLIP entry point counts and saves the vision tower only
+    # (LAVIS/evaluate_eva_clip.py:334-336, :404-424)
+    counted = model.visual if args.shape == "vit" else model
+    orig_total = sum((p != 0).float().sum() for p in counted.parameters())
     cfg = config_dict(args)
     if kernels is not None:
         cfg["kernels"] = kernels
     pruner = load_pruner(args.pruning_method, model, loader, cfg=cfg)
     start = time.time()
     model, sparsity_dict = pruner.prune()
-    remaining = sum((p != 0).float().sum() for p in model.parameters())
+    remaining = sum((p != 0).float().sum() for p in counted.parameters())
     print(float(remaining / orig_total * 100))
     if args.save_pruned_model:
         for folder in ("pruned_checkpoint", "sparsity_dict", "training_statistics"):
             os.makedirs(os.path.join(args.out_dir, folder), exist_ok=True)
-        torch.save(model.state_dict(),
+        torch.save(checkpoint_to_save(model.state_dict(), args.shape),
                    os.path.join(args.out_dir, "pruned_checkpoint", args.job_id + ".pth"))
         if sparsity_dict is not None and isinstance(sparsity_dict, dict):
             with open(os.path.join(args.out_dir, "sparsity_dict", args.job_id + ".yaml"), "w") as f:

@@ -187,6 +187,25 @@ class HipKernels:
         self.hess_ws = Workspace()
         self._pair_tables = {}
 
+    PAIR_TABLES_KEPT = 8      # >= the first-order loop's lanes (default 3), each with its own buffers
+
+    def _pointer_table(self, kind, rows, device):
+        """(host, device) int64 tables of `rows`, cached per distinct row set (the lanes of the
+        first-order loop rotate: each has its own static gradient buffers, so consecutive calls
+        alternate between a few tables).  A new table goes up from pinned memory without
+        blocking the host, which has other lanes' replays to queue."""
+        key = (kind, rows, device)
+        hit = self._pair_tables.pop(key, None)
+        if hit is None:
+            host = torch.tensor(rows, dtype=torch.int64)
+            if device.type == "cuda":
+                host = host.pin_memory()
+            hit = (host, host.to(device, non_blocking=True))
+            while len(self._pair_tables) >= self.PAIR_TABLES_KEPT:
+                self._pair_tables.pop(next(iter(self._pair_tables)))      # least recently used
+        self._pair_tables[key] = hit          # most recently used last
+        return hit
+
     # ---- K1 ---------------------------------------------------------------------------
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         _gpu(w, "w")
@@ -358,12 +377,7 @@ class HipKernels:
         # the pointer table is the same for every batch when the gradients live in a captured
         # graph's static buffers: building it afresh is a blocking H2D copy per batch that
         # stalls the host behind the replay it has just queued
-        cached = self._pair_tables.get("mixed")
-        if cached is None or cached[0] != rows or cached[2].device != out_accum.device:
-            host = torch.tensor(rows, dtype=torch.int64)
-            cached = (rows, host, host.to(out_accum.device))
-            self._pair_tables["mixed"] = cached
-        _, host, table = cached
+        host, table = self._pointer_table("mixed", rows, out_accum.device)
         nb = self.lib.ecoflap_absprod_reduce_multi_workspace_bytes(len(rows))
         ws = self.ws.get(nb, out_accum.device)
         _check(self.lib.ecoflap_absprod_reduce_mixed(
@@ -524,11 +538,7 @@ class HipKernels:
                 keep.append(g)
             rows.append((a.data_ptr(), _gpu(g, "grad").data_ptr(), a.numel(), DTYPE_CODE[g.dtype]))
         rows = tuple(rows)
-        cached = self._pair_tables.get("grad_accum")          # same pointers batch after batch
-        if cached is None or cached[0] != rows or cached[1].device != accs[0].device:
-            cached = (rows, torch.tensor(rows, dtype=torch.int64, device=accs[0].device))
-            self._pair_tables["grad_accum"] = cached
-        table = cached[1]
+        _, table = self._pointer_table("grad_accum", rows, accs[0].device)
         _check(self.lib.ecoflap_grad_accum_multi(_ptr(table), len(rows), _stream()),
                "ecoflap_grad_accum_multi")
 

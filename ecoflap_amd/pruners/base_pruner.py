@@ -61,9 +61,9 @@ class LayerWiseBasePruner(BasePruner):
                  is_global=False, model_prefix="t5_model", sparsity_ratio_granularity=None,
                  max_sparsity_per_layer=0.8, score_method="GradMagSquare_avg",
                  num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
-                 prune_per_model=False, kernels=None, z_source="philox", process_group=None,
+                 prune_per_model=False, kernels=None, z_source="torch", process_group=None,
                  prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, k1_form="block",
-                 **kwargs):
+                 k6_immediate=False, **kwargs):
         super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
                          importance_scores_cache=importance_scores_cache,
                          keep_indices_or_masks_cache=keep_indices_or_masks_cache,
@@ -90,6 +90,10 @@ class LayerWiseBasePruner(BasePruner):
         self.n_lanes = n_lanes
         self.eval_batch = eval_batch
         self.k1_form = k1_form
+        # stage 2: reduce each hooked Linear input inside its hook (one launch per input, as the
+        # reference does) instead of one launch per block — for models that write their
+        # activations in place after the Linear ran (pruners/wanda.py::_K6Collector.add)
+        self.k6_immediate = k6_immediate
         self.stage_stats = {}
 
     def model_setup_and_record_attributes(self, model):
@@ -102,7 +106,9 @@ class LayerWiseBasePruner(BasePruner):
         device = next(iter(model.parameters())).device
         if device.type == "cuda":
             from .. import blas_guard
-            blas_guard.verify(device)     # the GEMM library must be in its reproducible mode
+            # the GEMM library must be in its reproducible mode; batch invariance on top only
+            # when evaluations are going to be concatenated
+            blas_guard.verify(device, need_batch_invariance=int(getattr(self, "eval_batch", 1) or 1) > 1)
         return dtype_record, requires_grad_record, device
 
     def model_reset(self, model, dtype_record, requires_grad_record, device):

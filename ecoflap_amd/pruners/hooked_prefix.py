@@ -53,8 +53,15 @@ class HookedPrefixLoss:
     """Drop-in `loss_func(model, samples, cuda_enabled) -> (loss, batch_len)` around another
     loss closure; `LayerSparsity` announces the scored matrix through `begin_layer(name)`."""
 
-    def __init__(self, model, loss_func, block_lists, extra_modules=()):
+    def __init__(self, model, loss_func, block_lists, extra_modules=(), max_batches=256):
         self.model = model
+        # batches whose recorded activations are kept (least recently used goes first).
+        # `LayerSparsity` takes the calibration prefix ONCE and re-uses those batch objects for
+        # every layer, so the working set is the number of calibration batches (128 at batch
+        # size 1 for the reference's defaults); a loader that yields FRESH objects per pass gets
+        # no reuse out of an identity-keyed cache and must not grow it without bound either
+        self.max_batches = int(max_batches)
+        self._held = {}                       # id(samples) -> samples, in LRU order
         self.loss_func = loss_func
         self.paths = {}                       # module -> dotted path
         for lp in block_lists:
@@ -87,6 +94,7 @@ class HookedPrefixLoss:
     def reset(self):
         self.cache.clear()
         self.valid.clear()
+        self._held.clear()
         self.owner = None
 
     # ---- the loss closure ----------------------------------------------------------------------
@@ -124,11 +132,18 @@ class HookedPrefixLoss:
         # the cache is keyed by the batch OBJECT: keep it alive (an id can be recycled once its
         # object is gone — a loader yielding fresh batches would be served another batch's
         # activations) and check identity
-        held = self.__dict__.setdefault("_held", {})
+        held = self._held
         if held.get(key) is not samples:
-            held[key] = samples
             self.cache.pop(key, None)
             self.valid.pop(key, None)
+        held.pop(key, None)
+        held[key] = samples                       # most recently used last
+        while len(held) > self.max_batches:
+            old = next(iter(held))
+            del held[old]
+            self.cache.pop(old, None)
+            self.valid.pop(old, None)
+            self.stats["evicted"] = self.stats.get("evicted", 0) + 1
         record_sequence = self.sequence is None
         seen = []
         limit = self._limit()

@@ -70,7 +70,7 @@ class LayerSparsity:
         per_model_group=[],
         *,
         kernels=None,
-        z_source="philox",
+        z_source="torch",
         batch_len_fn=None,
         process_group=None,
         k1_form="block",
@@ -80,9 +80,10 @@ class LayerSparsity:
         """Positional arguments are the reference's (:120-135).  Keyword-only extras:
 
         kernels       backend object; None = the HIP library (raises if it is not built).
-        z_source      "philox": z generated in registers by the kernel (production);
-                      "torch": z = torch.normal after torch.manual_seed(seed) on the
+        z_source      "torch" (default): z = torch.normal after torch.manual_seed(seed) on the
                       parameter's device, exactly as the reference draws it (:482-485);
+                      "philox": z generated in registers by the kernel, never in memory (the
+                      build's own stream: opt-in, no reference run can equal its table);
                       or a callable (seed, param) -> z tensor (parity tests).
         process_group torch.distributed group to shard calibration batches over
                       (None = use the default group if initialised, else single process).
@@ -718,7 +719,10 @@ class LayerSparsity:
         dev0 = next(iter(self.model.parameters())).device
         if dev0.type == "cuda":
             from .. import blas_guard
-            blas_guard.verify(dev0)       # reproducible GEMMs (ecoflap_amd/blas_guard.py)
+            # reproducible GEMMs (ecoflap_amd/blas_guard.py); batch invariance is asked for only
+            # by a loss closure that concatenates evaluations
+            blas_guard.verify(dev0, need_batch_invariance=int(
+                getattr(self.loss_func, "eval_batch", 1) or 1) > 1)
         if len(self.importance_measure) == 0:
             if self.score_compute.startswith("MEZO"):
                 self.importance_measure = self.compute_importance_scores_mezo(mapping)

@@ -18,6 +18,8 @@ FLOPs of BLIP-2's scoring pass.  It is a drop-in `loss_func`: `(model, samples,
 cuda_enabled) -> (loss, batch_len)`; `LayerSparsity` tells it which matrix is being
 perturbed through the optional `begin_layer(name)` hook.
 """
+import os
+
 import torch
 
 from .base_pruner import capture_graph
@@ -855,6 +857,18 @@ class PrefixCachedLoss:
                                    for i, w, w2 in zip(sel, want, want2)
                                    if not (torch.equal(losses[i], w) and torch.equal(w, w2))],
                          "grouped": bool(used_groups), "lanes": len(lanes) + 1})
+                    # a mismatch that does not repeat = a forward of this run was not
+                    # reproducible.  Its one known cause (the GEMM library's Stream-K hand-off,
+                    # blas_guard.py) is switched off, so this is an error, not something to
+                    # paper over with the sequential losses — unless the user chose to run in
+                    # the library's default mode
+                    if os.environ.get("ECOFLAP_ALLOW_STREAMK") != "1":
+                        raise RuntimeError(
+                            "non-reproducible loss evaluation (batched and sequential passes "
+                            "differ once, then agree): "
+                            f"{self.stats['transient_mismatches'][-1]}; "
+                            "set ECOFLAP_ALLOW_STREAMK=1 to record it and carry on with the "
+                            "sequential losses")
                     if len(sel) == len(evals):
                         return want2
                     return self._sequential(model, evals, cuda_enabled)

@@ -89,9 +89,12 @@ class _K6Collector:
     batches and replays the mean in GLOBAL batch order (`ecoflap_colsq_replay`), so every rank
     ends with the one-process scaler_row bit for bit."""
 
-    def __init__(self, kernels, raw=False):
+    def __init__(self, kernels, raw=False, immediate=False):
         self.kernels, self.raw = kernels, raw
+        self.immediate = bool(immediate)    # reduce inside the hook (models with in-place ops)
         self.pending = []
+        self._flushes = []         # item lists of the current sample's launches
+        self._sample_flushes = []  # ... of the last finished sample (sizes the private workspace)
         self.ws = None             # private workspace while a graph is captured / replayed
         self.sites = None          # raw: [(wrapped, offset, cols)] in hook order (one forward)
         self.flat = None           # raw: static [sum cols] target of one forward
@@ -101,14 +104,32 @@ class _K6Collector:
         self.capturing = False     # inside a graph capture: launches are recorded, not run
 
     def add(self, wrapped, x, batch):
+        """`x` is kept BY REFERENCE until `flush()` (normally a view of the activation the hook
+        saw): the block must not write its Linear inputs in place after the Linear ran (in-place
+        residual adds / activations on that tensor, fused ops writing into their input).  The
+        reference reduces inside the hook (wanda_pruner.py:71-84) and has no such requirement, so
+        it is checked: the tensor's version counter is recorded here and compared at flush."""
         if any(p[0] is wrapped for p in self.pending):
             self.flush()           # a Linear called twice in one forward: in order, not at once
-        self.pending.append((wrapped, x, batch))
+        if self.immediate:
+            self.pending.append((wrapped, x, batch, x._version))
+            self.flush()
+            return
+        self.pending.append((wrapped, x, batch, x._version))
 
     def flush(self):
         if not self.pending:
             return
         pend, self.pending = self.pending, []
+        stale = [w_ for w_, x, _, ver in pend if x._version != ver]
+        if stale:
+            raise RuntimeError(
+                f"{len(stale)} hooked Linear input(s) of this block were modified in place between "
+                "the Linear's forward and the end of the block: the deferred one-launch column "
+                "statistic would read the overwritten values.  Construct the pruner with "
+                "k6_immediate=True (one launch per input, inside the hook, as the reference "
+                "reduces) for models that write their activations in place.")
+        pend = [(w_, x, b) for w_, x, b, _ in pend]
         if self.raw:
             # one forward may flush more than once (a Linear called twice): sites accumulate
             # until `end_sample`
@@ -132,7 +153,7 @@ class _K6Collector:
                     w_.dev_batch = b
         self.kernels.colsqnorm_accum_multi(items, self.ws)
         self.launches += 1
-        self._last_items = items
+        self._flushes.append(items)
 
     _site_cursor = 0
 
@@ -161,10 +182,19 @@ class _K6Collector:
                     w_.nsamples += b
             self.samples.append((self.flat.clone(), list(self.site_batches)))
         self._site_cursor = 0
+        if self._flushes:
+            self._sample_flushes, self._flushes = self._flushes, []
 
     def private_workspace(self):
-        """for graph capture: a workspace of its own for the launch just flushed eagerly"""
-        self.ws = self.kernels.colsqnorm_multi_workspace(self._last_items)
+        """for graph capture: a workspace of its own for the launches of the sample just run
+        eagerly — sized for the LARGEST of them (a Linear called twice per forward flushes more
+        than once; the launches of one graph run one after the other and the tickets in the
+        workspace reset themselves, so they can share it)"""
+        sizes = [self.kernels.colsqnorm_multi_workspace(items) for items in self._sample_flushes]
+        if not sizes or any(w is None for w in sizes):
+            self.ws = None
+        else:
+            self.ws = max(sizes, key=lambda w: w.numel())
         return self.ws is not None
 
     def merge(self, local_batch_ids, n_global, process_group):
@@ -425,7 +455,8 @@ class _BlockwiseWanda:
                 # ONE K6 launch per block and sample; under data parallelism the per-batch
                 # statistics are kept apart and replayed in global order (exact)
                 collector[0] = _K6Collector(
-                    self.kernels, raw=world > 1 and hasattr(self.kernels, "colsq_replay"))
+                    self.kernels, raw=world > 1 and hasattr(self.kernels, "colsq_replay"),
+                    immediate=bool(getattr(self.owner, "k6_immediate", False)))
                 for w_ in wrapped.values():
                     w_.sink = collector[0]
             if graphed:

@@ -50,7 +50,13 @@ def test_harness_writes_reference_outputs(tmp_path, monkeypatch):
         "--num_data_first_stage", "8", "--vit_prune_spec", "3-0.5-1.0-1.0", "--save_pruned_model",
         "--job_id", "t", "--out_dir", str(tmp_path)])
     sd = torch.load(tmp_path / "pruned_checkpoint" / "t.pth")
-    assert set(sd.keys()) == set(model.state_dict().keys())
+    # the EVA-CLIP entry point saves the vision tower only, minus `blocks.39`
+    # (LAVIS/evaluate_eva_clip.py:414-424); the toy tower has 3 blocks, so that is every
+    # `visual.` key and nothing else (no `classifier` buffer)
+    full = model.state_dict()
+    assert set(sd.keys()) == {k for k in full if k.startswith("visual.")} != set(full.keys())
+    for k in sd:
+        assert torch.equal(sd[k], full[k]), k
     saved = yaml.safe_load(open(tmp_path / "sparsity_dict" / "t.yaml"))
     assert saved == table and len(saved) == 12
     stats = yaml.safe_load(open(tmp_path / "training_statistics" / "t.yaml"))
@@ -73,9 +79,10 @@ def test_z_source_flag_reaches_the_pruner_and_draws_as_the_reference(tmp_path):
             "--max_sparsity_per_layer", "0.6", "--prunining_dataset_batch_size", "2", "--num_data", "8",
             "--num_data_first_stage", "8", "--t5_prune_spec", "2-0.5-1.0-1.0",
             "--vit_prune_spec", "2-0.5-1.0-1.0"]
-    assert H.config_dict(H.build_parser().parse_args(argv))["z_source"] == "philox"
-    assert H.config_dict(H.build_parser().parse_args(argv + ["--z_source", "torch"]))["z_source"] == "torch"
-    m1, t1 = H.main(argv + ["--z_source", "torch"], kernels=OracleKernels())
+    # the reference's draw is the DEFAULT at every entrypoint; the in-register stream is opt-in
+    assert H.config_dict(H.build_parser().parse_args(argv))["z_source"] == "torch"
+    assert H.config_dict(H.build_parser().parse_args(argv + ["--z_source", "philox"]))["z_source"] == "philox"
+    m1, t1 = H.main(argv, kernels=OracleKernels())            # the default IS the reference's draw
     real = ecoflap_amd.load_pruner
     try:
         ecoflap_amd.load_pruner = lambda name, model, loader, cfg_path=None, cfg=None: real(
@@ -198,3 +205,15 @@ def test_launcher_table_produces_valid_harness_flags():
     a = H.build_parser().parse_args(shlex.split(L.harness_flags(*L.JOBS["blip2/ecoflap_zeroth"])))
     assert a.job_id == "cc3m-blipt5_wanda_pruner_0.5-1.0-1.0_MEZO-GradOnly_sum0.6_block_bs8"
     assert a.max_sparsity_per_layer == 0.6 and a.t5_prune_spec == "24-0.5-1.0-1.0"
+
+
+def test_eva_clip_checkpoint_filter_drops_block_39_and_everything_outside_the_tower():
+    """LAVIS/evaluate_eva_clip.py:414-424: `"blocks.39" in name` -> dropped, `"visual." not in
+    name` -> dropped (substring tests); BLIP-2 / T5 checkpoints are the whole state_dict."""
+    import ecoflap_amd.harness as H
+    sd = {"visual.blocks.38.attn.qkv.weight": 1, "visual.blocks.39.attn.qkv.weight": 2,
+          "visual.blocks.39.mlp.fc1.bias": 3, "visual.cls_token": 4, "visual.head.weight": 5,
+          "classifier": 6, "logit_scale": 7, "text.transformer.w": 8}
+    kept = H.checkpoint_to_save(sd, "vit")
+    assert list(kept) == ["visual.blocks.38.attn.qkv.weight", "visual.cls_token", "visual.head.weight"]
+    assert H.checkpoint_to_save(sd, "blip2") is sd and H.checkpoint_to_save(sd, "t5") is sd

@@ -247,3 +247,129 @@ def test_hooked_prefix_adapter_falls_back_when_the_call_sequence_changes():
         assert hooked.disabled and len(w) == 1
         assert torch.equal(hooked(model, b3, False)[0], loss(model, b3, False)[0])
     assert all(m.forward.__func__ is torch.nn.Linear.forward for m in model.blocks)      # patches removed
+
+
+def test_blas_guard_refuses_every_time_not_only_the_first(monkeypatch):
+    """A failed probe is not cached: a second run in the same process (after the first refusal
+    was caught) is refused again; the two properties — the variable in the environment,
+    batch invariance — are reported apart, and a caller that never concatenates evaluations is
+    not refused for missing batch invariance alone."""
+    import pytest
+    from ecoflap_amd import blas_guard as G
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(G, "_verified", {})
+    monkeypatch.delenv("ECOFLAP_ALLOW_STREAMK", raising=False)
+    calls = []
+
+    def probe(result):
+        def f(dev):
+            calls.append(dev)
+            return result
+        return f
+
+    # 1. the variable is set but the probe says "not batch invariant"
+    monkeypatch.setenv(G.ENV, "1")
+    monkeypatch.setattr(G, "_probe", probe((False, True)))
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="not batch invariant"):
+            G.verify("cuda:0")
+    assert len(calls) == 2 and G._verified == {}          # probed again, nothing cached
+    with pytest.warns(UserWarning, match="could not be confirmed"):
+        assert G.verify("cuda:0", need_batch_invariance=False) is True
+    # 2. the variable is missing: refused on that alone, with the probe's result in the message
+    monkeypatch.delenv(G.ENV)
+    monkeypatch.setattr(G, "_probe", probe((True, True)))
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="is not in effect.*batch invariant at 16 evaluations = True"):
+            G.verify("cuda:0", need_batch_invariance=False)
+    assert G._verified == {}
+    # 3. the override turns refusals into warnings, still every time
+    monkeypatch.setenv("ECOFLAP_ALLOW_STREAMK", "1")
+    for _ in range(2):
+        with pytest.warns(UserWarning, match="is not in effect"):
+            assert G.verify("cuda:0") is False
+    # 4. a pass is cached
+    monkeypatch.setenv(G.ENV, "1")
+    n = len(calls)
+    assert G.verify("cuda:0") is True and G.verify("cuda:0") is True
+    assert len(calls) == n + 1 and G._verified == {0: (True, True)}
+
+
+def test_hooked_prefix_cache_is_bounded_for_a_loader_of_fresh_batches():
+    """A loader that yields NEW batch objects on every pass gets no reuse from an identity-keyed
+    cache; it must not keep every batch (and its recorded activations) alive either."""
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(4, 4) for _ in range(3)])
+
+        def forward(self, batch):
+            x = batch["x"]
+            for b in self.blocks:
+                x = b(x)
+            return {"loss": x.pow(2).mean()}
+
+    torch.manual_seed(0)
+    model = Net().eval()
+    loss = lambda m, b, c: (m(b)["loss"], 2)         # noqa: E731
+    hooked = HookedPrefixLoss(model, loss, ["blocks"], max_batches=8)
+    hooked.begin_layer("blocks.2.weight")
+    kept = [{"x": torch.randn(2, 4)} for _ in range(3)]
+    with torch.no_grad():
+        for i in range(40):
+            fresh = {"x": torch.randn(2, 4)}
+            assert torch.equal(hooked(model, fresh, False)[0], loss(model, fresh, False)[0])
+            b = kept[i % 3]                            # a working set inside the bound stays served
+            assert torch.equal(hooked(model, b, False)[0], loss(model, b, False)[0])
+            assert len(hooked._held) <= 8 and len(hooked.cache) <= 8 and len(hooked.valid) <= 8
+    assert hooked.stats["evicted"] >= 30
+    assert hooked.stats["events_served"] >= 2 * 37     # blocks 0 and 1 of the kept batches, after their first pass
+
+
+def test_k6_collector_refuses_inputs_written_in_place_before_the_flush():
+    """The deferred one-launch column statistic keeps the hooked inputs by reference; an input
+    modified in place before `flush()` is detected (tensor version counter) and refused loudly;
+    `immediate=True` reduces inside the hook, as the reference does, and has no such limit."""
+    import pytest
+    from ecoflap_amd.pruners.wanda import _K6Collector
+
+    class Kern:
+        def __init__(self):
+            self.seen = []
+
+        def colsqnorm_accum_multi(self, items, ws=None):
+            self.seen.append([x.clone() for _, x, *_ in items])
+
+    class W:
+        scaler_row, nsamples, n_dev = None, 0, None
+
+    x = torch.ones(4, 3)
+    col = _K6Collector(Kern())
+    col.add(W(), x, 2)
+    x.add_(1.0)                                       # in-place residual add after the Linear
+    with pytest.raises(RuntimeError, match="modified in place"):
+        col.flush()
+    k = Kern()
+    col = _K6Collector(k, immediate=True)
+    w = W()
+    x = torch.ones(4, 3)
+    col.add(w, x, 2)                                  # reduced here
+    x.add_(1.0)
+    col.flush()
+    col.end_sample()
+    assert len(k.seen) == 1 and torch.equal(k.seen[0][0], torch.ones(4, 3)) and w.nsamples == 2
+    # two launches in one sample (a Linear called twice): the private workspace is sized for
+    # the larger one
+    class K2(Kern):
+        def colsqnorm_multi_workspace(self, items):
+            return torch.zeros(sum(x.numel() for _, x, *_ in items), dtype=torch.uint8)
+    col = _K6Collector(K2())
+    w = W()
+    col.add(w, torch.ones(8, 3), 2)
+    col.add(w, torch.ones(2, 3), 2)                  # same Linear again: flushes the first
+    col.flush()
+    col.end_sample()
+    assert col.private_workspace() and col.ws.numel() == 24
