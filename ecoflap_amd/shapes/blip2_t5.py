@@ -104,8 +104,16 @@ class Blip2T5(nn.Module):
     def device(self):
         return self.query_tokens.device
 
+    # True: autocast on the CPU too (torch.autocast("cpu", ...)), so that the fp16 / bf16 model
+    # — and the reference's own pruner driving it, tests/golden/make_golden.py — runs at its true
+    # dtypes in a container without a GPU.  The reference's maybe_autocast is a no-op on the CPU
+    # (blip2.py:36-44), where it only ever holds fp32 weights.
+    cpu_autocast = False
+
     def maybe_autocast(self, dtype=torch.float16):
         if self.device.type == "cpu":
+            if self.cpu_autocast:
+                return torch.autocast("cpu", dtype=dtype)
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=dtype)
 
@@ -172,6 +180,19 @@ def blip2_flant5xl():
     """Config 3 shape: 588 prunable matrices, 3 701 932 032 prunable elements."""
     return Blip2T5(vit_kwargs=dict(img_size=224, patch_size=14, embed_dim=1408, depth=39,
                                    num_heads=16, mlp_hidden=6144))
+
+
+def blip2_width_slice(vit_depth=2, t5_layers=2):
+    """BLIP-2 at its TRUE WIDTHS and dtypes, few blocks: EVA ViT-g blocks (1408 / 6144, 16 heads,
+    257 tokens, fp16 Linear weights), the full Q-Former, FlanT5-XL blocks (2048 / 5120, 32 heads,
+    bf16) — what config 3's matrices look like to K1 / K6 / K7 (row lengths 1408 / 2048 / 5120 /
+    6144, a ViT-g block group of 25 231 360 > 2^24 elements), small enough for the reference's
+    own pruner to run it on the CPU (`cpu_autocast`)."""
+    m = Blip2T5(vit_kwargs=dict(img_size=224, patch_size=14, embed_dim=1408, depth=vit_depth,
+                                num_heads=16, mlp_hidden=6144),
+                t5_cfg=t5_config(num_layers=t5_layers))
+    m.cpu_autocast = True
+    return m
 
 
 def blip2_toy(depth=2, t5_layers=2, fp32=True):

@@ -359,8 +359,12 @@ class T5(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    cpu_autocast = False      # see Blip2T5.cpu_autocast
+
     def maybe_autocast(self, dtype=torch.float16):
         if self.device.type == "cpu":
+            if self.cpu_autocast:
+                return torch.autocast("cpu", dtype=dtype)
             import contextlib
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=dtype)

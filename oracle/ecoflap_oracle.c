@@ -255,18 +255,33 @@ double oracle_absprod_reduce(const void* w, const void* g, int64_t n, int dtw, i
 }
 
 /* ------------------------------------------------------------------ K6 (W:71-84)
- * scaler_row *= n/(n+b); n += b; scaler_row += norm(x,2,dim=tokens)**2 / n */
+ * scaler_row *= n/(n+b); n += b; scaler_row += norm(x,2,dim=tokens)**2 / n
+ *
+ * The sum of squares is torch's, bit for bit, as its CPU kernel forms it for this call
+ * (`torch.norm(inp, p=2, dim=1)` on the TRANSPOSED [cols, tokens] fp32 view: an outer reduction,
+ * one fp32 accumulator per column, tokens in order, acc = fma(x, x, acc) — ATen's NormTwoOps
+ * `acc + data * data` compiled with contraction; measured in this container against torch
+ * 2.10 for fp32 / fp16 / bf16 inputs at 16 ... 2056 tokens x 768 ... 6144 columns: 0 differing
+ * columns, where a double-precision sum rounded once differs in most columns at long token
+ * counts).  At true row lengths the Wanda selection sits on near-ties of |W| * sqrt(scaler_row)
+ * (bf16 weights take few distinct magnitudes), so an ulp in this statistic moves masks:
+ * tests/test_true_width.py.  A GPU reduction necessarily adds in another order; the HIP
+ * kernel is held to a few ulps of this value (tests/test_gpu_parity.py). */
+static inline float colsq_sum(const void* x, int64_t tokens, int64_t cols, int64_t c, int dt) {
+    float s = 0.0f;
+    for (int64_t t = 0; t < tokens; ++t) {
+        float v = load_dt(x, t * cols + c, dt);
+        s = fmaf(v, v, s);
+    }
+    return s;
+}
+
 void oracle_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens, int64_t cols,
                             int dt, int64_t n_before, int64_t batch) {
     float decay = (float)((double)n_before / (double)(n_before + batch));
     float n_new = (float)(n_before + batch);
     for (int64_t c = 0; c < cols; ++c) {
-        double s = 0.0;
-        for (int64_t t = 0; t < tokens; ++t) {
-            float v = load_dt(x, t * cols + c, dt);
-            s += (double)(v * v);
-        }
-        float nrm = sqrtf((float)s);
+        float nrm = sqrtf(colsq_sum(x, tokens, cols, c, dt));
         float sq = nrm * nrm;
         float r = scaler_row[c] * decay;
         scaler_row[c] = r + sq / n_new;
@@ -278,12 +293,7 @@ void oracle_colsqnorm_accum(float* scaler_row, const void* x, int64_t tokens, in
  * stage 2 exchanges; composing the two equals oracle_colsqnorm_accum call by call. */
 void oracle_colsq_raw(float* out_row, const void* x, int64_t tokens, int64_t cols, int dt) {
     for (int64_t c = 0; c < cols; ++c) {
-        double s = 0.0;
-        for (int64_t t = 0; t < tokens; ++t) {
-            float v = load_dt(x, t * cols + c, dt);
-            s += (double)(v * v);
-        }
-        float nrm = sqrtf((float)s);
+        float nrm = sqrtf(colsq_sum(x, tokens, cols, c, dt));
         out_row[c] = nrm * nrm;
     }
 }
@@ -307,53 +317,79 @@ void oracle_colsq_replay(float* scaler_row, const float* sq, const int64_t* batc
 static inline float wanda_metric(const void* w, int64_t i, int dt, float sq) {
     return fabsf(load_dt(w, i, dt)) * sq;   /* abs(W) * sqrt(scaler_row) in fp32 */
 }
-typedef struct { float m; int64_t idx; } mi_t;
-static int cmp_mi(const void* a, const void* b) {
-    const mi_t* x = (const mi_t*)a; const mi_t* y = (const mi_t*)b;
-    /* torch.sort(stable=True) ascending: NaN last, ties by original index */
-    int xn = isnan(x->m), yn = isnan(y->m);
-    if (xn != yn) return xn - yn;
-    if (!xn) { if (x->m < y->m) return -1; if (x->m > y->m) return 1; }
-    return (x->idx > y->idx) - (x->idx < y->idx);
+/* torch.sort(stable=True) ascending: NaN last, ties (incl. -0.0 == +0.0) by original index.
+ * An order-preserving 32-bit key of the metric and a STABLE least-significant-digit radix sort
+ * give exactly that order (the comparator-based qsort this replaces took most of a CPU parity
+ * run at true row lengths); `cmp_f` below is the same order as a comparator. */
+static inline uint32_t sort_key(float m) {
+    uint32_t u;
+    if (isnan(m)) return 0xffffffffu;
+    if (m == 0.0f) m = 0.0f;                       /* -0.0 and +0.0 compare equal */
+    memcpy(&u, &m, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-/* rows mode: zero the first k columns of each row in stable ascending metric order */
-void oracle_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows, int64_t cols,
-                             int dt, int64_t k, uint8_t* mask) {
-    mi_t* buf = (mi_t*)malloc(sizeof(mi_t) * (size_t)cols);
-    float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
-    for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
-    if (mask) memset(mask, 0, (size_t)(rows * cols));
-    for (int64_t r = 0; r < rows; ++r) {
-        for (int64_t c = 0; c < cols; ++c) {
-            buf[c].m = wanda_metric(w, r * cols + c, dt, sq[c]);
-            buf[c].idx = c;
+/* stable LSD radix sort of (key, idx) pairs by key; result in key/idx (tmp arrays: same length) */
+static void radix_sort_pairs(uint32_t* key, int32_t* idx, uint32_t* tkey, int32_t* tidx, int64_t n) {
+    for (int pass = 0; pass < 4; ++pass) {
+        int64_t count[257] = {0};
+        const int sh = 8 * pass;
+        for (int64_t i = 0; i < n; ++i) ++count[((key[i] >> sh) & 0xff) + 1];
+        for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t d = count[(key[i] >> sh) & 0xff]++;
+            tkey[d] = key[i];
+            if (idx) tidx[d] = idx[i];
         }
-        qsort(buf, (size_t)cols, sizeof(mi_t), cmp_mi);
-        for (int64_t j = 0; j < k && j < cols; ++j) {
-            store_dt(w, r * cols + buf[j].idx, dt, 0.0f);
-            if (mask) mask[r * cols + buf[j].idx] = 1;
-        }
-    }
-    free(buf); free(sq);
+        uint32_t* sk = key; key = tkey; tkey = sk;
+        if (idx) { int32_t* si = idx; idx = tidx; tidx = si; }
+    }   /* four passes: the result is back in the caller's arrays */
 }
-/* matrix mode: thres = sort(flatten)[k]; zero every metric <= thres */
 static int cmp_f(const void* a, const void* b) {
     float x = *(const float*)a, y = *(const float*)b;
     int xn = isnan(x), yn = isnan(y);
     if (xn != yn) return xn - yn;
     return (x > y) - (x < y);
 }
+/* rows mode: zero the first k columns of each row in stable ascending metric order */
+void oracle_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows, int64_t cols,
+                             int dt, int64_t k, uint8_t* mask) {
+    uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cols * 2);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)cols * 2);
+    float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
+    for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
+    if (mask) memset(mask, 0, (size_t)(rows * cols));
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int64_t c = 0; c < cols; ++c) {
+            key[c] = sort_key(wanda_metric(w, r * cols + c, dt, sq[c]));
+            idx[c] = (int32_t)c;
+        }
+        radix_sort_pairs(key, idx, key + cols, idx + cols, cols);
+        for (int64_t j = 0; j < k && j < cols; ++j) {
+            store_dt(w, r * cols + idx[j], dt, 0.0f);
+            if (mask) mask[r * cols + idx[j]] = 1;
+        }
+    }
+    free(key); free(idx); free(sq);
+}
+/* matrix mode: thres = sort(flatten)[k]; zero every metric <= thres */
 void oracle_wanda_prune_matrix(void* w, const float* scaler_row, int64_t rows, int64_t cols,
                                int dt, int64_t k, uint8_t* mask) {
     int64_t n = rows * cols;
     float* m = (float*)malloc(sizeof(float) * (size_t)n);
-    float* s = (float*)malloc(sizeof(float) * (size_t)n);
+    uint32_t* s = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n * 2);
     float* sq = (float*)malloc(sizeof(float) * (size_t)cols);
     for (int64_t c = 0; c < cols; ++c) sq[c] = sqrtf(scaler_row[c]);
-    for (int64_t i = 0; i < n; ++i) m[i] = wanda_metric(w, i, dt, sq[i % cols]);
-    memcpy(s, m, sizeof(float) * (size_t)n);
-    qsort(s, (size_t)n, sizeof(float), cmp_f);
-    float thres = s[k];
+    for (int64_t i = 0; i < n; ++i) {
+        m[i] = wanda_metric(w, i, dt, sq[i % cols]);
+        s[i] = sort_key(m[i]);
+    }
+    radix_sort_pairs(s, NULL, s + n, NULL, n);
+    /* the k-th smallest VALUE (any element carrying that key: equal keys are equal values, or
+     * both NaN — then `<=` is false for every element, as in torch) */
+    float thres = 0.0f;
+    int found = 0;
+    for (int64_t i = 0; i < n && !found; ++i)
+        if (sort_key(m[i]) == s[k]) { thres = m[i]; found = 1; }
     for (int64_t i = 0; i < n; ++i) {
         int z = (m[i] <= thres);
         if (z) store_dt(w, i, dt, 0.0f);

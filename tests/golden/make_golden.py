@@ -375,6 +375,118 @@ def golden_end_to_end(registry):
     save("g7_end_to_end.npz", **out)
 
 
+# --------------------------------------------------------------------------- G18: true widths
+def sha_of(t):
+    import hashlib
+    return hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+TRUE_WIDTH_THREADS = 4        # CPU GEMM partitioning is part of the forward's bits: the tests pin it too
+
+
+def golden_true_width(registry, lavis, only=None):
+    """The reference's own pruners at the BASELINE shapes' true row lengths / dtypes / group sizes
+     — too big to store weights, so the fixture holds the sparsity table, every
+    loss the reference evaluated, per-tensor sha256 of the pruned weights and their zero counts;
+    the initial state is rebuilt from its seed by the tests (its sha256 is stored to prove it).
+
+      vitb16           BASELINE configs[0] AT ITS OWN SHAPE: ViT-B/16 (EVA names, fp32, 48 matrices),
+                       8 samples bs 8, MEZO-GradOnly_sum, block, max 0.6 — scripts/eva_clip/ecoflap.py's
+                       flags through `vit_wanda_pruner`; model / loader built by the build's harness
+                       with config "1" of tools/run_config.py, so `harness.main` reproduces the inputs
+      blip2_slice      BLIP-2 at ViT-g width (1408 / 6144, fp16) + Q-Former + FlanT5-XL width
+                       (2048 / 5120, bf16), 2 + 2 + 2 blocks, `blipt5_wanda_pruner`, MEZO-GradOnly_sum,
+                       block, max 0.6: K1 fp16 / bf16 at true sizes, a 25 231 360-element group
+                       (> 2^24: the allocator's float32 counts), matrix- and rows-mode selection at
+                       true row lengths
+      t5xl_first       FlanT5-XL width, 2 + 2 blocks, `t5_wanda_pruner`, GradMagAbs_sum (configs[1]'s
+                       method), 8 sequences bs 1
+      t5xl_zeroth      the same model, MEZO-GradOnly_avg (scripts/t5/ecoflap.py's method)
+    """
+    import argparse
+    from ecoflap_amd import harness as H
+    from ecoflap_amd.shapes.blip2_t5 import blip2_width_slice
+    path = os.path.join(HERE, "g18_true_width.npz")
+    out = dict(np.load(path, allow_pickle=False)) if (only and os.path.exists(path)) else {}
+    torch.set_num_threads(TRUE_WIDTH_THREADS)
+    wp = lavis["wanda_pruner"]
+    base = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+                is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1,
+                num_noise=1, noise_eps=1e-3)
+
+    def run(tag, name, model, batches, cfg):
+        import time
+        t0 = time.time()
+        for k in [k for k in out if k.startswith(tag + "_")]:
+            del out[k]
+        out[f"{tag}_init_sha"] = np.array(sha_of(torch.cat(
+            [v.detach().reshape(-1).view(torch.uint8) for v in model.state_dict().values()])))
+        logs = {}
+        for fn in ("loss_vision", "loss_language", "loss_vision_language"):
+            logs[fn] = LossLog(getattr(lavis["utils"], fn))
+            setattr(wp, fn, logs[fn])
+        try:
+            pruner = registry.get_pruner_class(name)(model=model, data_loader=batches, **cfg)
+            model2, sp = pruner.prune()
+        finally:
+            for fn in logs:
+                setattr(wp, fn, getattr(lavis["utils"], fn))
+        names = sorted(sp.keys())
+        out[f"{tag}_sparsity_names"] = np.array(names)
+        out[f"{tag}_sparsity"] = np.array([sp[k] for k in names], dtype=np.float64)
+        out[f"{tag}_losses"] = np.array(sum((logs[fn].values for fn in logs), []), dtype=np.float64)
+        keys = [k for k, v in model2.state_dict().items()
+                if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
+        out[f"{tag}_final_names"] = np.array(keys)
+        sd = model2.state_dict()
+        out[f"{tag}_final_sha"] = np.array([sha_of(sd[k]) for k in keys])
+        out[f"{tag}_final_zeros"] = np.array([int((sd[k] == 0).sum()) for k in keys], dtype=np.int64)
+        out[f"{tag}_threads"] = np.array([TRUE_WIDTH_THREADS])
+        print(tag, f"{time.time() - t0:.1f} s", len(names), "table entries,", len(out[f"{tag}_losses"]),
+              "losses,", len(set(sp.values())), "distinct ratios")
+
+    cases = only or ["vitb16", "blip2_slice", "t5xl_first", "t5xl_zeroth"]
+    if "vitb16" in cases:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import run_config
+        args = H.build_parser().parse_args(run_config.CONFIGS["1"] + ["--device", "cpu"])
+        import random
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        model, loader = H.build_model_and_loader(args, torch.device("cpu"))
+        cfg = {k: v for k, v in H.config_dict(args).items()
+               if k not in ("z_source", "k1_form", "eval_batch", "n_lanes")}
+        run("vitb16", args.pruning_method, model, loader, cfg)
+    if "blip2_slice" in cases:
+        np.random.seed(42)
+        torch.manual_seed(31)
+        model = blip2_width_slice().eval()
+        batches = S.image_text_batches(4, 2, img_size=224, vocab=32128, seed=6)
+        run("blip2_slice", "blipt5_wanda_pruner", model, batches,
+            dict(base, t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+                 t5_pruning_method="none", vit_pruning_method="none", num_samples=4,
+                 max_sparsity_per_layer=0.6, num_data_first_stage=4,
+                 sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum"))
+    for tag, method in (("t5xl_first", "GradMagAbs_sum"), ("t5xl_zeroth", "MEZO-GradOnly_avg")):
+        if tag not in cases:
+            continue
+        np.random.seed(42)
+        torch.manual_seed(0)
+        model = T5(t5_config(num_layers=2), dtype=torch.bfloat16, init_std=0.02).eval()
+        model.cpu_autocast = True
+        # (an "image" key only because the reference's T5 stage 2 counts samples by it,
+        # wanda_pruner.py:204 — SURVEY F8a; the model never reads it)
+        batches = S.image_text_batches(8, 1, img_size=4, vocab=32128, in_len=32, out_len=16, seed=42)
+        # (zeroth order: 4 of the 8 sequences in stage 1 — 288 forwards instead of 576 keeps the
+        # CPU test that replays this under a minute; stage 2 calibrates on all 8)
+        run(tag, "t5_wanda_pruner", model, batches,
+            dict(base, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+                 max_sparsity_per_layer=0.6, score_method=method,
+                 num_data_first_stage=4 if method.startswith("MEZO") else 8))
+    save("g18_true_width.npz", **out)
+
+
 # --------------------------------------------------------------------------- G16: n:m branch
 def golden_nm(registry):
     """The structured n:m branch of both Wanda pruners (wanda_pruner.py:265-270 rows pruner, :546-551
@@ -850,9 +962,13 @@ if __name__ == "__main__":
     LayerSparsity, WrappedGPT = import_upop_pruners()
     registry, lavis = import_lavis_pruners()
     only = sys.argv[1:] or ["k1", "alloc", "wrapped", "scoring", "e2e", "names", "upop", "sparsegpt", "real", "global",
-                            "protected", "clip", "nm"]
+                            "protected", "clip", "nm", "true_width"]
     if "clip" in only:
         golden_clip()
+    if any(a.startswith("true_width") for a in only):
+        # `true_width` = all four cases; `true_width:blip2_slice,t5xl_first` = those only
+        sel = [a.split(":", 1)[1].split(",") for a in only if a.startswith("true_width:")]
+        golden_true_width(registry, lavis, only=sel[0] if sel else None)
     if "k1" in only:
         golden_k1(LayerSparsity)
     if "alloc" in only:

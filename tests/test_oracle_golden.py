@@ -73,14 +73,16 @@ def test_wrapped_gpt_running_mean(oracle, golden_dir):
             x2 = x.reshape(-1, x.shape[-1]).contiguous()
             oracle.colsqnorm_accum(s, x2, n, b)
             n += b
-            np.testing.assert_allclose(s.numpy(), g[f"{key}_s{i}"], rtol=1e-5, atol=0)
+            # bit for bit: the oracle adds the squares in torch's own order (one fp32 fma chain per
+            # column over the tokens)
+            assert np.array_equal(s.numpy(), g[f"{key}_s{i}"]), (key, i)
 
 
 def test_wrapped_gpt_raw_rows_replayed_equal_the_running_mean(oracle, golden_dir):
     """The decomposition the data-parallel stage 2 exchanges: per-batch ||x_c||^2 rows
     (`oracle_colsq_raw`) replayed in order (`oracle_colsq_replay`) == WrappedGPT.add_batch call
-    by call (wanda_pruner.py:71-84) — bit for bit against the fused restatement, 1e-5 against
-    the reference's own scaler_row goldens."""
+    by call (wanda_pruner.py:71-84) — bit for bit against the fused restatement and against the
+    reference's own scaler_row goldens."""
     g = np.load(os.path.join(golden_dir, "g5_wrapped_gpt.npz"))
     for case in g["cases"]:
         key, steps = str(case).split("|")
@@ -101,7 +103,29 @@ def test_wrapped_gpt_raw_rows_replayed_equal_the_running_mean(oracle, golden_dir
             rep = torch.zeros(cols, dtype=torch.float32)
             oracle.colsq_replay(rep, torch.stack(rows), bs)
             assert torch.equal(rep, fused), (key, i)
-            np.testing.assert_allclose(rep.numpy(), g[f"{key}_s{i}"], rtol=1e-5, atol=0)
+            assert np.array_equal(rep.numpy(), g[f"{key}_s{i}"]), (key, i)
+
+
+def test_wrapped_gpt_statistic_equals_torch_at_true_sizes(oracle):
+    """The reference's op chain (wanda_pruner.py:71-84: `inp.t()`, `.type(torch.float32)`,
+    `torch.norm(inp, p=2, dim=1) ** 2 / nsamples`) evaluated by torch on the CPU, against the
+    oracle, at the BASELINE shapes' token counts and widths and in their dtypes: bit for bit
+    (an ulp here moves Wanda masks at true row lengths: tests/test_true_width.py)."""
+    g = torch.Generator().manual_seed(5)
+    for dt, tokens, cols, batch in [(torch.bfloat16, 16, 2048, 1), (torch.bfloat16, 8 * 48, 5120, 8),
+                                    (torch.float16, 2 * 257, 1408, 2), (torch.float16, 8 * 257, 6144, 8),
+                                    (torch.float32, 8 * 197, 768, 8), (torch.float32, 8 * 197, 3072, 8)]:
+        row_ref = torch.zeros(cols, dtype=torch.float32)
+        row = torch.zeros(cols, dtype=torch.float32)
+        n = 0
+        for _ in range(2):
+            x = (torch.randn(tokens, cols, generator=g) * 1.3).to(dt)
+            inp = x.t().type(torch.float32)
+            row_ref *= n / (n + batch)
+            row_ref += torch.norm(inp, p=2, dim=1) ** 2 / (n + batch)
+            oracle.colsqnorm_accum(row, x, n, batch)
+            n += batch
+            assert torch.equal(row, row_ref), (dt, tokens, cols, int((row != row_ref).sum()))
 
 
 def test_philox_known_answer(oracle):

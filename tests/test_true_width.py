@@ -1,0 +1,154 @@
+"""Parity at the BASELINE shapes' TRUE row lengths, dtypes and group sizes against the reference
+itself (tests/golden/g18_true_width.npz, written by `make_golden.py true_width`, which runs the
+reference's own `vit_wanda_pruner` / `blipt5_wanda_pruner` / `t5_wanda_pruner` on the CPU):
+
+  vitb16        BASELINE configs[0] at its own shape (ViT-B/16, fp32, 48 matrices, 8 samples bs 8)
+  blip2_slice   ViT-g width fp16 (1408 / 6144) + Q-Former + FlanT5-XL width bf16 (2048 / 5120),
+                a block group of 25 231 360 > 2^24 elements
+  t5xl_first    FlanT5-XL width, first order (configs[1]'s method)
+  t5xl_zeroth   FlanT5-XL width, zeroth order (scripts/t5/ecoflap.py's method)
+
+CPU (`not gpu`): the product's host logic driven by the oracle backend, the default z source
+(= the reference's draw) and the same CPU forward equals the reference's sparsity table, every
+loss it evaluated and every pruned weight (sha256 per tensor) bit for bit.
+GPU (`gpu`): at the same sizes the HIP library equals the oracle on the GPU forward."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_same_pruning
+from oracle_backend import OracleKernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from ecoflap_amd import load_pruner  # noqa: E402
+from ecoflap_amd.shapes import synthetic as S  # noqa: E402
+
+BASE = dict(importance_scores_cache=None, keep_indices_cache=None, is_strct_pruning=False,
+            is_global=False, sparsity_dict=None, prune_per_model=False, iteration=1,
+            num_noise=1, noise_eps=1e-3)
+
+
+def sha_of(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def build(tag, device="cpu"):
+    """(pruner name, model, batches, cfg): the recipe of make_golden.py::golden_true_width."""
+    dev = torch.device(device)
+    if tag == "vitb16":
+        import random
+        import run_config
+        from ecoflap_amd import harness as H
+        args = H.build_parser().parse_args(run_config.CONFIGS["1"] + ["--device", device])
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        # (weights are drawn on the CPU and moved: the same initial state on either device)
+        model, loader = H.build_model_and_loader(args, torch.device("cpu"))
+        model = model.to(dev)
+        loader = [{k: v.to(dev) for k, v in b.items()} for b in loader]
+        cfg = {k: v for k, v in H.config_dict(args).items()
+               if k not in ("z_source", "k1_form", "eval_batch", "n_lanes")}
+        return args.pruning_method, model, loader, cfg
+    if tag == "blip2_slice":
+        from ecoflap_amd.shapes.blip2_t5 import blip2_width_slice
+        np.random.seed(42)
+        torch.manual_seed(31)
+        model = blip2_width_slice().eval().to(dev)
+        batches = S.image_text_batches(4, 2, img_size=224, vocab=32128, seed=6, device=dev)
+        return "blipt5_wanda_pruner", model, batches, dict(
+            BASE, t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+            t5_pruning_method="none", vit_pruning_method="none", num_samples=4,
+            max_sparsity_per_layer=0.6, num_data_first_stage=4,
+            sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum")
+    from ecoflap_amd.shapes.t5 import T5, t5_config
+    method = {"t5xl_first": "GradMagAbs_sum", "t5xl_zeroth": "MEZO-GradOnly_avg"}[tag]
+    np.random.seed(42)
+    torch.manual_seed(0)
+    model = T5(t5_config(num_layers=2), dtype=torch.bfloat16, init_std=0.02).eval()
+    model.cpu_autocast = True
+    model = model.to(dev)
+    batches = S.image_text_batches(8, 1, img_size=4, vocab=32128, in_len=32, out_len=16, seed=42,
+                                   device=dev)
+    return "t5_wanda_pruner", model, batches, dict(
+        BASE, prune_spec="2-0.5-1.0-1.0", num_samples=8, sparsity_ratio_granularity="block",
+        max_sparsity_per_layer=0.6, score_method=method,
+        num_data_first_stage=4 if method.startswith("MEZO") else 8)
+
+
+def run(tag, kernels, device="cpu", keep_weights=False, **extra):
+    name, model, batches, cfg = build(tag, device)
+    init_sha = sha_of(torch.cat([v.detach().cpu().reshape(-1).view(torch.uint8)
+                                 for v in model.state_dict().values()]))
+    cfg = dict(cfg, **extra)
+    if kernels is not None:
+        cfg["kernels"] = kernels
+    pruner = load_pruner(name, model, batches, cfg=cfg)
+    model, table = pruner.prune()
+    sd = model.state_dict()
+    keys = [k for k, v in sd.items()
+            if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
+    engine = getattr(pruner, "layer_sparsity_engine", None)
+    losses = getattr(engine, "loss_table", None)
+    return {"init_sha": init_sha, "table": table, "keys": keys,
+            "weights": {k: sd[k].detach().cpu() for k in keys} if keep_weights else None,
+            "sha": [sha_of(sd[k]) for k in keys],
+            "zeros": [int((sd[k] == 0).sum()) for k in keys],
+            "losses": None if losses is None else np.asarray(losses, dtype=np.float64).reshape(-1)}
+
+
+CASES = ["vitb16", "blip2_slice", "t5xl_first", "t5xl_zeroth"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_true_width_matches_the_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g18_true_width.npz"))
+    n = torch.get_num_threads()
+    torch.set_num_threads(int(g[f"{tag}_threads"][0]))     # the CPU forward's bits depend on it
+    try:
+        r = run(tag, OracleKernels())
+    finally:
+        torch.set_num_threads(n)
+    assert r["init_sha"] == str(g[f"{tag}_init_sha"]), "initial weights differ from the fixture's"
+    names = [str(k) for k in g[f"{tag}_sparsity_names"]]
+    assert sorted(r["table"]) == names
+    want = g[f"{tag}_sparsity"]
+    got = np.array([r["table"][k] for k in names], dtype=np.float64)
+    assert len(set(want.tolist())) > 1                       # a real allocation, not uniform
+    if r["losses"] is not None and tag != "t5xl_first":
+        ref_losses = g[f"{tag}_losses"]
+        assert r["losses"].shape == ref_losses.shape
+        assert np.array_equal(r["losses"].astype(np.float32), ref_losses.astype(np.float32)), (
+            "losses differ", float(np.abs(r["losses"] - ref_losses).max()))
+    assert np.array_equal(got, want), ("table differs", float(np.abs(got - want).max()))
+    assert r["keys"] == [str(k) for k in g[f"{tag}_final_names"]]
+    assert r["zeros"] == g[f"{tag}_final_zeros"].tolist()
+    bad = [k for k, a, b in zip(r["keys"], r["sha"], g[f"{tag}_final_sha"]) if a != str(b)]
+    assert not bad, f"pruned weights differ from the reference's: {bad[:4]} (+{max(len(bad) - 4, 0)})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_true_width_hip_equals_oracle(tag):
+    """Same shapes on the GPU: the HIP library vs the oracle's arithmetic on the same GPU forward
+    and the same draws (`z_source="torch"`, the default).  Table and losses: equal.  Pruned
+    weights: equal up to near-tie swaps of the selection (helpers.assert_same_pruning: the column
+    statistic is a float reduction the GPU adds in another order than torch's CPU kernel)."""
+    res = {}
+    for name, backend in (("hip", None), ("oracle", OracleKernels())):
+        res[name] = run(tag, backend, device="cuda", keep_weights=True)
+        torch.cuda.empty_cache()
+    a, b = res["hip"], res["oracle"]
+    assert a["init_sha"] == b["init_sha"]
+    assert a["table"] == b["table"] and len(set(a["table"].values())) > 1
+    if a["losses"] is not None:
+        assert np.array_equal(a["losses"], b["losses"])
+    assert a["keys"] == b["keys"] and a["zeros"] == b["zeros"]
+    differing, positions = assert_same_pruning(a["weights"], b["weights"])
+    print(f"{tag}: {differing} of {len(a['keys'])} matrices not bit-identical, {positions} positions")
