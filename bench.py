@@ -91,6 +91,14 @@ def parse():
                     help="weak (default, what the driver's scaling run measures): every rank scores "
                          "the matrices on its own --num-data pairs; strong: --num-data pairs in "
                          "total, split over the ranks (a user with one calibration set and N GPUs)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="PROJECTION, one process, no process group: run rank --emulate-rank's share "
+                         "of a W-rank data-parallel pass on this GPU — its shard of the global batch "
+                         "list and the drift-only K1 chaining of the other ranks' units — and print "
+                         "a line flagged \"projection\": true.  No collective runs and nothing "
+                         "about xGMI / RCCL is measured: the line says what one rank's GPU would "
+                         "spend per step, not what N GPUs achieve")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--no-parity-leg", action="store_true",
                     help="skip the short z_source='torch' leg after the timed region")
     ap.add_argument("--no-k1-events", action="store_true",
@@ -360,6 +368,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    emulated = args.emulate_world > 1
+    if emulated and (world != 1 or args.gpus != 1 or not 0 <= args.emulate_rank < args.emulate_world):
+        print("bench.py: --emulate-world runs as ONE process with --gpus 1 and "
+              "0 <= --emulate-rank < --emulate-world", file=sys.stderr)
+        sys.exit(2)
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
@@ -398,23 +411,25 @@ def main():
     img = 28 if args.toy else 224
     vocab = 96 if args.toy else 32128
     # every rank its own shard of the global calibration set (global batch index = rank + N*j)
-    strong = args.scaling == "strong" and world > 1
+    # the world the SCHEDULE sees: the process group's, or the emulated one (no group)
+    s_world, s_rank = (args.emulate_world, args.emulate_rank) if emulated else (world, rank)
+    strong = args.scaling == "strong" and s_world > 1
     if strong:
-        if (args.num_data // args.batch_size) % world != 0:
+        if (args.num_data // args.batch_size) % s_world != 0:
             print(f"bench.py: --scaling strong needs the {args.num_data // args.batch_size} batches "
-                  f"to divide over {world} ranks", file=sys.stderr)
+                  f"to divide over {s_world} ranks", file=sys.stderr)
             sys.exit(2)
-        args.num_data //= world
+        args.num_data //= s_world
     batches_local = S.image_text_batches(args.num_data, args.batch_size, img_size=img, vocab=vocab,
-                                         in_len=16, out_len=16, seed=42 + rank, device=dev)
+                                         in_len=16, out_len=16, seed=42 + s_rank, device=dev)
     nb_local = len(batches_local)
     # global list seen by the schedule: batch j*world + r lives on rank r (placeholders elsewhere)
     batches = []
     for j in range(nb_local):
-        for r in range(world):
-            batches.append(batches_local[j] if r == rank else
+        for r in range(s_world):
+            batches.append(batches_local[j] if r == s_rank else
                            {"text_input": batches_local[j]["text_input"]})
-    num_samples_global = args.num_data * world
+    num_samples_global = args.num_data * s_world
 
     prunable = [k for k, v in model.named_parameters()
                 if v.dim() == 2 and ".block" in k and "relative_attention_bias.weight" not in k
@@ -463,6 +478,8 @@ def main():
         ls = LayerSparsity(model, batches, loss_fn, num_samples_global, 0.5, 0.6,
                            "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=kern,
                            z_source=z_source, k1_form=args.k1_form)
+        if emulated:
+            ls.emulate_rank_world = (s_rank, s_world)
         kern.enabled = timed and events and not args.no_k1_events
         out = ls.return_sparsity()
         kern.enabled = False
@@ -517,7 +534,7 @@ def main():
     # block and one FlanT5 decoder block, each scored twice from the same cached prefix: first
     # with torch's draws, then with the in-register stream.
     parity_mode = None
-    if not args.no_parity_leg and not args.full_forward and world == 1:
+    if not args.no_parity_leg and not args.full_forward and world == 1 and not emulated:
         kern.enabled = False
         legs = {}
         vit_blocks = [b for b in block_starts if prunable[b].startswith("visual_encoder")]
@@ -556,7 +573,7 @@ def main():
     drift = kern.summary("drift")
     # weak: a matrix scored on 128 pairs per rank = one unit per rank; strong: the ranks share
     # ONE calibration set, a matrix is scored once by all of them together
-    value = (1 if strong else world) * args.steps / elapsed
+    value = (1 if strong else s_world) * args.steps / elapsed
 
     out = {
         "metric": "layers scored/sec (zeroth-order, BLIP-2 @0.5)",
@@ -583,7 +600,7 @@ def main():
             "prunable_elements": numel_total,
             "layers_timed": layer_ids,
             "pairs_per_gpu": args.num_data,
-            "pairs_total": args.num_data * world,
+            "pairs_total": args.num_data * s_world,
             "batch_size": args.batch_size,
             "forwards_per_step": 2 * nb_local,
             "k1_form": args.k1_form,
@@ -598,7 +615,8 @@ def main():
                                 if (args.eval_batch > 1 and not args.no_graphs) else
                                 (f", {args.lanes} evaluations in flight on concurrent lanes"
                                  if (args.lanes > 1 and not args.no_graphs) else ""))),
-            "parallelism": f"dp{world} (batch-sharded, one all-reduce of the loss table)",
+            "parallelism": (f"dp{s_world} (batch-sharded, one all-reduce of the loss table)"
+                            + (" — EMULATED: one rank's share on one GPU, no collective" if emulated else "")),
         },
         "breakdown": {
             "model_build_s": build_s,
@@ -658,6 +676,20 @@ def main():
                          "theta+/theta- for each of the layer's U units, write the drifted W",
                 "triple": "4*s*numel (read W; write theta+, theta-, restored)",
                 "single": "2*s*numel per pass (read W, write W)"}[kind],
+        }
+    if emulated:
+        # NOT a measurement of N GPUs: what rank r of W would spend per step on its own GPU
+        # (its 1/W of the forwards + K1 over ALL W*U units of every matrix), times W for `value`
+        # under the assumption that the ranks run in perfect parallel and the closing all-reduce
+        # of a 2.3-KB (strong: 75-KB) table is free
+        out["projection"] = True
+        out["projected"] = {
+            "world": s_world, "rank": s_rank, "n_gpus_measured": 1,
+            "what": "one rank's share of a dp%d pass timed on ONE GPU without a process group; "
+                    "`value` = %s x steps / that time" % (s_world, "1" if strong else str(s_world)),
+            "not_measured": "RCCL / xGMI transport, the other ranks, host contention of 8 processes",
+            "k1_units_chained_per_matrix": nb_local * s_world,
+            "k1_units_owned_per_matrix": nb_local,
         }
     if parity_mode is not None:
         out["parity_mode_layers_per_s"] = parity_mode["parity_mode_layers_per_s"]

@@ -125,6 +125,7 @@ class LayerSparsity:
         # graph and replayed (the eager loop is launch-bound at batch 1: thousands of tiny kernels)
         self.grad_graphs = grad_graphs
         self.process_group = process_group
+        self.emulate_rank_world = None      # (rank, world): see `_dist`
         assert k1_form in ("units", "block", "triple", "single")
         self.k1_form = k1_form
         self.stats = {}          # wall-clock + unit counts of the last run (reference: @print_time)
@@ -134,6 +135,12 @@ class LayerSparsity:
     # ------------------------------------------------------------------ distributed helpers
     def _dist(self):
         import torch.distributed as dist
+        if self.emulate_rank_world is not None:
+            # one rank's share of a data-parallel run without a process group (bench.py
+            # --emulate-rank): its batches, its K1 chaining of the not-owned units; the
+            # closing all-reduce is skipped, so the TABLE of such a run means nothing
+            rank, world = self.emulate_rank_world
+            return None, int(rank), int(world)
         if dist.is_available() and dist.is_initialized():
             group = self.process_group
             return dist, dist.get_rank(group), dist.get_world_size(group)
@@ -141,7 +148,7 @@ class LayerSparsity:
 
     def _all_reduce_sum(self, t):
         dist, _, world = self._dist()
-        if world > 1:
+        if world > 1 and dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
         return t
 
