@@ -225,7 +225,9 @@ class TimedKernels:
             owned = sum(1 for t in w_plus[c0:c1] if t is not None)
             pair = self.hip_events.pair()
             # per launch: read W, write theta+/theta- of its owned units, write the drifted W
-            self.unit_records.append((pair[0], pair[1], (2 * owned + 2) * s * n))
+            # (+ one read of z per unit when z comes from memory: the parity mode)
+            zr = (c1 - c0) if z is not None else 0
+            self.unit_records.append((pair[0], pair[1], (2 * owned + 2 + zr) * s * n))
             return pair
         return self.inner.zo_perturb_units(w, zo_eps, seeds, w_plus, w_minus, z, events=events)
 
@@ -235,8 +237,10 @@ class TimedKernels:
         if self.hip_events is None:
             self.hip_events = HipEvents()
         # per layer: read W, write theta+/theta- of its owned units, write the drifted W
-        nbytes = sum((2 * sum(1 for t in plus if t is not None) + 2) * w.element_size() * w.numel()
-                     for w, _, _, plus, _ in layers)
+        # (+ one read of z per unit when z comes from memory: the parity mode)
+        nbytes = sum((2 * sum(1 for t in it[3] if t is not None) + 2
+                      + (len(it[5]) if len(it) > 5 and it[5] is not None else 0))
+                     * it[0].element_size() * it[0].numel() for it in layers)
         pair = self.hip_events.pair()
         self.unit_records.append((pair[0], pair[1], nbytes))
         self.layers_per_launch.append(len(layers))
@@ -542,15 +546,45 @@ def main():
         picks = [bs[len(bs) // 2] for bs in (vit_blocks, dec_blocks) if bs]
         ends = {b: (block_starts[block_starts.index(b) + 1]
                     if block_starts.index(b) + 1 < len(block_starts) else n_total) for b in picks}
+        class DrawTimer:
+            """The reference's draw (layer_single_base_pruner.py:482-485) with a torch event pair
+            around it: what the z tensors cost to produce (torch.normal's own kernels write each
+            z once; K1 reads it once)."""
+
+            def __init__(self):
+                self.pairs, self.bytes = [], 0
+
+            def __call__(self, seed, param):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                torch.manual_seed(seed)
+                z = torch.normal(mean=0, std=1, size=param.data.size(), device=param.data.device,
+                                 dtype=param.data.dtype)
+                e_.record()
+                self.pairs.append((s_, e_))
+                self.bytes += z.numel() * z.element_size()
+                return z
+
+        draws = DrawTimer()
+        main_records, main_lpl = kern.unit_records, kern.layers_per_launch
+        kern.unit_records, kern.layers_per_launch = [], []
         for b in picks:
             ids = list(range(b, ends[b]))
             run([b], timed=False, reset=True)               # prefix cache -> this block, untimed
             for mode in ("torch", "philox"):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                run(ids, timed=True, z_source=mode, reset=False, events=False)
+                # (the K1 launches of the torch leg carry their event pair: same instrumentation
+                # as the timed region's, it costs the loop nothing)
+                run(ids, timed=True, z_source=draws if mode == "torch" else mode, reset=False,
+                    events=(mode == "torch"))
                 torch.cuda.synchronize()
                 legs.setdefault(mode, []).append((len(ids), time.perf_counter() - t1))
+        parity_k1 = kern.summary(args.k1_form if args.k1_form in ("units", "block") else "units") \
+            if kern.unit_records else None
+        parity_lpl = kern.layers_per_launch
+        kern.unit_records, kern.layers_per_launch = main_records, main_lpl
+        draw_s = sum(a.elapsed_time(b_) for a, b_ in draws.pairs) * 1e-3
         n_l = sum(n for n, _ in legs["torch"])
         parity_mode = {
             "what": "z drawn as the reference does (torch.manual_seed(seed); torch.normal on the "
@@ -567,6 +601,35 @@ def main():
         }
         parity_mode["slowdown"] = (parity_mode["philox_same_layers_per_s"]
                                    / parity_mode["parity_mode_layers_per_s"])
+        if parity_k1:
+            parity_mode["roofline"] = {
+                "kernel": ("zo_perturb_layers_kernel<HAS_Z> (ecoflap_zo_perturb_layers_z: one launch "
+                           "per transformer block, every unit's z read from memory)"
+                           if args.k1_form == "block" else "zo_perturb_units_kernel<HAS_Z>"),
+                "bound": "hbm",
+                "achieved": parity_k1["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": parity_k1["gbs"] / HBM_PEAK_GBS,
+                "launches": parity_k1["launches"], "avg_launch_us": parity_k1["avg_us"],
+                "layers_per_launch": parity_lpl,
+                "algorithmic_bytes_per_launch": parity_k1["bytes_per_launch"],
+                "bytes_rule": "sum over the launch's layers of (3*U+2)*s*numel: read W once, per unit "
+                              "read z and write theta+/theta-, write the drifted W",
+                "timing": "kernel begin/end timestamps in HIP events attached to the launch",
+                "per_launch": parity_k1["per_launch"],
+                # producing z is torch.normal's work (library kernels, as in the reference): one
+                # write of s*numel per unit, outside K1; timed by a torch event pair per draw
+                "z_draws": {"count": len(draws.pairs), "bytes_written": draws.bytes,
+                            "seconds": draw_s,
+                            "gbs": (draws.bytes / draw_s / 1e9) if draw_s > 0 else None,
+                            "frac_of_peak": (draws.bytes / draw_s / 1e9 / HBM_PEAK_GBS) if draw_s > 0 else None},
+                # K1 + the draws together against the bytes both move
+                "k1_plus_draws": {
+                    "bytes": parity_k1["bytes_per_launch"] * parity_k1["launches"] + draws.bytes,
+                    "seconds": parity_k1["avg_us"] * parity_k1["launches"] * 1e-6 + draw_s,
+                    "frac_of_peak": ((parity_k1["bytes_per_launch"] * parity_k1["launches"] + draws.bytes)
+                                     / (parity_k1["avg_us"] * parity_k1["launches"] * 1e-6 + draw_s)
+                                     / 1e9 / HBM_PEAK_GBS) if draw_s > 0 else None},
+            }
 
     kind = args.k1_form
     k1 = kern.summary(kind)

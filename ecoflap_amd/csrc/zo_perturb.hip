@@ -417,18 +417,26 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_units_kernel(void* 
 // once per matrix.  Device table, one row of ECO_LAYER_ROW int64 per layer:
 //   [0] w_in  [1] w_final  [2] numel  [3] n_units  [4] first super-row of the layer in the launch
 //   [5 .. 5+U) seeds   [5+U .. 5+2U) theta+ pointers   [5+2U .. 5+3U) theta- pointers   (U = MAX_UNITS)
+// The parity form (HAS_Z: z drawn by the caller as the reference draws it, torch.manual_seed +
+// torch.normal per unit, read from memory here) carries one more column,
+//   [5+3U .. 5+4U) z pointers,
+// and runs the generic three-rounding update (a supplied z is not known to be safe for the
+// shortcuts of the in-register path).  Algorithmic bytes: (3*U_owned' + 2) * s per element with
+// U_owned' = owned units, plus s per element for each NOT-owned unit's z (drift needs it too).
 #define ECO_LAYER_ROW (5 + 3 * ECOFLAP_MAX_UNITS)
+#define ECO_LAYER_ROW_Z (5 + 4 * ECOFLAP_MAX_UNITS)
 
-template <int DT>
+template <int DT, bool HAS_Z>
 __global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_layers_kernel(
     const int64_t* __restrict__ table, int n_layers, int64_t total_rows, float eps) {
     constexpr int N = Vec<DT>::N;
+    constexpr int ROW = HAS_Z ? ECO_LAYER_ROW_Z : ECO_LAYER_ROW;
     const int64_t per = (int64_t)(gridDim.x / ECO_XCDS);
     const int64_t Rg = (int64_t)(blockIdx.x % ECO_XCDS) * per + blockIdx.x / ECO_XCDS;
     if (Rg >= total_rows) return;
     int l = 0;                                     // wave-uniform scan: scalar loads
-    while (l + 1 < n_layers && Rg >= table[(int64_t)(l + 1) * ECO_LAYER_ROW + 4]) ++l;
-    const int64_t* __restrict__ row = table + (int64_t)l * ECO_LAYER_ROW;
+    while (l + 1 < n_layers && Rg >= table[(int64_t)(l + 1) * ROW + 4]) ++l;
+    const int64_t* __restrict__ row = table + (int64_t)l * ROW;
     const void* win = (const void*)row[0];
     void* wout = (void*)row[1];
     const int64_t n = row[2];
@@ -438,12 +446,16 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_layers_kernel(
     const LaneVecs L = lane_vecs(R, nvec);
     u32x4 s0 = ld16_if(L.ok0, win, L.v0), s1 = ld16_if(L.ok1, win, L.v1);
     for (int u = 0; u < n_units; ++u) {
-        const uint64_t seed = (uint64_t)row[5 + u];
         float z[2 * N];
-        gen_z_lane<DT>(L.v0, (uint32_t)seed, (uint32_t)(seed >> 32), z);
+        if constexpr (HAS_Z) {
+            load_z_lane<DT>((const void*)row[5 + 3 * ECOFLAP_MAX_UNITS + u], L, z);
+        } else {
+            const uint64_t seed = (uint64_t)row[5 + u];
+            gen_z_lane<DT>(L.v0, (uint32_t)seed, (uint32_t)(seed >> 32), z);
+        }
         u32x4 p0, m0, p1, m1;
-        unit_update<DT, true>(s0, z, eps, p0, m0);
-        unit_update<DT, true>(s1, z + N, eps, p1, m1);
+        unit_update<DT, !HAS_Z>(s0, z, eps, p0, m0);
+        unit_update<DT, !HAS_Z>(s1, z + N, eps, p1, m1);
         void* dp = (void*)row[5 + ECOFLAP_MAX_UNITS + u];
         if (dp) {   // wave-uniform: not-owned units only carry the drift
             void* dm = (void*)row[5 + 2 * ECOFLAP_MAX_UNITS + u];
@@ -464,8 +476,13 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_perturb_layers_kernel(
         const int64_t e = tail0 + threadIdx.x;
         float a = Vec<DT>::load1(win, e);
         for (int u = 0; u < n_units; ++u) {
-            const uint64_t seed = (uint64_t)row[5 + u];
-            const float z = gen_z1<DT>(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+            float z;
+            if constexpr (HAS_Z) {
+                z = Vec<DT>::load1((const void*)row[5 + 3 * ECOFLAP_MAX_UNITS + u], e);
+            } else {
+                const uint64_t seed = (uint64_t)row[5 + u];
+                z = gen_z1<DT>(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+            }
             a = k1_step<DT>(a, z, 1.0f, eps);
             const float b = k1_step<DT>(a, z, -2.0f, eps);
             void* dp = (void*)row[5 + ECOFLAP_MAX_UNITS + u];
@@ -655,9 +672,9 @@ extern "C" int ecoflap_zo_perturb_units_timed(void* w, int64_t n, int dtype, flo
                                  (hipEvent_t)start_event, (hipEvent_t)stop_event);
 }
 
-extern "C" int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int64_t total_rows,
-                                         int dtype, float zo_eps, void* stream,
-                                         void* start_event, void* stop_event) {
+template <bool HAS_Z>
+static int zo_perturb_layers_impl(const int64_t* table, int n_layers, int64_t total_rows, int dtype,
+                                  float zo_eps, void* stream, void* start_event, void* stop_event) {
     if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
     if (n_layers < 0 || total_rows < 0 || total_rows > 0x7ffffff0LL) return ECOFLAP_ESIZE;
     if (n_layers == 0 || total_rows == 0) return 0;
@@ -666,12 +683,26 @@ extern "C" int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)((total_rows + ECO_XCDS - 1) / ECO_XCDS * ECO_XCDS);
     DISPATCH_DT(dtype, {
-        hipExtLaunchKernelGGL((zo_perturb_layers_kernel<DT>), dim3(g), dim3(ECO_K1_THREADS), 0, s,
+        hipExtLaunchKernelGGL((zo_perturb_layers_kernel<DT, HAS_Z>), dim3(g), dim3(ECO_K1_THREADS), 0, s,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, table, n_layers,
                               total_rows, zo_eps);
     });
     ECO_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int64_t total_rows,
+                                         int dtype, float zo_eps, void* stream,
+                                         void* start_event, void* stop_event) {
+    return zo_perturb_layers_impl<false>(table, n_layers, total_rows, dtype, zo_eps, stream,
+                                         start_event, stop_event);
+}
+
+extern "C" int ecoflap_zo_perturb_layers_z(const int64_t* table, int n_layers, int64_t total_rows,
+                                           int dtype, float zo_eps, void* stream,
+                                           void* start_event, void* stop_event) {
+    return zo_perturb_layers_impl<true>(table, n_layers, total_rows, dtype, zo_eps, stream,
+                                        start_event, stop_event);
 }
 
 // An empty launch through the same instrumented path: what the event pair of

@@ -21,6 +21,7 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
     "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
+    "ecoflap_zo_perturb_layers_z",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_absprod_reduce_mixed", "ecoflap_colsqnorm_workspace_bytes",
@@ -87,6 +88,7 @@ def load_library():
     lib.ecoflap_zo_perturb_units_timed.argtypes = [vp, i64, ci, f32, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.ecoflap_null_launch_timed.argtypes = [vp, vp, vp]
     lib.ecoflap_zo_perturb_layers.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
+    lib.ecoflap_zo_perturb_layers_z.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
@@ -269,14 +271,21 @@ class HipKernels:
                 minus_a, z_a, _stream()), "ecoflap_zo_perturb_units")
 
     def zo_perturb_layers(self, layers, zo_eps, events=None):
-        """Block-batched K1 (in-register z): layers = [(w_in, w_final, seeds, w_plus, w_minus)],
-        all of one dtype, each with at most MAX_UNITS units (None, None = drift only); one
-        launch for all of them, drifted weights into w_final (w_in is left untouched).
-        events: optional callable -> (start, stop) raw hipEvent_t handles."""
-        U, row_len = self.MAX_UNITS, 5 + 3 * self.MAX_UNITS
+        """Block-batched K1: layers = [(w_in, w_final, seeds, w_plus, w_minus)] (in-register z)
+        or [(w_in, w_final, seeds, w_plus, w_minus, zs)] (z supplied per unit: the parity mode),
+        all of one dtype and one of the two forms, each with at most MAX_UNITS units (None, None
+        = drift only); one launch for all of them, drifted weights into w_final (w_in is left
+        untouched).  events: optional callable -> (start, stop) raw hipEvent_t handles."""
+        has_z = len(layers[0]) > 5 and layers[0][5] is not None
+        U = self.MAX_UNITS
+        row_len = 5 + (4 if has_z else 3) * U
         dt = layers[0][0].dtype
         rows, total = [], 0
-        for w_in, w_final, seeds, w_plus, w_minus in layers:
+        for item in layers:
+            w_in, w_final, seeds, w_plus, w_minus = item[:5]
+            zs = item[5] if len(item) > 5 else None
+            if (zs is not None) != has_z:
+                raise EcoflapHipError("zo_perturb_layers: z for every layer of the launch or for none")
             _gpu(w_in, "w_in")
             _gpu(w_final, "w_final")
             n_units = len(seeds)
@@ -291,12 +300,21 @@ class HipKernels:
                     _gpu(t, "unit buffer")
                     if t.dtype != dt or t.numel() != w_in.numel():
                         raise EcoflapHipError("unit buffers must match w_in in dtype and numel")
+            if has_z:
+                if len(zs) != n_units:
+                    raise EcoflapHipError("zo_perturb_layers: one z per unit")
+                for z in zs:
+                    _gpu(z, "z")
+                    if z.dtype != dt or z.numel() != w_in.numel() or z.data_ptr() % 16:
+                        raise EcoflapHipError("z must match w_in in dtype and numel, 16-byte aligned")
             per_vec = 16 // w_in.element_size()
             row = [w_in.data_ptr(), w_final.data_ptr(), w_in.numel(), n_units, total]
             row += [(int(x) & (2 ** 64 - 1)) - (2 ** 64 if (int(x) & (2 ** 63)) else 0) for x in seeds]
             row += [0] * (U - n_units)
             row += [t.data_ptr() if t is not None else 0 for t in w_plus] + [0] * (U - n_units)
             row += [t.data_ptr() if t is not None else 0 for t in w_minus] + [0] * (U - n_units)
+            if has_z:
+                row += [z.data_ptr() for z in zs] + [0] * (U - n_units)
             assert len(row) == row_len
             rows.append(row)
             total += max(1, -(-(w_in.numel() // per_vec) // 128))
@@ -306,9 +324,10 @@ class HipKernels:
         table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(layers[0][0].device,
                                                                       non_blocking=True)
         ev = events() if events is not None else (None, None)
-        _check(self.lib.ecoflap_zo_perturb_layers(_ptr(table), len(rows), total, DTYPE_CODE[dt],
-                                                  float(zo_eps), _stream(), ev[0], ev[1]),
-               "ecoflap_zo_perturb_layers")
+        fn = self.lib.ecoflap_zo_perturb_layers_z if has_z else self.lib.ecoflap_zo_perturb_layers
+        _check(fn(_ptr(table), len(rows), total, DTYPE_CODE[dt], float(zo_eps), _stream(),
+                  ev[0], ev[1]),
+               "ecoflap_zo_perturb_layers_z" if has_z else "ecoflap_zo_perturb_layers")
 
     def zo_fill_normal(self, z_out, seed):
         _gpu(z_out, "z_out")

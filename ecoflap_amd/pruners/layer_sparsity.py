@@ -260,7 +260,7 @@ class LayerSparsity:
         # "block": consecutive layers owned by the same stage of the forward share one K1 launch
         groups, stash = {}, {}
         stage_of = getattr(self.loss_func, "stage_of", None)
-        if (self.k1_form == "block" and self.z_source == "philox" and stage_of is not None
+        if (self.k1_form == "block" and stage_of is not None
                 and hasattr(self.kernels, "zo_perturb_layers")):
             start = 0
             for li in range(1, len(names) + 1):
@@ -293,8 +293,15 @@ class LayerSparsity:
                         kk += int(mine)
                     fin = torch.empty_like(g_home)
                     stash[g] = (plus, minus, fin, scr)
-                    batch.append((g_home, fin, [units[u][3] for u in g_units], plus, minus))
+                    item = (g_home, fin, [units[u][3] for u in g_units], plus, minus)
+                    if self.z_source != "philox":
+                        # parity mode: every unit's z drawn as the reference draws it (each draw
+                        # re-seeds, :482-485, so drawing the block's layers ahead of their turn
+                        # changes no value); not-owned units need theirs for the drift
+                        item += ([self._draw_z(units[u][3], params[g]) for u in g_units],)
+                    batch.append(item)
                 self.kernels.zo_perturb_layers(batch, zo_eps)
+                del batch, item
             if self.k1_form in ("units", "block"):
                 # one launch: theta+/theta- of every owned unit into scratch, final drifted theta
                 # back into the parameter's own storage; then only forwards remain

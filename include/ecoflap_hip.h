@@ -140,6 +140,17 @@ int ecoflap_zo_perturb_layers(const int64_t* table, int n_layers, int64_t total_
                               int dtype, float zo_eps, void* stream,
                               void* start_event, void* stop_event);
 
+/* The same with z SUPPLIED per unit (parity mode: the caller draws each unit's z as the
+ * reference does, torch.manual_seed(seed) + torch.normal on the device,
+ * layer_single_base_pruner.py:482-485, for every layer of the block up front — each draw
+ * re-seeds, so the order of the draws does not matter).  Rows are [5 + 4*ECOFLAP_MAX_UNITS] wide:
+ * the row above followed by z[MAX_UNITS] (device pointers to tensors of the layer's numel and
+ * dtype, 16-byte aligned, non-NULL for every unit, owned or not: the drift needs them too);
+ * seeds are ignored.  Bit-identical to one ecoflap_zo_perturb_units call with z per layer. */
+int ecoflap_zo_perturb_layers_z(const int64_t* table, int n_layers, int64_t total_rows,
+                                int dtype, float zo_eps, void* stream,
+                                void* start_event, void* stop_event);
+
 /* An empty kernel through the same instrumented launch: the floor of that event pair. */
 int ecoflap_null_launch_timed(void* stream, void* start_event, void* stop_event);
 

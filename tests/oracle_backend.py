@@ -49,6 +49,23 @@ class OracleKernels:
                 w_minus[u].copy_(minus)
         w.copy_(cur)
 
+    MAX_UNITS = 32
+
+    def zo_perturb_layers(self, layers, zo_eps, events=None):
+        """Block-batched K1: per layer the unit chain from w_in, theta+ / theta- into the unit
+        buffers, the drifted weights into w_final (w_in untouched)."""
+        for item in layers:
+            w_in, w_final, seeds, w_plus, w_minus = item[:5]
+            zs = item[5] if len(item) > 5 else None
+            cur = self._host(w_in).clone()
+            for u, seed in enumerate(seeds):
+                zz = self._z(zs[u] if zs is not None else None, seed, w_in)
+                plus, minus, cur = self.o.zo_perturb_triple(cur, float(zo_eps), zz)
+                if w_plus[u] is not None:
+                    w_plus[u].copy_(plus)
+                    w_minus[u].copy_(minus)
+            w_final.copy_(cur)
+
     def absprod_reduce(self, w, g, mode, out_accum):
         v = self.o.absprod_reduce(self._host(w) if w is not None else None,
                                   self._host(g) if g is not None else None, mode)

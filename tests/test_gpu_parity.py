@@ -119,6 +119,43 @@ def test_k1_block_batched_equals_per_layer_launches(kern, dt):
                 assert torch.equal(plus[u], rp[u]) and torch.equal(minus[u], rm[u]), u
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_k1_block_batched_with_supplied_z_equals_oracle(kern, oracle, dt):
+    """ecoflap_zo_perturb_layers_z (parity mode: every unit's z read from memory, one launch per
+    transformer block) == the oracle's three-rounding chain on the same z, and == one
+    ecoflap_zo_perturb_units call with z per layer, bit for bit; ragged sizes, drift-only units."""
+    torch.manual_seed(23)
+    sizes = [(2048 * 96, 5), (5, 3), (4099, 7), (128 * 8 * 3 + 11, 16), (1023, 32)]
+    layers, refs = [], []
+    for li, (n, n_units) in enumerate(sizes):
+        w0 = (torch.randn(n, device="cuda") * 0.05).to(dt)
+        seeds = list(range(n_units))
+        owned = [(u + li) % 3 != 1 for u in range(n_units)]
+        zs = [torch.randn(n, device="cuda").to(dt) for _ in range(n_units)]
+        mk = lambda: [torch.empty(n, dtype=dt, device="cuda") if o else None for o in owned]   # noqa: E731
+        plus, minus, fin = mk(), mk(), torch.empty_like(w0)
+        layers.append((w0, fin, seeds, plus, minus, zs))
+        w_ref = w0.clone()
+        rp, rm = mk(), mk()
+        kern.zo_perturb_units(w_ref, 1e-3, seeds, rp, rm, zs)
+        cur = w0.cpu()
+        chain = []
+        for u in range(n_units):
+            p_, m_, cur = oracle.zo_perturb_triple(cur, 1e-3, zs[u].cpu())
+            chain.append((p_, m_))
+        refs.append((w0.clone(), w_ref, rp, rm, owned, chain, cur))
+    kern.zo_perturb_layers(layers, 1e-3)
+    for (w_in, fin, _, plus, minus, _z), (w_orig, w_ref, rp, rm, owned, chain, last) in zip(layers, refs):
+        assert torch.equal(w_in, w_orig)                       # originals untouched
+        assert torch.equal(fin, w_ref) and torch.equal(fin.cpu(), last)
+        for u, o in enumerate(owned):
+            if o:
+                assert torch.equal(plus[u], rp[u]) and torch.equal(minus[u], rm[u]), u
+                assert torch.equal(plus[u].cpu(), chain[u][0]) and torch.equal(minus[u].cpu(), chain[u][1]), u
+    with pytest.raises(Exception):                             # z for every layer or for none
+        kern.zo_perturb_layers([layers[0], layers[1][:5]], 1e-3)
+
+
 def test_stage1_block_batched_k1_equals_per_layer(kern):
     """k1_form="block" (one K1 launch per transformer block, drifted weights parked until each
     layer's turn is over) == "units": loss table, sparsity table, drifted weights — through the
@@ -130,7 +167,7 @@ def test_stage1_block_batched_k1_equals_per_layer(kern):
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_toy
 
-    def run(form, cached):
+    def run(form, cached, z_source="philox"):
         torch.manual_seed(0)
         model = blip2_toy(fp32=False).eval().to("cuda")
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
@@ -142,7 +179,7 @@ def test_stage1_block_batched_k1_equals_per_layer(kern):
                 if cached else loss_vision_language)
         np.random.seed(3)
         ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
-                           kernels=kern, z_source="philox", k1_form=form)
+                           kernels=kern, z_source=z_source, k1_form=form)
         sp = ls.return_sparsity()
         return ls.loss_table.copy(), sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}
 
@@ -152,6 +189,11 @@ def test_stage1_block_batched_k1_equals_per_layer(kern):
         assert a[1] == b[1]
         for k in a[2]:
             assert torch.equal(a[2][k], b[2][k]), k
+    # the same with the reference's draws (z materialised: ecoflap_zo_perturb_layers_z)
+    a, b = run("units", True, "torch"), run("block", True, "torch")
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
 
 
 @pytest.mark.parametrize("dt", DTYPES)

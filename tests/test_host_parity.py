@@ -108,9 +108,19 @@ def test_prefix_cached_loss_is_exact(golden_dir, tag, method, num_noise, num_sam
         np.random.seed(int(g[key + "_cfg"][0]))
         if cached:
             loss_fn = PrefixCachedLoss(model, kind="vision" if tag == "vit" else "vision_language")
+        # cached: also the block-batched K1 with SUPPLIED z (the entrypoints' default): every
+        # matrix of a transformer block perturbed ahead of its turn, drifted weights parked
         ls = LayerSparsity(model, batches, loss_fn, num_samples, 0.5, 0.6, method, num_noise,
-                           1e-3, mapping, kernels=OracleKernels(), z_source=torch_cpu_normal)
+                           1e-3, mapping, kernels=OracleKernels(), z_source=torch_cpu_normal,
+                           k1_form="block" if cached else "units")
+        if cached:
+            calls = []
+            real = ls.kernels.zo_perturb_layers
+            ls.kernels.zo_perturb_layers = lambda layers, eps, events=None: (
+                calls.append([len(it) for it in layers]), real(layers, eps, events))[1]
         sp = ls.return_sparsity()
+        if cached:                                      # one launch per block, z for every layer
+            assert calls and all(n == 6 for c in calls for n in c) and max(len(c) for c in calls) >= 4
         tables.append(ls.loss_table.copy())
         assert np.array_equal(np.array([sp[k] for k in names]), g[key + "_sparsity"])
         sd = model.state_dict()
