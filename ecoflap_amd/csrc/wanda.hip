@@ -638,13 +638,83 @@ static __device__ __forceinline__ uint32_t block_max4(uint32_t wave_value, uint3
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(a > b ? a : b));
 }
 
+// ---- the k-th smallest by ONE histogram pass instead of a bisection (round 4) --------------
+// profiles/r04_secondary/k7_rows_phases.md: of the ~41 VALU instructions per element of the
+// bisection form, ~21 were the bisection itself (71 per probe and lane, 9-14 probes), 5 the
+// compaction, 3 the low bits.  Here the top of the search costs 3 VALU + one LDS atomic per
+// element: the metrics' bit patterns are binned RELATIVE TO THE ROW MAXIMUM,
+//     bin = sat_sub(m, mx - (2^28 - 1)) >> 18          (1024 bins of 2^18 codes = 1/32 octave,
+//                                                        32 octaves below the maximum; what lies
+//                                                        further down shares bin 0)
+// into an LDS histogram (ds_add_u32), the bin holding the k-th smallest is found by one scan
+// (16 bins per lane + a wave prefix), and only that bin's elements (a few dozen of a 2048- or
+// 5120-wide row) go on to the 18 low-bit rounds.  Exact: the bins partition the values in
+// order, every count is a count of elements.  A bin with more than RH_CAND elements (massive
+// ties) or a k-th smallest in the shared bin 0 takes the generic bit-by-bit search over all
+// elements.
+#define RH_BINS 1024
+#define RH_SHIFT 18
+#define RH_SPAN ((1u << 28) - 1u)         // RH_BINS << RH_SHIFT, minus one
+#define RH_CAND 128                        // candidates one wave finishes (two per lane)
+
+static __device__ __forceinline__ uint32_t rh_lowbound(uint32_t mx) { return mx > RH_SPAN ? mx - RH_SPAN : 0u; }
+static __device__ __forceinline__ uint32_t rh_bin(uint32_t m, uint32_t lowbound) {
+    return __builtin_elementwise_sub_sat(m, lowbound) >> RH_SHIFT;
+}
+// wave-wide inclusive prefix sum on the DPP network; `total` = the wave's sum (uniform)
+static __device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, uint32_t& total) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+    total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return v;
+}
+// One wave scans the RH_BINS counters (lane l: bins [16 l, 16 l + 16)): the bin holding the k-th
+// smallest (1-indexed), the number of elements in lower bins, and that bin's population — all
+// wave-uniform.  The counters sum to >= k.
+static __device__ __forceinline__ void rh_find(const uint32_t* hist, uint32_t k, int lane, uint32_t& bin,
+                                               uint32_t& less_below, uint32_t& ncand) {
+    constexpr int PER = RH_BINS / 64;
+    uint32_t c[PER];
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+        const u32x4 v = ((const u32x4*)hist)[lane * (PER / 4) + q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
+    }
+#pragma unroll
+    for (int j = 1; j < PER; ++j) c[j] += c[j - 1];               // local inclusive sums
+    uint32_t total;
+    const uint32_t incl = wave_scan_dpp(c[PER - 1], total);
+    const uint32_t P = incl - c[PER - 1];                        // elements in the lanes before
+    const int32_t kk = (int32_t)k - (int32_t)P;                  // <= 0: the bin lies in an earlier lane
+    uint32_t cnt = 0, below = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const bool lt = (int32_t)c[j] < kk;
+        cnt += lt ? 1u : 0u;
+        below = lt ? c[j] : below;
+    }
+    const uint64_t has = __ballot(incl >= k);                    // first lane whose range reaches k
+    const int L = __builtin_ctzll(has);
+    const uint32_t cntL = (uint32_t)__builtin_amdgcn_readlane((int)cnt, L);
+    bin = (uint32_t)L * PER + cntL;
+    less_below = (uint32_t)__builtin_amdgcn_readlane((int)(P + below), L);
+    ncand = hist[bin];                                           // uniform address: broadcast read
+    ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
+}
+
 // One 256-thread workgroup per row (rows beyond the wave form's reach, and the long rows of a
 // block whose short rows run in the wave form): the same search — bisection over the packed high
 // halves, then the compacted bucket — with the per-probe count summed over the four waves through
 // LDS (one barrier per probe).
-template <int DT, int NV>
+template <int DT, int NV, bool HIST>
 static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t grow, uint32_t* lds8,
-                                                     uint32_t* wave4, uint32_t* cand_lds, uint32_t* res3) {
+                                                     uint32_t* wave4, uint32_t* cand_lds, uint32_t* res3,
+                                                     uint32_t* hist) {
     constexpr int N = Vec<DT>::N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -660,6 +730,12 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
 #pragma unroll
     for (int j = 0; j < NV; ++j)
         if (tid + 256 * j < nvec) wv[j] = ld16(wrow, tid + 256 * j);
+    if constexpr (HIST) {                      // the row's histogram (+ the candidate counter behind it)
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        static_assert(RH_BINS == 1024, "one 16-byte clear per thread");
+        ((u32x4*)hist)[tid] = zero;
+        if (tid == 0) hist[RH_BINS] = 0u;
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = tid + 256 * j;
@@ -694,10 +770,33 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
             const uint32_t o = __shfl_xor(mx, off, 64);
             mx = o > mx ? o : mx;
         }
+        // (the barrier inside also orders the histogram's clears before the adds below)
         mx = block_max4((uint32_t)__builtin_amdgcn_readfirstlane((int)mx), lds8, phase++, wave, lane);
-        const int top = mx ? 31 - __builtin_clz(mx) : -1;
-        uint32_t prefix, less16, ncand;
-        {
+        uint32_t lo, less_below, ncand;        // the interval [lo, lo + 2^bits) holding the k-th smallest
+        int bits;
+        bool crowded;
+        if constexpr (HIST) {
+            const uint32_t lowbound = rh_lowbound(mx);
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (tid + 256 * j < nvec) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        __hip_atomic_fetch_add(&hist[rh_bin(m[j][i], lowbound)], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            __syncthreads();
+            // every wave scans the counters for itself: the same uniform result in all four,
+            // no second barrier to hand it round
+            uint32_t bin;
+            rh_find(hist, (uint32_t)k, lane, bin, less_below, ncand);
+            if (bin == 0 && lowbound > 0) {
+                lo = 0; bits = 32; less_below = 0; crowded = true;
+            } else {
+                lo = lowbound + (bin << RH_SHIFT); bits = RH_SHIFT; crowded = ncand > RH_CAND;
+            }
+        } else {
+            const int top = mx ? 31 - __builtin_clz(mx) : -1;
             constexpr int WH = NV * N / 2;
             constexpr uint32_t ALL = 256 * NV * N;
             uint32_t xh[WH], xg[WH];
@@ -705,62 +804,81 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
 #pragma unroll
             for (int w = 0; w < WH; ++w) xg[w] = xh[w] | 0x80008000u;
             const uint32_t mx16 = mx >> 16;
-            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
-            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
+            uint32_t blo = 0, flo = 0, bhi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { bhi = mx16 + 1; fhi = (uint32_t)cols; }
+            while (bhi - blo > 1) {
+                const uint32_t mid = (blo + bhi) >> 1;
                 const uint32_t fm = ALL - block_sum4(wave_count_hi16_ge<WH, true>(xh, xg, mid), lds8, phase++, wave, lane);
-                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+                if (fm < (uint32_t)k) { blo = mid; flo = fm; } else { bhi = mid; fhi = fm; }
             }
-            prefix = lo << 16;
-            less16 = flo;
+            lo = blo << 16;
+            less_below = flo;
             ncand = fhi - flo;
+            bits = (top < 15 ? top : 15) + 1;
+            crowded = ncand > RH_CAND;
         }
-        if (ncand <= 128) {                               // block-uniform
-            // compact the bucket's elements; ONE wave finishes the low 16 bits on them with
-            // ballots — 16 rounds without a block barrier or a pass over the registers
-            uint32_t mine = 0;
-#pragma unroll
-            for (int j = 0; j < NV; ++j)
-#pragma unroll
-                for (int i = 0; i < N; ++i) mine += ((m[j][i] ^ prefix) < 0x10000u) ? 1u : 0u;
-            uint32_t total;
-            uint32_t pos = block_scan_256(mine, wave4, total) - mine;
-            if (mine) {
+        if (!crowded) {                                   // block-uniform
+            // compact the interval's elements; ONE wave finishes the low bits on them with
+            // ballots — `bits` rounds without a block barrier or a pass over the registers
+            const uint32_t span = 1u << bits;
+            if constexpr (HIST) {
+                // order among the candidates does not matter: a counter hands out the slots
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if ((m[j][i] ^ prefix) < 0x10000u) cand_lds[pos++] = m[j][i];
+                    for (int i = 0; i < N; ++i) {
+                        const uint32_t rel = m[j][i] - lo;
+                        if (rel < span) {
+                            const uint32_t p_ = __hip_atomic_fetch_add(&hist[RH_BINS], 1u, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            cand_lds[p_] = rel;
+                        }
+                    }
+            } else {
+                uint32_t mine = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) mine += ((m[j][i] - lo) < span) ? 1u : 0u;
+                uint32_t total;
+                uint32_t pos = block_scan_256(mine, wave4, total) - mine;
+                if (mine) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            if ((m[j][i] - lo) < span) cand_lds[pos++] = m[j][i] - lo;
+                }
             }
             __syncthreads();
             if (wave == 0) {
                 const bool v0 = (uint32_t)lane < ncand, v1 = (uint32_t)lane + 64 < ncand;
                 const uint32_t c0 = v0 ? cand_lds[lane] : 0u, c1 = v1 ? cand_lds[lane + 64] : 0u;
-                for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
-                    const uint32_t cand = prefix | (1u << bit);
-                    const uint32_t c = less16 + (uint32_t)__popcll(__ballot(v0 && c0 < cand)) +
+                uint32_t off = 0;
+                for (int bit = bits - 1; bit >= 0; --bit) {
+                    const uint32_t cand = off | (1u << bit);
+                    const uint32_t c = less_below + (uint32_t)__popcll(__ballot(v0 && c0 < cand)) +
                                        (uint32_t)__popcll(__ballot(v1 && c1 < cand));
-                    if (c < (uint32_t)k) prefix = cand;
+                    if (c < (uint32_t)k) off = cand;
                 }
-                const uint32_t less = less16 + (uint32_t)__popcll(__ballot(v0 && c0 < prefix)) +
-                                      (uint32_t)__popcll(__ballot(v1 && c1 < prefix));
-                const uint32_t eq = (uint32_t)__popcll(__ballot(v0 && c0 == prefix)) +
-                                    (uint32_t)__popcll(__ballot(v1 && c1 == prefix));
-                if (lane == 0) { res3[0] = prefix; res3[1] = less; res3[2] = eq; }
+                const uint32_t less = less_below + (uint32_t)__popcll(__ballot(v0 && c0 < off)) +
+                                      (uint32_t)__popcll(__ballot(v1 && c1 < off));
+                const uint32_t eq = (uint32_t)__popcll(__ballot(v0 && c0 == off)) +
+                                    (uint32_t)__popcll(__ballot(v1 && c1 == off));
+                if (lane == 0) { res3[0] = lo + off; res3[1] = less; res3[2] = eq; }
             }
             __syncthreads();
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[0]);
             total_equal = (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[2]);
             take_equal = (uint32_t)k - (uint32_t)__builtin_amdgcn_readfirstlane((int)res3[1]);
-        } else {                                          // crowded bucket: all elements, bit by bit
-            uint32_t less = less16;
-            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
-                const uint32_t cand = prefix | (1u << bit);
+        } else {                                          // crowded interval: all elements, bit by bit
+            uint32_t less = less_below, off = 0;
+            for (int bit = bits - 1; bit >= 0; --bit) {
+                const uint32_t cand = lo + (off | (1u << bit));
                 const uint32_t c = block_sum4(wave_count_less(m, cand), lds8, phase++, wave, lane);
-                if (c < (uint32_t)k) { prefix = cand; less = c; }
+                if (c < (uint32_t)k) { off |= 1u << bit; less = c; }
             }
-            T = prefix;
+            T = lo + off;
             uint32_t eq = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -815,13 +933,14 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
     }
 }
 
-template <int DT, int NV>
+template <int DT, int NV, bool HIST>
 __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) {
     __shared__ uint32_t lds8[8];
     __shared__ uint32_t wave4[4];
-    __shared__ uint32_t cand_lds[128];
+    __shared__ uint32_t cand_lds[RH_CAND];
     __shared__ uint32_t res3[3];
-    rows_reg_body<DT, NV>(g, blockIdx.x, lds8, wave4, cand_lds, res3);
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HIST ? RH_BINS + 4 : 4];
+    rows_reg_body<DT, NV, HIST>(g, blockIdx.x, lds8, wave4, cand_lds, res3, hist);
 }
 
 // -------------------------------------------------------------------------------------
@@ -833,9 +952,10 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
 // all waves then load, search and store in phase and the memory and VALU phases stop overlapping
 // across waves; seeding the search from the previous row's threshold through a word in the
 // workspace — loads of many waves from one address serialise like atomics, ~30 ns each.)
-template <int DT, int NV>
+template <int DT, int NV, bool HIST>
 static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_t first_row,
-                                                      uint32_t (*cand_lds_all)[64 * 2]) {
+                                                      uint32_t (*cand_lds_all)[64 * 2],
+                                                      uint32_t (*hist_all)[RH_BINS]) {
     constexpr int N = Vec<DT>::N;
     const int lane = threadIdx.x & 63;
     // (the wave index is uniform, which the compiler cannot see through threadIdx: without the
@@ -856,6 +976,11 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
 #pragma unroll
     for (int j = 0; j < NV; ++j)
         if (lane + 64 * j < nvec) wv[j] = ld16(wrow, lane + 64 * j);
+    if constexpr (HIST) {                      // the wave's histogram, cleared while the loads fly
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < RH_BINS / 256; ++q) ((u32x4*)hist_all[wave])[lane + 64 * q] = zero;
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = lane + 64 * j;
@@ -877,11 +1002,12 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
     const bool all = (k >= cols);
     uint32_t T = 0xffffffffu, take_equal = 0, total_equal = 0;
     if (!all) {
-        // k-th smallest (1-indexed) = largest T with #(m < T) < k.  Its high 16 bits come from a
-        // bisection over the packed high halves; then only the elements that share them
-        // (typically ~1 % of a row: sign + exponent + 7 mantissa bits) can still change a count —
-        // they are compacted to at most two per lane, and the 16 low bits are found bit by bit
-        // with 2 ballots per round instead of a pass over the row.
+        // k-th smallest (1-indexed) = largest T with #(m < T) < k.  First an interval
+        // [lo, lo + 2^bits) that holds it, with the number of elements below it — from the
+        // histogram of the metrics relative to the row maximum (HIST) or from a bisection over the
+        // packed high halves —; then only the elements inside the interval (typically ~1 % of a
+        // row) can still change a count: they are compacted to at most two per lane and the low
+        // bits are found bit by bit with 2 ballots per round instead of a pass over the row.
         uint32_t mx = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -895,9 +1021,31 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
             mx = o > mx ? o : mx;
         }
         mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);      // uniform: scalar loop control
-        const int top = mx ? 31 - __builtin_clz(mx) : -1;
-        uint32_t prefix, less16, ncand;        // less16 = #(m < prefix), ncand = population of the 16-bit bucket
-        {
+        uint32_t lo, less_below, ncand;        // less_below = #(m < lo), ncand = population of the interval
+        int bits;
+        bool crowded;
+        if constexpr (HIST) {
+            uint32_t* hist = hist_all[wave];
+            const uint32_t lowbound = rh_lowbound(mx);
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (lane + 64 * j < nvec) {      // (padding must not be binned: it lies above mx)
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        __hip_atomic_fetch_add(&hist[rh_bin(m[j][i], lowbound)], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            // (one wave's LDS operations are performed in issue order: the clears above, these
+            // adds and the reads of the scan need no barrier between them)
+            uint32_t bin;
+            rh_find(hist, (uint32_t)k, lane, bin, less_below, ncand);
+            if (bin == 0 && lowbound > 0) {      // k-th smallest more than 32 octaves below the maximum
+                lo = 0; bits = 32; less_below = 0; crowded = true;
+            } else {
+                lo = lowbound + (bin << RH_SHIFT); bits = RH_SHIFT; crowded = ncand > RH_CAND;
+            }
+        } else {
+            const int top = mx ? 31 - __builtin_clz(mx) : -1;
             constexpr int WH = NV * N / 2;
             constexpr bool KEEPG = NV <= 4;
             constexpr uint32_t ALL = 64 * NV * N;              // padding (0xffff....) is never "less"
@@ -910,29 +1058,33 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
             // f(c) = #(hi16(m) < c) is monotone; wanted: p16 = max{c : f(c) < k}.  Bisection on
             // [lo, hi] with f(lo) < k <= f(hi); the last two values give the bucket's population
             const uint32_t mx16 = mx >> 16;
-            uint32_t lo = 0, flo = 0, hi = 65536u, fhi = ALL;
-            if (mx16 < 0xffffu) { hi = mx16 + 1; fhi = (uint32_t)cols; }   // every real element is below
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
+            uint32_t blo = 0, flo = 0, bhi = 65536u, fhi = ALL;
+            if (mx16 < 0xffffu) { bhi = mx16 + 1; fhi = (uint32_t)cols; }   // every real element is below
+            while (bhi - blo > 1) {
+                const uint32_t mid = (blo + bhi) >> 1;
                 const uint32_t fm = ALL - wave_count_hi16_ge<WH, KEEPG>(xh, xg, mid);
-                if (fm < (uint32_t)k) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+                if (fm < (uint32_t)k) { blo = mid; flo = fm; } else { bhi = mid; fhi = fm; }
             }
-            prefix = lo << 16;
-            less16 = flo;
+            lo = blo << 16;
+            less_below = flo;
             ncand = fhi - flo;
+            bits = (top < 15 ? top : 15) + 1;
+            crowded = ncand > RH_CAND;
         }
-        constexpr uint32_t CMAX = 2;             // candidates per lane
-        if (ncand <= 64 * CMAX) {                // wave-uniform
+        constexpr uint32_t CMAX = 2;             // candidates per lane (RH_CAND = 64 * CMAX)
+        if (!crowded) {                          // wave-uniform
+            const uint32_t span = 1u << bits;    // (bits <= 18 here)
             uint32_t pos = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const bool hit = (m[j][i] ^ prefix) < 0x10000u;
+                    const uint32_t rel = m[j][i] - lo;
+                    const bool hit = rel < span;
                     const uint64_t mask = __ballot(hit);
                     if (mask) {                  // wave-uniform: most element slots have no candidate
                         if (hit) cand_lds[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = m[j][i];
+                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = rel;
                         pos += (uint32_t)__popcll(mask);
                     }
                 }
@@ -945,29 +1097,30 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
                 cv[c] = lane + 64 * c < ncand;
                 cr[c] = cv[c] ? cand_lds[lane + 64 * c] : 0u;
             }
-            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
-                const uint32_t cand = prefix | (1u << bit);
-                uint32_t c = less16;
+            uint32_t off = 0;                    // T = lo + off
+            for (int bit = bits - 1; bit >= 0; --bit) {
+                const uint32_t cand = off | (1u << bit);
+                uint32_t c = less_below;
 #pragma unroll
                 for (uint32_t q = 0; q < CMAX; ++q) c += (uint32_t)__popcll(__ballot(cv[q] && cr[q] < cand));
-                if (c < (uint32_t)k) prefix = cand;
+                if (c < (uint32_t)k) off = cand;
             }
-            T = prefix;
-            uint32_t less = less16;
+            T = lo + off;
+            uint32_t less = less_below;
 #pragma unroll
             for (uint32_t q = 0; q < CMAX; ++q) {
-                less += (uint32_t)__popcll(__ballot(cv[q] && cr[q] < T));
-                total_equal += (uint32_t)__popcll(__ballot(cv[q] && cr[q] == T));
+                less += (uint32_t)__popcll(__ballot(cv[q] && cr[q] < off));
+                total_equal += (uint32_t)__popcll(__ballot(cv[q] && cr[q] == off));
             }
             take_equal = (uint32_t)k - less;
-        } else {                                 // crowded bucket (few distinct values): all elements
-            uint32_t less = less16;
-            for (int bit = (top < 15 ? top : 15); bit >= 0; --bit) {
-                const uint32_t cand = prefix | (1u << bit);
+        } else {                                 // crowded interval (few distinct values): all elements
+            uint32_t less = less_below, off = 0;
+            for (int bit = bits - 1; bit >= 0; --bit) {
+                const uint32_t cand = lo + (off | (1u << bit));
                 const uint32_t c = wave_count_less(m, cand);
-                if (c < (uint32_t)k) { prefix = cand; less = c; }
+                if (c < (uint32_t)k) { off |= 1u << bit; less = c; }
             }
-            T = prefix;
+            T = lo + off;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -1025,10 +1178,11 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
     }
 }
 
-template <int DT, int NV>
+template <int DT, int NV, bool HIST>
 __global__ __launch_bounds__(256, 4) void wanda_rows_wave_kernel(const RowsGroup g) {
     __shared__ uint32_t cand_lds_all[4][64 * 2];
-    rows_wave_body<DT, NV>(g, (int64_t)blockIdx.x * 4, cand_lds_all);
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[HIST ? 4 : 1][RH_BINS];
+    rows_wave_body<DT, NV, HIST>(g, (int64_t)blockIdx.x * 4, cand_lds_all, hist_all);
 }
 
 // A block's short rows (wave form) and long rows (workgroup form) in ONE grid: the long rows of a
@@ -1036,17 +1190,20 @@ __global__ __launch_bounds__(256, 4) void wanda_rows_wave_kernel(const RowsGroup
 // (measured: 33 us for 22 % of the block's bytes, after the 58 us of the other 78 %), and launches
 // on one stream do not overlap; side streams joined by events cost more than they gave.  The
 // long-row workgroups come first in the grid so that they are not the tail.
-template <int DT, int NVW, int NVR>
+template <int DT, int NVW, int NVR, bool HIST>
 __global__ __launch_bounds__(256, 4) void wanda_rows_fused_kernel(const RowsGroup gw, const RowsGroup gr) {
     __shared__ uint32_t cand_lds_all[4][64 * 2];      // wave form: 2 candidates per lane and wave
     __shared__ uint32_t lds8[8];
     __shared__ uint32_t wave4[4];
-    __shared__ uint32_t res3[3];
+    __shared__ uint32_t res3[4];
+    // wave form: one histogram per wave; workgroup form: the first one (+ its counter in res3's
+    // neighbour would alias: the counter lives behind the LAST histogram instead)
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[HIST ? 4 : 1][RH_BINS];
     const int64_t n_long = gr.start[gr.n];
     if ((int64_t)blockIdx.x < n_long)
-        rows_reg_body<DT, NVR>(gr, blockIdx.x, lds8, wave4, &cand_lds_all[0][0], res3);
+        rows_reg_body<DT, NVR, HIST>(gr, blockIdx.x, lds8, wave4, &cand_lds_all[0][0], res3, &hist_all[0][0]);
     else
-        rows_wave_body<DT, NVW>(gw, ((int64_t)blockIdx.x - n_long) * 4, cand_lds_all);
+        rows_wave_body<DT, NVW, HIST>(gw, ((int64_t)blockIdx.x - n_long) * 4, cand_lds_all, hist_all);
 }
 
 #define ROWS_WAVE_MAX_NVEC 256                           // 4 vectors per lane (2048 bf16 columns)
@@ -1063,18 +1220,31 @@ static inline int rows_reg_class(int64_t nvec) {        // vectors per thread, o
     return 0;
 }
 
-template <int DT>
-static void launch_rows_wave(const RowsGroup& g, int nv, hipStream_t s) {
-    const dim3 grid((unsigned)((g.start[g.n] + 3) / 4)), blk(256);
-    if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1>), grid, blk, 0, s, g);
-    else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2>), grid, blk, 0, s, g);
-    else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4>), grid, blk, 0, s, g);
+// Which search the rows kernels run: the histogram form (default) or the bisection form of
+// rounds 2-3 (ECOFLAP_WANDA_ROWS_SEARCH=bisect: A/B measurements and the parity tests, which run
+// both against the oracle).  Read per call: cheap, and a test can flip it inside one process.
+static inline bool rows_search_hist() {
+    const char* e = getenv("ECOFLAP_WANDA_ROWS_SEARCH");
+    return !(e && e[0] == 'b');
 }
 
+template <int DT, bool HIST>
+static void launch_rows_wave_t(const RowsGroup& g, int nv, hipStream_t s) {
+    const dim3 grid((unsigned)((g.start[g.n] + 3) / 4)), blk(256);
+    if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1, HIST>), grid, blk, 0, s, g);
+    else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2, HIST>), grid, blk, 0, s, g);
+    else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4, HIST>), grid, blk, 0, s, g);
+}
 template <int DT>
-static void launch_rows_fused(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
+static void launch_rows_wave(const RowsGroup& g, int nv, hipStream_t s) {
+    if (rows_search_hist()) launch_rows_wave_t<DT, true>(g, nv, s);
+    else launch_rows_wave_t<DT, false>(g, nv, s);
+}
+
+template <int DT, bool HIST>
+static void launch_rows_fused_t(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
     const dim3 grid((unsigned)(gr.start[gr.n] + (gw.start[gw.n] + 3) / 4)), blk(256);
-#define FUSED(W_, R_) hipLaunchKernelGGL((wanda_rows_fused_kernel<DT, W_, R_>), grid, blk, 0, s, gw, gr)
+#define FUSED(W_, R_) hipLaunchKernelGGL((wanda_rows_fused_kernel<DT, W_, R_, HIST>), grid, blk, 0, s, gw, gr)
 #define FUSED_R(W_)                                                          \
     do {                                                                     \
         if (nvr == 1) FUSED(W_, 1); else if (nvr == 2) FUSED(W_, 2);         \
@@ -1084,11 +1254,16 @@ static void launch_rows_fused(const RowsGroup& gw, int nvw, const RowsGroup& gr,
 #undef FUSED_R
 #undef FUSED
 }
-
 template <int DT>
-static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
+static void launch_rows_fused(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
+    if (rows_search_hist()) launch_rows_fused_t<DT, true>(gw, nvw, gr, nvr, s);
+    else launch_rows_fused_t<DT, false>(gw, nvw, gr, nvr, s);
+}
+
+template <int DT, bool HIST>
+static void launch_rows_reg_t(const RowsGroup& g, int nv, hipStream_t s) {
     const dim3 grid((unsigned)g.start[g.n]), blk(256);
-#define ROWS_REG(NV_) hipLaunchKernelGGL((wanda_rows_reg_kernel<DT, NV_>), grid, blk, 0, s, g)
+#define ROWS_REG(NV_) hipLaunchKernelGGL((wanda_rows_reg_kernel<DT, NV_, HIST>), grid, blk, 0, s, g)
     switch (nv) {
         case 1: ROWS_REG(1); break;
         case 2: ROWS_REG(2); break;
@@ -1100,6 +1275,11 @@ static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
         default: ROWS_REG(16); break;
     }
 #undef ROWS_REG
+}
+template <int DT>
+static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
+    if (rows_search_hist()) launch_rows_reg_t<DT, true>(g, nv, s);
+    else launch_rows_reg_t<DT, false>(g, nv, s);
 }
 
 // =====================================================================================

@@ -110,9 +110,11 @@ def _hessian(rank, world):
     for i, x in enumerate(xs):
         if i % world == rank:
             w.add_batch(x, None)
+    w.flush()                       # buffered calibration samples -> H (as the block loop does)
     owner = SimpleNamespace(kernels=kern, process_group=None)
     _BlockwiseWanda(owner)._merge_hessians({"lin": w})
     torch.cuda.synchronize()
+    assert torch.isfinite(w.H).all()
     return w.H.detach().cpu()
 
 

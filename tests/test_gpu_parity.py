@@ -552,11 +552,54 @@ def _ties(w, levels):
     return (torch.round(w * levels) / levels)
 
 
+@pytest.fixture(params=["hist", "bisect"])
+def rows_search(request, monkeypatch):
+    """Both searches of the rows kernels: the histogram form (default) and the bisection form
+    (ECOFLAP_WANDA_ROWS_SEARCH=bisect; the library reads the variable per call)."""
+    monkeypatch.setenv("ECOFLAP_WANDA_ROWS_SEARCH", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cols", [2048, 5120, 1000])
+def test_wanda_rows_histogram_edge_cases(kern, oracle, dt, cols, rows_search):
+    """What the histogram search must not get wrong: a k-th smallest more than 32 octaves below
+    the row maximum (outlier column: the shared bin 0), a row that is half zeros, one value
+    everywhere (the crowded bin), metrics spread log-uniformly over 40 octaves, rows whose values
+    sit on bin boundaries, an infinite weight — wave form, workgroup form and the LDS form (odd
+    width), every k from a sweep; masks and weights == the oracle bit for bit."""
+    g = torch.Generator().manual_seed(cols)
+    rows = []
+    base = torch.randn(cols, generator=g) * 0.05
+    rows.append(base.clone())                                                    # plain
+    r = base.clone(); r[torch.randperm(cols, generator=g)[:cols // 2 + 3]] = 0.0
+    rows.append(r)                                                               # half zeros
+    rows.append(torch.full((cols,), 0.0371))                                     # one value
+    rows.append(torch.exp2(torch.rand(cols, generator=g) * 40 - 30) * torch.sign(base))   # 40 octaves
+    rows.append(torch.exp2(torch.randint(-20, 4, (cols,), generator=g).float()))  # exact powers of two
+    r = base.clone(); r[5] = float("inf"); rows.append(r)                        # an infinite metric
+    r = base.clone() * 1e-30; rows.append(r)                                     # tiny (fp16: zeros / subnormals)
+    w = torch.stack(rows).to(dt)
+    for sq_kind in ("flat", "outlier"):
+        s = torch.rand(cols, generator=g) + 0.1
+        if sq_kind == "outlier":
+            s[cols // 3] = 1e30 if dt != torch.float16 else 6e4    # one column dwarfs the rest
+        for k in (0, 1, cols // 4, cols // 2, cols - 1, cols):
+            wg = gpu(w.clone())
+            mask = torch.zeros(w.shape, dtype=torch.uint8, device="cuda")
+            kern.wanda_prune_rows(wg, gpu(s), k, mask)
+            wr = w.clone()
+            mref = oracle.wanda_prune_rows(wr, s, k)
+            bad = (mask.cpu() != mref).any(1).nonzero().flatten().tolist()
+            assert not bad, (sq_kind, k, "rows", bad)
+            assert torch.equal(wg.cpu().view(torch.uint8), wr.view(torch.uint8)), (sq_kind, k)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("rows,cols,frac,levels", [
     (7, 64, 0.5, None), (5, 100, 0.37, 4), (3, 1, 0.5, None), (16, 5120, 0.5, None),
     (9, 3000, 0.61, 8), (4, 257, 0.0, None), (4, 257, 1.0, None), (6, 15360, 0.5, 16)])
-def test_wanda_rows_vs_oracle(kern, oracle, dt, rows, cols, frac, levels):
+def test_wanda_rows_vs_oracle(kern, oracle, dt, rows, cols, frac, levels, rows_search):
     torch.manual_seed(rows * cols)
     w = torch.randn(rows, cols) * 0.05
     if levels:
@@ -767,7 +810,8 @@ def test_wanda_block_call_equals_oracle_per_matrix(kern, oracle):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("short_vec,long_vec,levels", [
     (64, 300, None), (128, 600, 3), (256, 1000, None), (200, 257, 40), (33, 640, None)])
-def test_wanda_block_short_and_long_rows_share_one_grid(kern, oracle, dt, short_vec, long_vec, levels):
+def test_wanda_block_short_and_long_rows_share_one_grid(kern, oracle, dt, short_vec, long_vec, levels,
+                                                        rows_search):
     """Rows-mode items of the wave form (<= 256 vectors per row) and of the workgroup form
     (257..1024 vectors) in one block call take the fused grid: every register-class pairing, ties
     (few distinct values: the crowded-bucket path and the column-order cut), k = 0 and k = cols,
@@ -798,7 +842,7 @@ def test_wanda_block_short_and_long_rows_share_one_grid(kern, oracle, dt, short_
             assert torch.equal(mask.cpu(), mref), tuple(wg.shape)
 
 
-def test_wanda_rows_random_shapes_vs_oracle(kern, oracle):
+def test_wanda_rows_random_shapes_vs_oracle(kern, oracle, rows_search):
     """Rows mode over random widths (every wave / workgroup register class, vector and odd
     widths), dtypes, k and tie densities, several matrices per block call == oracle, bit for bit."""
     import random
