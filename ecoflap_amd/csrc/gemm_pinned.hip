@@ -1,0 +1,264 @@
+// gemm_pinned.hip — the forward's 16-bit Linears through hipBLASLt with the SOLUTION PINNED per
+// weight shape (plumbing of the shape modules, include/ecoflap_shape_ops.h; not the pruner ABI).
+//
+// Why: torch hands `F.linear` to hipBLASLt's heuristic, which (a) picks Stream-K kernels for the
+// loop's larger GEMMs — in their default mode not reproducible call to call (~1 call in 30 000,
+// ecoflap_amd/blas_guard.py) — and (b) picks DIFFERENT kernels for M = 257 and M = 16 * 257, so
+// a batch of 16 evaluations is not the 16 single evaluations bit for bit and the loop cannot
+// share their suffix at batch size 1 (profiles/r03_sparsegpt.json: 49 stages not batch
+// invariant, 5.2 layers/s against 14.7 at batch size 8).  Both are properties of a choice the
+// library makes per call.  Here the choice is made ONCE per (N, K, dtype, bias) and kept:
+//   * candidates = the library's own heuristic list for the LARGE problem (16 x the probe M);
+//   * a candidate is dropped by NAME when it is a Stream-K kernel (`_SK<n>`, n > 0) or splits K
+//     over workgroups (`_GSU<n>`, n > 1): their summation order depends on the grid;
+//   * the rest is MEASURED: the large problem twice (same bits?) and the probe problem alone
+//     against its first and last slot of the large one (same bits at every row offset?);
+//   * the fastest survivor is pinned: every later call of that weight shape, whatever M, runs
+//     that solution index (re-bound to the problem size through getAlgosFromIndex).
+// With one macro tile and one K order for every M the result of a row no longer depends on how
+// many rows travel with it: batch invariance by construction, no environment variable involved.
+#include "common.h"
+#include "../../include/ecoflap_shape_ops.h"
+
+#include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#define ECOFLAP_ELIBRARY 999     /* hipErrorUnknown: a hipBLASLt / runtime call failed */
+
+namespace {
+
+struct Bound {                       // the pinned solution bound to one problem size
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+};
+struct Problem;
+struct Plan {
+    int index = -1;
+    std::string name;
+    int tried = 0, passed = 0;
+    float best_us = 0.f;
+    std::map<int64_t, std::pair<Problem*, Bound>> by_m;     // descriptors + binding per row count
+};
+using Key = std::tuple<int64_t, int64_t, int, int, int>;      // N, K, dtype, has_bias, bias_dtype
+
+std::mutex g_mu;
+std::map<Key, Plan> g_plans;
+hipblasLtHandle_t g_handle = nullptr;
+
+inline hipDataType hip_type(int dt) {
+    return dt == ECOFLAP_F16 ? HIP_R_16F : (dt == ECOFLAP_BF16 ? HIP_R_16BF : HIP_R_32F);
+}
+
+struct Problem {                     // descriptors of y[M,N] = x[M,K] W[N,K]^T (+ b): column-major
+    hipblasLtMatmulDesc_t desc = nullptr;          // view y^T[N,M] = W^T(op T on [K,N]) x^T[K,M]
+    hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+    ~Problem() {
+        if (a) hipblasLtMatrixLayoutDestroy(a);
+        if (b) hipblasLtMatrixLayoutDestroy(b);
+        if (c) hipblasLtMatrixLayoutDestroy(c);
+        if (desc) hipblasLtMatmulDescDestroy(desc);
+    }
+    bool make(int64_t M, int64_t N, int64_t K, int dt, bool has_bias, int bias_dt, const void* bias) {
+        const hipDataType t = hip_type(dt);
+        if (hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
+        const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+        hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+        hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+        if (has_bias) {
+            const uint32_t ep = HIPBLASLT_EPILOGUE_BIAS;
+            const int32_t bt = (int32_t)hip_type(bias_dt);
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+        }
+        return hipblasLtMatrixLayoutCreate(&a, t, (uint64_t)K, (uint64_t)N, K) == HIPBLAS_STATUS_SUCCESS &&
+               hipblasLtMatrixLayoutCreate(&b, t, (uint64_t)K, (uint64_t)M, K) == HIPBLAS_STATUS_SUCCESS &&
+               hipblasLtMatrixLayoutCreate(&c, t, (uint64_t)N, (uint64_t)M, N) == HIPBLAS_STATUS_SUCCESS;
+    }
+};
+
+// `_<tag><number>` anywhere in a Tensile solution name -> the number (-1: tag absent)
+int tagged_number(const std::string& name, const char* tag) {
+    const std::string t = std::string("_") + tag;
+    size_t p = 0;
+    while ((p = name.find(t, p)) != std::string::npos) {
+        p += t.size();
+        if (p < name.size() && name[p] >= '0' && name[p] <= '9') return atoi(name.c_str() + p);
+    }
+    return -1;
+}
+bool grid_dependent_sum(const std::string& name) {
+    return tagged_number(name, "SK") > 0 || tagged_number(name, "GSU") > 1 ||
+           name.find("StreamK") != std::string::npos;
+}
+
+__global__ void fill_pattern_kernel(uint16_t* p, int64_t n, int64_t period, uint32_t salt, int dt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t h = (uint32_t)(i % period) * 2654435761u + salt;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float v = ((float)(h & 0xffff) / 65536.0f - 0.5f) * 0.25f;     // [-1/8, 1/8)
+        if (dt == ECOFLAP_F16) {
+            const _Float16 hv = (_Float16)v;
+            p[i] = __builtin_bit_cast(uint16_t, hv);
+        } else {
+            p[i] = (uint16_t)(__float_as_uint(v) >> 16);                    // bf16, truncated
+        }
+    }
+}
+
+bool bind(int index, const Problem& pr, Bound& out) {
+    std::vector<int> idx{index};
+    std::vector<hipblasLtMatmulHeuristicResult_t> res;
+    if (hipblaslt_ext::getAlgosFromIndex(g_handle, idx, res) != HIPBLAS_STATUS_SUCCESS || res.empty()) return false;
+    const float one = 1.f, zero = 0.f;
+    size_t ws = 0;
+    if (hipblaslt_ext::matmulIsAlgoSupported(g_handle, pr.desc, &one, pr.a, pr.b, &zero, pr.c, pr.c, res[0].algo, ws) !=
+        HIPBLAS_STATUS_SUCCESS)
+        return false;
+    out.algo = res[0].algo;
+    out.workspace = ws;
+    return true;
+}
+
+hipblasStatus_t run(const Problem& pr, const Bound& b, const void* x, const void* w, void* y, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    const float one = 1.f, zero = 0.f;
+    if (b.workspace > ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
+    return hipblasLtMatmul(g_handle, pr.desc, &one, w, pr.a, x, pr.b, &zero, y, pr.c, y, pr.c, &b.algo, ws, ws_bytes, s);
+}
+
+}  // namespace
+
+extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias,
+                                          int bias_dtype, int* solution_index, int* tried, int* passed,
+                                          float* best_us, char* name_out, int name_len) {
+    if ((dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) || m_probe <= 0 || N <= 0 || K <= 0) return ECOFLAP_EDTYPE;
+    std::lock_guard<std::mutex> lock(g_mu);
+    const Key key{N, K, dtype, has_bias ? 1 : 0, has_bias ? bias_dtype : 0};
+    auto found = g_plans.find(key);
+    if (found == g_plans.end()) {
+        if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return ECOFLAP_ELIBRARY;
+        constexpr int SLOTS = 16;
+        const int64_t Mb = SLOTS * m_probe;
+        const size_t es = 2, ws_bytes = (size_t)64 << 20;
+        uint16_t *x = nullptr, *w = nullptr, *bias = nullptr, *yb = nullptr, *yb2 = nullptr, *ya = nullptr;
+        void* ws = nullptr;
+        bool ok = hipMalloc(&x, Mb * K * es) == hipSuccess && hipMalloc(&w, N * K * es) == hipSuccess &&
+                  hipMalloc(&bias, N * 4) == hipSuccess && hipMalloc(&yb, Mb * N * es) == hipSuccess &&
+                  hipMalloc(&yb2, Mb * N * es) == hipSuccess && hipMalloc(&ya, m_probe * N * es) == hipSuccess &&
+                  hipMalloc(&ws, ws_bytes) == hipSuccess;
+        Plan plan;
+        if (ok) {
+            hipStream_t s = nullptr;
+            // every slot of the large input is a copy of the probe input (period = its size)
+            hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, x, Mb * K, m_probe * K, 17u, dtype);
+            hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, w, N * K, N * K, 91u, dtype);
+            // (N * 4 bytes of small bf16 patterns: a sane vector read as f16, bf16 or f32)
+            hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, s, bias, N * 2, N * 2, 5u,
+                               dtype == ECOFLAP_F16 && bias_dtype != ECOFLAP_F32 ? ECOFLAP_F16 : ECOFLAP_BF16);
+            Problem big, small;
+            ok = big.make(Mb, N, K, dtype, has_bias, bias_dtype, bias) && small.make(m_probe, N, K, dtype, has_bias, bias_dtype, bias);
+            std::vector<hipblasLtMatmulHeuristicResult_t> cand(96);
+            int n_cand = 0;
+            if (ok) {
+                hipblasLtMatmulPreference_t pref;
+                hipblasLtMatmulPreferenceCreate(&pref);
+                hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes));
+                ok = hipblasLtMatmulAlgoGetHeuristic(g_handle, big.desc, big.a, big.b, big.c, big.c, pref, (int)cand.size(),
+                                                     cand.data(), &n_cand) == HIPBLAS_STATUS_SUCCESS;
+                hipblasLtMatmulPreferenceDestroy(pref);
+            }
+            std::vector<uint16_t> h_alone((size_t)m_probe * N), h_big((size_t)m_probe * N);
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            for (int c = 0; ok && c < n_cand && plan.passed < 6; ++c) {
+                if (cand[c].state != HIPBLAS_STATUS_SUCCESS) continue;
+                const int index = hipblaslt_ext::getIndexFromAlgo(cand[c].algo);
+                const std::string name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, cand[c].algo);
+                ++plan.tried;
+                if (index < 0 || grid_dependent_sum(name)) continue;
+                Bound bb, bs;
+                if (!bind(index, big, bb) || !bind(index, small, bs)) continue;
+                if (run(big, bb, x, w, yb, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+                if (run(big, bb, x, w, yb2, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+                if (run(small, bs, x, w, ya, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+                if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
+                // same bits on a repeated call, and at the first and the last row offset
+                bool same = true;
+                (void)hipMemcpy(h_alone.data(), ya, h_alone.size() * es, hipMemcpyDeviceToHost);
+                for (int slot : {0, SLOTS - 1}) {
+                    (void)hipMemcpy(h_big.data(), yb + (size_t)slot * m_probe * N, h_big.size() * es, hipMemcpyDeviceToHost);
+                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size() * es) == 0;
+                    (void)hipMemcpy(h_big.data(), yb2 + (size_t)slot * m_probe * N, h_big.size() * es, hipMemcpyDeviceToHost);
+                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size() * es) == 0;
+                }
+                if (!same) continue;
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < 3; ++r) run(big, bb, x, w, yb, ws, ws_bytes, s);
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                const float us = ms * 1e3f / 3.f;
+                ++plan.passed;
+                if (plan.index < 0 || us < plan.best_us) {
+                    plan.index = index;
+                    plan.name = name;
+                    plan.best_us = us;
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        for (void* p : {(void*)x, (void*)w, (void*)bias, (void*)yb, (void*)yb2, (void*)ya, ws})
+            if (p) (void)hipFree(p);
+        if (!ok) return ECOFLAP_ELIBRARY;
+        found = g_plans.emplace(key, plan).first;
+    }
+    const Plan& p = found->second;
+    if (solution_index) *solution_index = p.index;
+    if (tried) *tried = p.tried;
+    if (passed) *passed = p.passed;
+    if (best_us) *best_us = p.best_us;
+    if (name_out && name_len > 0) {
+        strncpy(name_out, p.name.c_str(), (size_t)name_len - 1);
+        name_out[name_len - 1] = 0;
+    }
+    return p.index >= 0 ? 0 : ECOFLAP_ESIZE;      // ESIZE: no candidate survived — the caller keeps torch's GEMM
+}
+
+extern "C" int ecoflap_linear_pinned(const void* x, const void* w, const void* bias, void* y, int64_t M,
+                                     int64_t N, int64_t K, int dtype, int bias_dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || !w || !y) return ECOFLAP_ENULL;
+    std::lock_guard<std::mutex> lock(g_mu);
+    const Key key{N, K, dtype, bias ? 1 : 0, bias ? bias_dtype : 0};
+    auto it = g_plans.find(key);
+    if (it == g_plans.end() || it->second.index < 0) return ECOFLAP_EMODE;    // plan first (outside capture)
+    auto bm = it->second.by_m.find(M);
+    if (bm == it->second.by_m.end()) {
+        Problem* pr = new Problem();        // binding needs no device work: safe under stream capture
+        Bound nb;
+        if (!pr->make(M, N, K, dtype, bias != nullptr, bias_dtype, bias) || !bind(it->second.index, *pr, nb)) {
+            delete pr;
+            return ECOFLAP_ESIZE;
+        }
+        bm = it->second.by_m.emplace(M, std::make_pair(pr, nb)).first;
+    }
+    Problem& pr = *bm->second.first;
+    if (bias)       // the modules of one shape share the descriptors; each call carries its own vector
+        hipblasLtMatmulDescSetAttribute(pr.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    const hipblasStatus_t st = run(pr, bm->second.second, x, w, y, workspace, workspace_bytes, (hipStream_t)stream);
+    if (st == HIPBLAS_STATUS_ALLOC_FAILED) return ECOFLAP_EWORKSPACE;
+    return st == HIPBLAS_STATUS_SUCCESS ? 0 : ECOFLAP_ELIBRARY;
+}

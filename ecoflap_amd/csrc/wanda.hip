@@ -558,6 +558,30 @@ static __device__ __forceinline__ void zero_pruned(u32x4& wv, const bool* prune)
             wv[q] &= (prune[2 * q] ? 0u : 0xffffu) | (prune[2 * q + 1] ? 0u : 0xffff0000u);
     }
 }
+// `m <= T` goes: the common ending of a row (no mask bytes wanted, no tie cut by column order).
+// 16-bit dtypes: one compare and ONE sub-dword select per element — v_cndmask_b32_sdwa writes the
+// element's half of the packed register and preserves the other (the compiler's form is compare,
+// select, select, or, and per PAIR plus the bool bookkeeping: ~5 per element in the listing).
+// Element halves are visited low halves first, high halves second: consecutive writes never
+// touch the same register (the 16-bit-destination forwarding hazard of this ISA).
+template <int DT>
+static __device__ __forceinline__ void zero_le(u32x4& wv, const uint32_t* m, uint32_t T) {
+    if constexpr (Vec<DT>::N == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = m[i] <= T ? 0u : wv[i];
+    } else {
+        const uint32_t zero = 0u;
+        uint32_t r0 = wv[0], r1 = wv[1], r2 = wv[2], r3 = wv[3];
+#define ECO_SEL_LO(R_, M_) asm volatile("v_cmp_lt_u32 vcc, %2, %1\n\tv_cndmask_b32_sdwa %0, %3, %0, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v"(R_) : "v"(M_), "s"(T), "v"(zero) : "vcc")
+#define ECO_SEL_HI(R_, M_) asm volatile("v_cmp_lt_u32 vcc, %2, %1\n\tv_cndmask_b32_sdwa %0, %3, %0, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_1" : "+v"(R_) : "v"(M_), "s"(T), "v"(zero) : "vcc")
+        ECO_SEL_LO(r0, m[0]); ECO_SEL_LO(r1, m[2]); ECO_SEL_LO(r2, m[4]); ECO_SEL_LO(r3, m[6]);
+        ECO_SEL_HI(r0, m[1]); ECO_SEL_HI(r1, m[3]); ECO_SEL_HI(r2, m[5]); ECO_SEL_HI(r3, m[7]);
+#undef ECO_SEL_LO
+#undef ECO_SEL_HI
+        wv[0] = r0; wv[1] = r1; wv[2] = r2; wv[3] = r3;
+    }
+}
+
 template <int N>
 static __device__ __forceinline__ void store_mask_bytes(uint8_t* mrow, const bool* prune) {
     uint32_t lo = 0, hi = 0;
@@ -891,6 +915,17 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
     const bool ordered = !all && (take_equal < total_equal);   // ties cut by column order
     if (!ordered) {
         const uint32_t Tq = all ? 0xffffffffu : T;
+        if (!mask_out) {                       // block-uniform: the production call
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int64_t v = tid + 256 * j;
+                if (v < nvec) {
+                    zero_le<DT>(wv[j], m[j], Tq);
+                    st16(wrow, v, wv[j]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int64_t v = tid + 256 * j;
@@ -900,7 +935,7 @@ static __device__ __forceinline__ void rows_reg_body(const RowsGroup& g, int64_t
                 for (int i = 0; i < N; ++i) prune[i] = m[j][i] <= Tq;
                 zero_pruned<DT>(wv[j], prune);
                 st16(wrow, v, wv[j]);
-                if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
+                store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
             }
         }
         return;
@@ -952,7 +987,9 @@ __global__ __launch_bounds__(256) void wanda_rows_reg_kernel(const RowsGroup g) 
 // all waves then load, search and store in phase and the memory and VALU phases stop overlapping
 // across waves; seeding the search from the previous row's threshold through a word in the
 // workspace — loads of many waves from one address serialise like atomics, ~30 ns each.)
-template <int DT, int NV, bool HIST>
+// FULL: every row of the launch has exactly 64 * NV vectors (FlanT5's 2048-wide rows in bf16):
+// no padding values, no bounds tests (the padding's defaults alone were 61 register moves).
+template <int DT, int NV, bool HIST, bool FULL = false>
 static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_t first_row,
                                                       uint32_t (*cand_lds_all)[64 * 2],
                                                       uint32_t (*hist_all)[RH_BINS]) {
@@ -975,7 +1012,7 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
     uint32_t m[NV][N];
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-        if (lane + 64 * j < nvec) wv[j] = ld16(wrow, lane + 64 * j);
+        if (FULL || lane + 64 * j < nvec) wv[j] = ld16(wrow, lane + 64 * j);
     if constexpr (HIST) {                      // the wave's histogram, cleared while the loads fly
         const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -984,7 +1021,7 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t v = lane + 64 * j;
-        if (v < nvec) {
+        if (FULL || v < nvec) {
             float f[N];
             Vec<DT>::unpack(wv[j], f);
 #pragma unroll
@@ -1011,7 +1048,7 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
         uint32_t mx = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            if (lane + 64 * j < nvec) {
+            if (FULL || lane + 64 * j < nvec) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) mx = m[j][i] > mx ? m[j][i] : mx;
             }
@@ -1029,7 +1066,7 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
             const uint32_t lowbound = rh_lowbound(mx);
 #pragma unroll
             for (int j = 0; j < NV; ++j)
-                if (lane + 64 * j < nvec) {      // (padding must not be binned: it lies above mx)
+                if (FULL || lane + 64 * j < nvec) {      // (padding must not be binned: it lies above mx)
 #pragma unroll
                     for (int i = 0; i < N; ++i)
                         __hip_atomic_fetch_add(&hist[rh_bin(m[j][i], lowbound)], 1u, __ATOMIC_RELAXED,
@@ -1074,6 +1111,9 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
         constexpr uint32_t CMAX = 2;             // candidates per lane (RH_CAND = 64 * CMAX)
         if (!crowded) {                          // wave-uniform
             const uint32_t span = 1u << bits;    // (bits <= 18 here)
+            // (tried: a counter handing out the slots, `cand[atomicAdd(counter, 1)] = rel` under the
+            // lanes' own branch — the compiler turns it into a wave-aggregated atomic, 11 VALU per
+            // element slot with a hit against 6 for the ballot form below, plus an LDS round trip)
             uint32_t pos = 0;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
@@ -1082,7 +1122,7 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
                     const uint32_t rel = m[j][i] - lo;
                     const bool hit = rel < span;
                     const uint64_t mask = __ballot(hit);
-                    if (mask) {                  // wave-uniform: most element slots have no candidate
+                    if (mask) {                  // wave-uniform: a third of the element slots have no candidate
                         if (hit) cand_lds[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = rel;
                         pos += (uint32_t)__popcll(mask);
@@ -1133,16 +1173,27 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
     if (!ordered) {
         // every element equal to T goes (or, with k >= cols, every element): prune = m <= T
         const uint32_t Tq = all ? 0xffffffffu : T;
+        if (!mask_out) {                       // wave-uniform: the production call
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int64_t v = lane + 64 * j;
+                if (FULL || v < nvec) {
+                    zero_le<DT>(wv[j], m[j], Tq);
+                    st16(wrow, v, wv[j]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int64_t v = lane + 64 * j;
-            if (v < nvec) {
+            if (FULL || v < nvec) {
                 bool prune[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) prune[i] = m[j][i] <= Tq;
                 zero_pruned<DT>(wv[j], prune);
                 st16(wrow, v, wv[j]);
-                if (mask_out) store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
+                store_mask_bytes<N>(mask_out + row * cols + v * N, prune);
             }
         }
         return;
@@ -1178,11 +1229,11 @@ static __device__ __forceinline__ void rows_wave_body(const RowsGroup& g, int64_
     }
 }
 
-template <int DT, int NV, bool HIST>
+template <int DT, int NV, bool HIST, bool FULL>
 __global__ __launch_bounds__(256, 4) void wanda_rows_wave_kernel(const RowsGroup g) {
     __shared__ uint32_t cand_lds_all[4][64 * 2];
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[HIST ? 4 : 1][RH_BINS];
-    rows_wave_body<DT, NV, HIST>(g, (int64_t)blockIdx.x * 4, cand_lds_all, hist_all);
+    rows_wave_body<DT, NV, HIST, FULL>(g, (int64_t)blockIdx.x * 4, cand_lds_all, hist_all);
 }
 
 // A block's short rows (wave form) and long rows (workgroup form) in ONE grid: the long rows of a
@@ -1190,7 +1241,7 @@ __global__ __launch_bounds__(256, 4) void wanda_rows_wave_kernel(const RowsGroup
 // (measured: 33 us for 22 % of the block's bytes, after the 58 us of the other 78 %), and launches
 // on one stream do not overlap; side streams joined by events cost more than they gave.  The
 // long-row workgroups come first in the grid so that they are not the tail.
-template <int DT, int NVW, int NVR, bool HIST>
+template <int DT, int NVW, int NVR, bool HIST, bool FULL>
 __global__ __launch_bounds__(256, 4) void wanda_rows_fused_kernel(const RowsGroup gw, const RowsGroup gr) {
     __shared__ uint32_t cand_lds_all[4][64 * 2];      // wave form: 2 candidates per lane and wave
     __shared__ uint32_t lds8[8];
@@ -1203,7 +1254,7 @@ __global__ __launch_bounds__(256, 4) void wanda_rows_fused_kernel(const RowsGrou
     if ((int64_t)blockIdx.x < n_long)
         rows_reg_body<DT, NVR, HIST>(gr, blockIdx.x, lds8, wave4, &cand_lds_all[0][0], res3, &hist_all[0][0]);
     else
-        rows_wave_body<DT, NVW, HIST>(gw, ((int64_t)blockIdx.x - n_long) * 4, cand_lds_all, hist_all);
+        rows_wave_body<DT, NVW, HIST, FULL>(gw, ((int64_t)blockIdx.x - n_long) * 4, cand_lds_all, hist_all);
 }
 
 #define ROWS_WAVE_MAX_NVEC 256                           // 4 vectors per lane (2048 bf16 columns)
@@ -1228,23 +1279,36 @@ static inline bool rows_search_hist() {
     return !(e && e[0] == 'b');
 }
 
-template <int DT, bool HIST>
+// every row of the group exactly 64 * nv vectors wide (no padding lanes)?
+template <int DT>
+static inline bool rows_group_full(const RowsGroup& g, int nv) {
+    for (int i = 0; i < g.n; ++i)
+        if (g.cols[i] != (int64_t)64 * nv * Vec<DT>::N) return false;
+    return true;
+}
+
+template <int DT, bool HIST, bool FULL>
 static void launch_rows_wave_t(const RowsGroup& g, int nv, hipStream_t s) {
     const dim3 grid((unsigned)((g.start[g.n] + 3) / 4)), blk(256);
-    if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1, HIST>), grid, blk, 0, s, g);
-    else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2, HIST>), grid, blk, 0, s, g);
-    else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4, HIST>), grid, blk, 0, s, g);
+    if (nv == 1) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 1, HIST, FULL>), grid, blk, 0, s, g);
+    else if (nv == 2) hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 2, HIST, FULL>), grid, blk, 0, s, g);
+    else hipLaunchKernelGGL((wanda_rows_wave_kernel<DT, 4, HIST, FULL>), grid, blk, 0, s, g);
 }
 template <int DT>
 static void launch_rows_wave(const RowsGroup& g, int nv, hipStream_t s) {
-    if (rows_search_hist()) launch_rows_wave_t<DT, true>(g, nv, s);
-    else launch_rows_wave_t<DT, false>(g, nv, s);
+    const bool full = rows_group_full<DT>(g, nv);
+    if (rows_search_hist()) {
+        if (full) launch_rows_wave_t<DT, true, true>(g, nv, s);
+        else launch_rows_wave_t<DT, true, false>(g, nv, s);
+    } else {
+        launch_rows_wave_t<DT, false, false>(g, nv, s);
+    }
 }
 
-template <int DT, bool HIST>
+template <int DT, bool HIST, bool FULL>
 static void launch_rows_fused_t(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
     const dim3 grid((unsigned)(gr.start[gr.n] + (gw.start[gw.n] + 3) / 4)), blk(256);
-#define FUSED(W_, R_) hipLaunchKernelGGL((wanda_rows_fused_kernel<DT, W_, R_, HIST>), grid, blk, 0, s, gw, gr)
+#define FUSED(W_, R_) hipLaunchKernelGGL((wanda_rows_fused_kernel<DT, W_, R_, HIST, FULL>), grid, blk, 0, s, gw, gr)
 #define FUSED_R(W_)                                                          \
     do {                                                                     \
         if (nvr == 1) FUSED(W_, 1); else if (nvr == 2) FUSED(W_, 2);         \
@@ -1256,8 +1320,13 @@ static void launch_rows_fused_t(const RowsGroup& gw, int nvw, const RowsGroup& g
 }
 template <int DT>
 static void launch_rows_fused(const RowsGroup& gw, int nvw, const RowsGroup& gr, int nvr, hipStream_t s) {
-    if (rows_search_hist()) launch_rows_fused_t<DT, true>(gw, nvw, gr, nvr, s);
-    else launch_rows_fused_t<DT, false>(gw, nvw, gr, nvr, s);
+    const bool full = rows_group_full<DT>(gw, nvw);
+    if (rows_search_hist()) {
+        if (full) launch_rows_fused_t<DT, true, true>(gw, nvw, gr, nvr, s);
+        else launch_rows_fused_t<DT, true, false>(gw, nvw, gr, nvr, s);
+    } else {
+        launch_rows_fused_t<DT, false, false>(gw, nvw, gr, nvr, s);
+    }
 }
 
 template <int DT, bool HIST>

@@ -104,6 +104,11 @@ class LayerWiseBasePruner(BasePruner):
             requires_grad_record[n] = p.requires_grad
             p.requires_grad = True
         device = next(iter(model.parameters())).device
+        if device.type == "cuda" and hasattr(model, "stage_plan"):
+            # the build's own shape modules: their 16-bit Linears run ONE pinned hipBLASLt solution
+            # per weight shape (shapes/fused.py; a model built on the CPU and moved over gets it here)
+            from ..shapes.fused import pin_linears
+            pin_linears(model)
         if device.type == "cuda":
             from .. import blas_guard
             # the GEMM library must be in its reproducible mode; batch invariance on top only

@@ -895,6 +895,7 @@ class PrefixCachedLoss:
         when the shared pass's input now holds the k results; False: the caller takes the
         per-evaluation path (first-use check failed, or the Linear cannot be patched)."""
         import torch.nn.functional as F
+        from ..shapes.fused import linear_or_torch
         k = len(evals)
         name = self._pair_name
         if not name.endswith(".weight"):
@@ -905,6 +906,7 @@ class PrefixCachedLoss:
             return False
         if not isinstance(mod, torch.nn.Linear):
             return False
+        _linear = linear_or_torch if getattr(mod, "_ecoflap_pinned", False) else F.linear
         fam = self._fam
         key = (fam, entry, k)
         cat_in = self._owner_in.get(key)
@@ -924,7 +926,9 @@ class PrefixCachedLoss:
         def per_slot(x):
             if x.shape[0] != k * B:              # the Linear's input must carry the k slots in front
                 raise _NotBatchLeading()
-            return torch.cat([F.linear(x[i * B:(i + 1) * B], thetas[i], mod.bias)
+            # (the module's own dispatch: the pinned hipBLASLt solution of this weight shape where
+            # the shape modules use it, shapes/fused.py — the very call an evaluation makes alone)
+            return torch.cat([_linear(x[i * B:(i + 1) * B], thetas[i], mod.bias)
                               for i in range(k)], 0)
 
         had = "forward" in mod.__dict__

@@ -99,6 +99,9 @@ class Blip2T5(nn.Module):
         self.t5_proj = nn.Linear(self.Qformer.config.hidden_size, self.t5_model.config.d_model)
         self.vit_autocast_dtype = torch.float16
         self.t5_autocast_dtype = torch.bfloat16
+        if next(self.parameters()).device.type == "cuda":
+            from .fused import pin_linears
+            pin_linears(self)   # 16-bit GPU Linears: one pinned hipBLASLt solution per weight shape
 
     @property
     def device(self):

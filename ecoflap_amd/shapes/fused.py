@@ -204,3 +204,131 @@ def multi_compare(pairs, flag=None):
         if rc != 0:
             raise _hip.EcoflapHipError(f"ecoflap_multi_compare failed ({rc})")
     return flag
+
+
+# ---- 16-bit Linears through hipBLASLt with the solution pinned per weight shape -----------------
+# (csrc/gemm_pinned.hip, include/ecoflap_shape_ops.h: why, and how the solution is chosen)
+_gemm = None            # libecoflap_gemm.so (None: not loaded yet; False: unavailable)
+_plans = {}             # (N, K, dtype, has_bias, bias dtype) -> dict (index, name, ...) or None = keep torch's GEMM
+_gemm_ws = {}           # stream -> workspace tensor
+
+
+def _gemm_lib():
+    global _gemm
+    if _gemm is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libecoflap_gemm.so")
+        if os.environ.get("ECOFLAP_PINNED_GEMM", "1") == "0":
+            _gemm = False
+        elif not os.path.exists(path):
+            raise _hip.EcoflapHipError(f"{path} is not built (make -C ecoflap_amd/csrc); set "
+                                       "ECOFLAP_PINNED_GEMM=0 to run on the framework's own GEMM choice")
+        else:
+            lib = ctypes.CDLL(path)
+            vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+            ip, fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+            lib.ecoflap_linear_pinned_plan.argtypes = [i64, i64, i64, ci, ci, ci, ip, ip, ip, fp, ctypes.c_char_p, ci]
+            lib.ecoflap_linear_pinned.argtypes = [vp, vp, vp, vp, i64, i64, i64, ci, ci, vp, sz, vp]
+            _gemm = lib
+    return _gemm
+
+
+def pinned_plans():
+    """{(N, K, dtype, has_bias): {"index", "name", "tried", "passed", "us"} or None} chosen so far
+    (bench.py and the run summaries record it: a solution index means something only together with
+    the library version)."""
+    return {k[:4]: v for k, v in _plans.items()}
+
+
+def linear(x, weight, bias):
+    """F.linear(x, weight, bias) for a 16-bit weight on the GPU without autograd, through the
+    pinned hipBLASLt solution of this weight shape -> tensor, or None (caller runs F.linear:
+    CPU, fp32 weights, autograd on, no surviving candidate, ECOFLAP_PINNED_GEMM=0).  Under
+    autocast to the weight's dtype the input is cast as autocast would cast it."""
+    if (torch.is_grad_enabled() or weight.device.type != "cuda"
+            or weight.dtype not in (torch.float16, torch.bfloat16) or weight.dim() != 2
+            or not weight.is_contiguous()):
+        return None
+    if x.dtype != weight.dtype:
+        if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == weight.dtype
+                and x.is_floating_point()):
+            return None
+        x = x.to(weight.dtype)
+    elif torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != weight.dtype:
+        return None
+    if bias is not None and (bias.dtype not in (weight.dtype, torch.float32) or not bias.is_contiguous()):
+        return None
+    lib = _gemm_lib()
+    if lib is False:
+        return None
+    N, K = weight.shape
+    if x.shape[-1] != K or K % 8 != 0 or N % 8 != 0:
+        return None
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M == 0:
+        return None
+    dt = _hip.DTYPE_CODE[weight.dtype]
+    bdt = _hip.DTYPE_CODE[bias.dtype] if bias is not None else 0
+    key = (N, K, weight.dtype, bias is not None, bdt)
+    if key not in _plans:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"pinned GEMM: the solution for weight shape {N}x{K} has not been "
+                               "chosen yet and a graph is being captured (run the stage eagerly once)")
+        idx, tried, passed = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
+        us = ctypes.c_float(0.0)
+        name = ctypes.create_string_buffer(512)
+        torch.cuda.synchronize()
+        rc = lib.ecoflap_linear_pinned_plan(M if M <= 4096 else 2048, N, K, dt, int(bias is not None), bdt,
+                                            ctypes.byref(idx), ctypes.byref(tried), ctypes.byref(passed),
+                                            ctypes.byref(us), name, 512)
+        if rc == 0:
+            _plans[key] = {"index": idx.value, "name": name.value.decode(errors="replace"),
+                           "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value}
+        elif rc == -3:          # ECOFLAP_ESIZE: no candidate survived; torch's GEMM for this shape
+            _plans[key] = None
+        else:
+            raise _hip.EcoflapHipError(f"ecoflap_linear_pinned_plan failed ({rc}) for {N}x{K}")
+    if _plans[key] is None:
+        return None
+    stream = torch.cuda.current_stream()
+    ws = _gemm_ws.get(stream.cuda_stream)
+    if ws is None or ws.device != weight.device:
+        ws = _gemm_ws[stream.cuda_stream] = torch.empty(64 << 20, dtype=torch.uint8, device=weight.device)
+    y = torch.empty((M, N), dtype=weight.dtype, device=weight.device)
+    rc = lib.ecoflap_linear_pinned(x2.data_ptr(), weight.data_ptr(),
+                                   None if bias is None else bias.data_ptr(), y.data_ptr(), M, N, K, dt,
+                                   bdt, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_linear_pinned failed ({rc}) for [{M}, {K}] x {N}x{K}")
+    return y.view(*x.shape[:-1], N)
+
+
+def linear_or_torch(x, weight, bias):
+    """The forward of every Linear of the shape modules (`pin_linears`) and of the loop's
+    per-slot form of the owning Linear (pruners/prefix_cache.py): one dispatch, so the batched
+    and the per-evaluation paths run the same kernel on the same bits."""
+    y = linear(x, weight, bias)
+    return y if y is not None else torch.nn.functional.linear(x, weight, bias)
+
+
+def _pinned_forward(self, x):
+    return linear_or_torch(x, self.weight, self.bias)
+
+
+def pin_linears(model):
+    """Every nn.Linear of `model` gets an instance-level `forward` that goes through
+    `linear_or_torch`: its 16-bit GPU forward runs the pinned solution, everything else (CPU, fp32,
+    autograd) F.linear as before.  The modules stay exactly `nn.Linear` (the reference's
+    `find_layers` tests `type(module) in [nn.Linear]`, wanda_pruner.py:33-52), with the same
+    parameters and state_dict keys; deep copies (the loop's lanes) carry the method along."""
+    import types
+    n = 0
+    for mod in model.modules():
+        if type(mod) is torch.nn.Linear and "forward" not in mod.__dict__:
+            mod.forward = types.MethodType(_pinned_forward, mod)
+            mod._ecoflap_pinned = True
+            n += 1
+    return n

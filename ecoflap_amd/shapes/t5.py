@@ -354,6 +354,9 @@ class T5(nn.Module):
         if dtype is not None:
             for p in self.t5_model.parameters():
                 p.data = p.data.to(dtype)
+        if next(self.parameters()).device.type == "cuda":
+            from .fused import pin_linears
+            pin_linears(self)   # 16-bit GPU Linears: one pinned hipBLASLt solution per weight shape
 
     @property
     def device(self):

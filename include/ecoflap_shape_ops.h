@@ -8,6 +8,7 @@
  */
 #ifndef ECOFLAP_SHAPE_OPS_H
 #define ECOFLAP_SHAPE_OPS_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -58,6 +59,31 @@ int ecoflap_multi_copy(const ecoflap_copy_item* items, int n, void* stream);
 /* Bitwise comparison of up to ECOFLAP_COPY_MAX_ITEMS pairs (dst vs src of each item) in one
  * launch: *mismatch_flag |= 1 when any byte differs (the caller zeroes it). */
 int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_flag, void* stream);
+
+/* ---- libecoflap_gemm.so (csrc/gemm_pinned.hip) ------------------------------------------------
+ * y[M,N] = x[M,K] W[N,K]^T (+ bias[N]) for F16 / BF16 (fp32 accumulation) through hipBLASLt with
+ * the SOLUTION PINNED per (N, K, dtype, bias): chosen once, among the library's own candidates
+ * for the weight shape, by name (no Stream-K, no K split over workgroups) and by measurement
+ * (same bits on a repeated call; the probe problem alone == its first and its last slot of a
+ * 16-slot problem), then used for every M.  One macro tile and one K order for every row count:
+ * a row's result does not depend on how many rows travel with it (batch invariance by
+ * construction) nor on an environment variable of the library.
+ *
+ * ecoflap_linear_pinned_plan: choose (or look up) the plan; allocates and synchronises, so call
+ *   it OUTSIDE stream capture, before the first ecoflap_linear_pinned of that weight shape.
+ *   m_probe = a row count the loop uses (the check runs at m_probe and 16 * m_probe).
+ *   -> 0 and the solution's index / name, or ECOFLAP_ESIZE when no candidate survived (the
+ *   caller then keeps the framework's GEMM for this shape).
+ * ecoflap_linear_pinned: the product; launches only (safe under capture once planned and once
+ *   called with this M).  bias_dtype: dtype code of `bias` (the Linear's own dtype, or F32).
+ *   workspace: >= 64 MiB recommended (the pinned solutions take none or little).
+ *   ECOFLAP_EMODE: no plan for this weight shape. */
+int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias,
+                               int bias_dtype, int* solution_index, int* tried, int* passed,
+                               float* best_us, char* name_out, int name_len);
+int ecoflap_linear_pinned(const void* x, const void* w, const void* bias, void* y, int64_t M,
+                          int64_t N, int64_t K, int dtype, int bias_dtype, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,98 @@
+"""The forward's 16-bit Linears through hipBLASLt with the solution pinned per weight shape
+(csrc/gemm_pinned.hip, shapes/fused.py): for every Linear shape of BLIP-2 the chosen solution is
+not a Stream-K / split-K kernel, equals torch's GEMM to rounding, gives the SAME BITS for a row
+whatever travels with it (1, 8 x 257 or 16 x 8 x 257 rows; first, middle, last slot) and on every
+repeated call — with TENSILE_STREAMK_DATA_PARALLEL removed from the environment of a child
+process too (the property must not hang on that variable)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [  # (N, K, dtype, bias, rows of one evaluation)
+    (4224, 1408, torch.float16, False, 8 * 257), (1408, 1408, torch.float16, True, 8 * 257),
+    (6144, 1408, torch.float16, True, 8 * 257), (1408, 6144, torch.float16, True, 8 * 257),
+    (6144, 1408, torch.float16, True, 257),            # batch size 1: the launchers' default
+    (2048, 2048, torch.bfloat16, False, 8 * 48), (5120, 2048, torch.bfloat16, False, 8 * 48),
+    (2048, 5120, torch.bfloat16, False, 8 * 48), (32128, 2048, torch.bfloat16, False, 8 * 16),
+]
+
+
+def _check_all():
+    from ecoflap_amd.shapes import fused
+    import torch.nn.functional as F
+    report = {}
+    for N, K, dt, has_bias, rows in SHAPES:
+        g = torch.Generator(device="cuda").manual_seed(N + K + rows)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dt)
+        b = (torch.randn(N, device="cuda", generator=g) * 0.1).to(dt) if has_bias else None
+        x = (torch.randn(16 * rows, K, device="cuda", generator=g) * 0.7).to(dt)
+        with torch.no_grad():
+            whole = fused.linear(x, w, b)
+            assert whole is not None, (N, K, "no pinned solution")
+            plan = fused.pinned_plans()[(N, K, dt, has_bias)]
+            assert plan["index"] >= 0 and plan["passed"] >= 1
+            name = plan["name"]
+            assert "_SK" not in name or "_SK0" in name, name
+            ref = F.linear(x.float(), w.float(), None if b is None else b.float())
+            err = (whole.float() - ref).abs().max().item()
+            assert err <= 2e-2 * ref.abs().max().item() + 1e-3, (N, K, err)
+            for slot in (0, 7, 15):
+                alone = fused.linear(x[slot * rows:(slot + 1) * rows].contiguous(), w, b)
+                assert torch.equal(alone, whole[slot * rows:(slot + 1) * rows]), (N, K, rows, slot)
+            one = fused.linear(x[5:6].contiguous(), w, b)                # a single row
+            assert torch.equal(one, whole[5:6]), (N, K, "one row")
+            for _ in range(50):
+                assert torch.equal(fused.linear(x, w, b), whole), (N, K, "not repeatable")
+            # under graph capture (planned, and this M seen eagerly)
+            xs = x[:rows].contiguous()
+            eager = fused.linear(xs, w, b)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cap = fused.linear(xs, w, b)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(cap, eager)
+        report[f"{N}x{K} {str(dt).split('.')[-1]} bias={has_bias}"] = plan
+    return report
+
+
+def test_pinned_linears_are_batch_invariant_and_repeatable():
+    report = _check_all()
+    for k, v in report.items():
+        print(k, v["index"], f"{v['us_at_16_slots']:.0f} us", v["name"][:100])
+
+
+def test_pinned_linears_do_not_depend_on_the_stream_k_variable():
+    """A child process with TENSILE_STREAMK_DATA_PARALLEL=0 (the package's `setdefault` leaves an
+    explicit value alone): torch's own GEMM choice is then neither batch invariant nor
+    reproducible (blas_guard.py), the pinned solutions still are."""
+    env = dict(os.environ, TENSILE_STREAMK_DATA_PARALLEL="0", ECOFLAP_ALLOW_STREAMK="1")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "import torch, ecoflap_amd, os; assert os.environ['TENSILE_STREAMK_DATA_PARALLEL'] == '0';"
+            "import test_pinned_gemm as t; t._check_all(); print('ok')") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_pinned_model_forward_equals_its_own_batched_form_at_batch_size_1():
+    """BLIP-2's ViT-g block at batch size 1 (257 rows per evaluation): 16 concatenated evaluations
+    == each alone, bit for bit — the case torch's own GEMM choice fails (different kernels for
+    M = 257 and M = 4112) and the reason the loop could not share evaluations at batch size 1."""
+    from ecoflap_amd.shapes.eva_vit import Block, half_linear_weights
+    from ecoflap_amd.shapes.fused import pin_linears
+    torch.manual_seed(0)
+    blk = Block(1408, 16, 6144).cuda().eval()
+    half_linear_weights(blk)
+    assert pin_linears(blk) == 4
+    x = (torch.randn(16, 257, 1408, device="cuda") * 0.5).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        whole = blk(x, None)
+        for i in (0, 9, 15):
+            assert torch.equal(blk(x[i:i + 1], None), whole[i:i + 1]), i
