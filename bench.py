@@ -699,6 +699,9 @@ def main():
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
             "suffix_forward": (_compact_stats(snap.stats) if hasattr(snap, "stats") else None),
+            # the forward's 16-bit Linears: hipBLASLt solution pinned per weight shape
+            # (csrc/gemm_pinned.hip); an index means something only with the library version
+            "pinned_gemm": _pinned_gemm_report(),
         },
     }
     if k1:
@@ -763,6 +766,21 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _pinned_gemm_report():
+    try:
+        from ecoflap_amd.shapes import fused
+        import torch.version
+        return {"hip": getattr(torch.version, "hip", None),
+                "shapes": {f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}":
+                           (None if v is None else {"used": v["used"], "index": v["index"],
+                                                    "us_at_16_slots": round(v["us_at_16_slots"], 1),
+                                                    "library_first_choice_us": round(v["library_first_choice_us"], 1),
+                                                    "name": v["name"][:96]})
+                           for k, v in fused.pinned_plans().items()}}
+    except Exception as e:          # never let the report break the line
+        return {"error": repr(e)}
 
 
 def _blocked(loss_fn):

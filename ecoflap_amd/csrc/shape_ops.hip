@@ -41,9 +41,13 @@ __global__ __launch_bounds__(256) void t5_rmsnorm_kernel(const void* __restrict_
 //   s = dtype(x + r)            (written to sum_out)      [if r != nullptr]
 //   y = dtype((float(s) - mean) * rstd * w + b)
 // one wave per row, two passes over registers' worth of row (mean, then centred squares).
+// rb != nullptr: r is a Linear's output WITHOUT its bias (the pinned GEMM of csrc/gemm_pinned.hip
+// has no bias epilogue on gfx950) and rb that bias: r' = dtype(r + rb) first, the value the
+// Linear itself would have returned from a rounded accumulator.
 template <int DT>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const void* __restrict__ x,
                                                             const void* __restrict__ r,
+                                                            const void* __restrict__ rb,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ b,
                                                             void* __restrict__ sum_out,
@@ -62,6 +66,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const void* __restri
         if (r) {
             float g[N];
             Vec<DT>::unpack(ld16(r, base + v), g);
+            if (rb) {
+                float h[N];
+                Vec<DT>::unpack(ld16(rb, v), h);
+#pragma unroll
+                for (int i = 0; i < N; ++i) g[i] = Vec<DT>::round(g[i] + h[i]);
+            }
 #pragma unroll
             for (int i = 0; i < N; ++i) f[i] = Vec<DT>::round(f[i] + g[i]);
             st16(sum_out, base + v, Vec<DT>::pack(f));
@@ -171,23 +181,98 @@ extern "C" int ecoflap_gelu_mul(const void* a, const void* b, void* y, int64_t n
     return 0;
 }
 
-extern "C" int ecoflap_add_layernorm(const void* x, const void* residual, const float* w,
-                                     const float* b, void* sum_out, void* y, int64_t rows,
-                                     int64_t d, float eps, int dtype, void* stream) {
+static int add_layernorm_impl(const void* x, const void* residual, const void* residual_bias,
+                              const float* w, const float* b, void* sum_out, void* y, int64_t rows,
+                              int64_t d, float eps, int dtype, void* stream) {
     if (dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) return ECOFLAP_EDTYPE;
     if (rows < 0 || d <= 0 || (d % 8) != 0) return ECOFLAP_ESIZE;
     if (rows == 0) return 0;
-    if (!x || !w || !b || !y || (residual && !sum_out)) return ECOFLAP_ENULL;
+    if (!x || !w || !b || !y || (residual && !sum_out) || (residual_bias && !residual)) return ECOFLAP_ENULL;
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ECOFLAP_F16)
-        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_F16>), grid, blk, 0, s, x, residual, w, b,
+        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_F16>), grid, blk, 0, s, x, residual, residual_bias, w, b,
                            sum_out, y, rows, d, eps);
     else
-        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_BF16>), grid, blk, 0, s, x, residual, w, b,
+        hipLaunchKernelGGL((add_layernorm_kernel<ECOFLAP_BF16>), grid, blk, 0, s, x, residual, residual_bias, w, b,
                            sum_out, y, rows, d, eps);
     ECO_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ecoflap_add_layernorm(const void* x, const void* residual, const float* w,
+                                     const float* b, void* sum_out, void* y, int64_t rows,
+                                     int64_t d, float eps, int dtype, void* stream) {
+    return add_layernorm_impl(x, residual, nullptr, w, b, sum_out, y, rows, d, eps, dtype, stream);
+}
+
+extern "C" int ecoflap_add_bias_layernorm(const void* x, const void* residual, const void* residual_bias,
+                                          const float* w, const float* b, void* sum_out, void* y,
+                                          int64_t rows, int64_t d, float eps, int dtype, void* stream) {
+    return add_layernorm_impl(x, residual, residual_bias, w, b, sum_out, y, rows, d, eps, dtype, stream);
+}
+
+// The two other consumers of a Linear output that arrives WITHOUT its bias (see above):
+//   bias_gelu:          y = dtype(gelu(dtype(a + bias)))          (EVA Mlp: act(fc1(x)), erf GELU)
+//   bias_add_residual:  y = dtype(x + dtype(m + bias))            (EVA Block: x + fc2(...))
+// a, m, x, y: [rows, d]; bias: [d]; all of `dtype`.  One pass each — the pass the activation /
+// the residual add makes anyway.
+template <int DT, bool GELU>
+__global__ __launch_bounds__(256) void bias_consumer_kernel(const void* __restrict__ a,
+                                                            const void* __restrict__ bias,
+                                                            const void* __restrict__ x,
+                                                            void* __restrict__ y, int64_t nvec,
+                                                            int64_t vpr) {
+    constexpr int N = Vec<DT>::N;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        float fa[N], fb[N];
+        Vec<DT>::unpack(ld16(a, v), fa);
+        Vec<DT>::unpack(ld16(bias, v % vpr), fb);
+#pragma unroll
+        for (int i = 0; i < N; ++i) fa[i] = Vec<DT>::round(fa[i] + fb[i]);
+        if (GELU) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                fa[i] = 0.5f * fa[i] * (1.0f + erff(fa[i] * 0.70710678118654752440f));
+        } else {
+            float fx[N];
+            Vec<DT>::unpack(ld16(x, v), fx);
+#pragma unroll
+            for (int i = 0; i < N; ++i) fa[i] = fx[i] + fa[i];
+        }
+        st16(y, v, Vec<DT>::pack(fa));
+    }
+}
+
+static int bias_consumer(const void* a, const void* bias, const void* x, void* y, int64_t rows, int64_t d,
+                         int dtype, bool gelu, void* stream) {
+    if (dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) return ECOFLAP_EDTYPE;
+    if (rows < 0 || d <= 0 || (d % 8) != 0) return ECOFLAP_ESIZE;
+    if (rows == 0) return 0;
+    if (!a || !bias || !y || (!gelu && !x)) return ECOFLAP_ENULL;
+    if (!aligned16(a) || !aligned16(bias) || !aligned16(y) || (x && !aligned16(x))) return ECOFLAP_EALIGN;
+    const int64_t vpr = d / 8, nvec = rows * vpr;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define BC_GO(DT_, G_) hipLaunchKernelGGL((bias_consumer_kernel<DT_, G_>), grid, blk, 0, s, a, bias, x, y, nvec, vpr)
+    if (dtype == ECOFLAP_F16) { if (gelu) BC_GO(ECOFLAP_F16, true); else BC_GO(ECOFLAP_F16, false); }
+    else { if (gelu) BC_GO(ECOFLAP_BF16, true); else BC_GO(ECOFLAP_BF16, false); }
+#undef BC_GO
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_bias_gelu(const void* a, const void* bias, void* y, int64_t rows, int64_t d,
+                                 int dtype, void* stream) {
+    return bias_consumer(a, bias, nullptr, y, rows, d, dtype, true, stream);
+}
+
+extern "C" int ecoflap_bias_add_residual(const void* x, const void* m, const void* bias, void* y,
+                                         int64_t rows, int64_t d, int dtype, void* stream) {
+    return bias_consumer(m, bias, x, y, rows, d, dtype, false, stream);
 }
 
 extern "C" int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias,

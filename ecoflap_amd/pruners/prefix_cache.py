@@ -895,7 +895,7 @@ class PrefixCachedLoss:
         when the shared pass's input now holds the k results; False: the caller takes the
         per-evaluation path (first-use check failed, or the Linear cannot be patched)."""
         import torch.nn.functional as F
-        from ..shapes.fused import linear_or_torch
+        from ..shapes.fused import linear as _pinned, linear_or_torch
         k = len(evals)
         name = self._pair_name
         if not name.endswith(".weight"):
@@ -926,8 +926,16 @@ class PrefixCachedLoss:
         def per_slot(x):
             if x.shape[0] != k * B:              # the Linear's input must carry the k slots in front
                 raise _NotBatchLeading()
-            # (the module's own dispatch: the pinned hipBLASLt solution of this weight shape where
-            # the shape modules use it, shapes/fused.py — the very call an evaluation makes alone)
+            # the module's own dispatch, slot by slot: the pinned hipBLASLt solution of this weight
+            # shape where the shape modules use it (shapes/fused.py) — the very call an evaluation
+            # makes alone —, with the bias left to the consuming op exactly when the module's own
+            # forward would leave it there (`_defer_bias`): same kernel, same roundings, same bits
+            if mod.bias is not None and mod.__dict__.get("_defer_bias"):
+                ys = [_pinned(x[i * B:(i + 1) * B], thetas[i], None) for i in range(k)]
+                if all(y is not None for y in ys):
+                    mod._bias_pending = True
+                    return torch.cat(ys, 0)
+            mod._bias_pending = False
             return torch.cat([_linear(x[i * B:(i + 1) * B], thetas[i], mod.bias)
                               for i in range(k)], 0)
 

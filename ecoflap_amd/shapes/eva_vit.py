@@ -69,24 +69,33 @@ class Block(nn.Module):
 
     def forward(self, x, rel_pos_bias=None):
         from . import fused          # one kernel per norm (and residual add) on the GPU loop
+        # (a Linear pinned by fused.pin_linears may return its output WITHOUT the bias; the op
+        # that consumes the output adds it: `take_pending_bias` says whether this call did)
         h = fused.add_layernorm(x, None, self.norm1)
         a = self.attn(fused.trace("00_ln1", self.norm1(x) if h is None else h[1]),
                       rel_pos_bias=rel_pos_bias)
-        fused.trace("03_proj", a)
-        h = fused.add_layernorm(x, a, self.norm2)
+        pb = fused.take_pending_bias(self.attn.proj)
+        h = fused.add_layernorm(x, a, self.norm2, residual_bias=pb)
         if h is None:
+            if pb is not None:
+                a = a + pb
             x = x + a
             h2 = self.norm2(x)
         else:
             x, h2 = h
-        if fused.TRACE_SINK is None:
-            return x + self.mlp(h2)
+        fused.trace("03_proj", a)            # (without the proj bias when it was deferred)
         fused.trace("04_x1", x)
         fused.trace("05_ln2", h2)
-        m = fused.trace("06_fc1", self.mlp.fc1(h2))          # Mlp.forward, op by op
-        m = fused.trace("07_gelu", self.mlp.act(m))
-        m = fused.trace("08_fc2", self.mlp.fc2(m))
-        return fused.trace("09_out", x + m)
+        m = self.mlp.fc1(h2)                 # Mlp.forward, op by op
+        b1 = fused.take_pending_bias(self.mlp.fc1)
+        fused.trace("06_fc1", m)
+        m = fused.bias_gelu(m, b1) if b1 is not None else self.mlp.act(m)
+        fused.trace("07_gelu", m)
+        m = self.mlp.fc2(m)
+        b2 = fused.take_pending_bias(self.mlp.fc2)
+        fused.trace("08_fc2", m)
+        out = fused.bias_add_residual(x, m, b2) if b2 is not None else x + m
+        return fused.trace("09_out", out)
 
 
 class PatchEmbed(nn.Module):

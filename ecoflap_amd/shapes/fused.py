@@ -29,6 +29,9 @@ def _get():
         lib.ecoflap_t5_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
         lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
+        lib.ecoflap_add_bias_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
+        lib.ecoflap_bias_gelu.argtypes = [vp, vp, vp, i64, i64, ci, vp]
+        lib.ecoflap_bias_add_residual.argtypes = [vp, vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_vit_attention.argtypes = [vp, vp, i64, i64, i64, i64, f32, ci, vp]
         lib.ecoflap_multi_copy.argtypes = [vp, ci, vp]
@@ -78,9 +81,10 @@ def gelu_mul(a, b):
     return y
 
 
-def add_layernorm(x, residual, norm):
+def add_layernorm(x, residual, norm, residual_bias=None):
     """nn.LayerNorm `norm` (fp32 parameters) of the 16-bit activation x — or of x + residual,
     also returned — as ONE kernel instead of cast / layer_norm / cast (/ add).
+    residual_bias: the bias of the Linear that produced `residual` WITHOUT it (`take_pending_bias`).
     -> (x_plus_residual or x, normalised) or None (caller runs the torch ops)."""
     if (torch.is_grad_enabled() or x.device.type != "cuda"
             or x.dtype not in (torch.float16, torch.bfloat16) or x.shape[-1] % 8 != 0
@@ -89,11 +93,23 @@ def add_layernorm(x, residual, norm):
         return None
     if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
         return None
+    if residual_bias is not None and (residual is None or residual_bias.dtype != x.dtype
+                                      or residual_bias.numel() != x.shape[-1]
+                                      or not residual_bias.is_contiguous()):
+        return None
     xc = x if x.is_contiguous() else x.contiguous()
     rc_ = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
     y = torch.empty_like(xc)
     s = torch.empty_like(xc) if rc_ is not None else xc
     d = xc.shape[-1]
+    if residual_bias is not None:
+        rc = _get().ecoflap_add_bias_layernorm(
+            xc.data_ptr(), rc_.data_ptr(), residual_bias.data_ptr(), norm.weight.data_ptr(),
+            norm.bias.data_ptr(), s.data_ptr(), y.data_ptr(),
+            xc.numel() // d, d, float(norm.eps), _hip.DTYPE_CODE[xc.dtype], _stream())
+        if rc != 0:
+            raise _hip.EcoflapHipError(f"ecoflap_add_bias_layernorm failed ({rc})")
+        return s, y
     rc = _get().ecoflap_add_layernorm(
         xc.data_ptr(), None if rc_ is None else rc_.data_ptr(), norm.weight.data_ptr(),
         norm.bias.data_ptr(), None if rc_ is None else s.data_ptr(), y.data_ptr(),
@@ -227,17 +243,25 @@ def _gemm_lib():
             lib = ctypes.CDLL(path)
             vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
             ip, fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
-            lib.ecoflap_linear_pinned_plan.argtypes = [i64, i64, i64, ci, ci, ci, ip, ip, ip, fp, ctypes.c_char_p, ci]
+            lib.ecoflap_linear_pinned_plan.argtypes = [i64, i64, i64, ci, ci, ci, ip, ip, ip, fp, fp,
+                                                       ctypes.c_char_p, ci]
             lib.ecoflap_linear_pinned.argtypes = [vp, vp, vp, vp, i64, i64, i64, ci, ci, vp, sz, vp]
             _gemm = lib
     return _gemm
 
 
+def _pinned_wanted(plan):
+    """A weight shape with a surviving solution runs it — always: which kernel a Linear runs must
+    not hang on a timing (two ranks of one job have to make the same choice).  The times are
+    recorded for the reader (`pinned_plans`)."""
+    return True
+
+
 def pinned_plans():
-    """{(N, K, dtype, has_bias): {"index", "name", "tried", "passed", "us"} or None} chosen so far
-    (bench.py and the run summaries record it: a solution index means something only together with
-    the library version)."""
-    return {k[:4]: v for k, v in _plans.items()}
+    """{(N, K, dtype): {"index", "name", "tried", "passed", "us_at_16_slots"} or None} chosen so
+    far, with `used` = what the policy makes of it now (bench.py and the run summaries record it: a
+    solution index means something only together with the library version)."""
+    return {k: (None if v is None else dict(v, used=_pinned_wanted(v))) for k, v in _plans.items()}
 
 
 def linear(x, weight, bias):
@@ -256,7 +280,8 @@ def linear(x, weight, bias):
         x = x.to(weight.dtype)
     elif torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != weight.dtype:
         return None
-    if bias is not None and (bias.dtype not in (weight.dtype, torch.float32) or not bias.is_contiguous()):
+    if bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous()
+                             or bias.data_ptr() % 16):
         return None
     lib = _gemm_lib()
     if lib is False:
@@ -272,26 +297,30 @@ def linear(x, weight, bias):
         return None
     dt = _hip.DTYPE_CODE[weight.dtype]
     bdt = _hip.DTYPE_CODE[bias.dtype] if bias is not None else 0
-    key = (N, K, weight.dtype, bias is not None, bdt)
+    key = (N, K, weight.dtype)              # one plan per weight shape (the bias is added around the GEMM)
     if key not in _plans:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError(f"pinned GEMM: the solution for weight shape {N}x{K} has not been "
                                "chosen yet and a graph is being captured (run the stage eagerly once)")
         idx, tried, passed = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
-        us = ctypes.c_float(0.0)
+        us, default_us = ctypes.c_float(0.0), ctypes.c_float(0.0)
         name = ctypes.create_string_buffer(512)
         torch.cuda.synchronize()
         rc = lib.ecoflap_linear_pinned_plan(M if M <= 4096 else 2048, N, K, dt, int(bias is not None), bdt,
                                             ctypes.byref(idx), ctypes.byref(tried), ctypes.byref(passed),
-                                            ctypes.byref(us), name, 512)
+                                            ctypes.byref(us), ctypes.byref(default_us), name, 512)
         if rc == 0:
-            _plans[key] = {"index": idx.value, "name": name.value.decode(errors="replace"),
-                           "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value}
+            import os
+            plan = {"index": idx.value, "name": name.value.decode(errors="replace"),
+                    "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value,
+                    "library_first_choice_us": default_us.value}
+            _plans[key] = plan
         elif rc == -3:          # ECOFLAP_ESIZE: no candidate survived; torch's GEMM for this shape
             _plans[key] = None
         else:
             raise _hip.EcoflapHipError(f"ecoflap_linear_pinned_plan failed ({rc}) for {N}x{K}")
-    if _plans[key] is None:
+    plan = _plans[key]
+    if plan is None or not _pinned_wanted(plan):
         return None
     stream = torch.cuda.current_stream()
     ws = _gemm_ws.get(stream.cuda_stream)
@@ -315,7 +344,50 @@ def linear_or_torch(x, weight, bias):
 
 
 def _pinned_forward(self, x):
+    # a Linear whose parent block adds the bias in the op that consumes the output anyway
+    # (`_defer_bias`, set by pin_linears): the pinned solutions have no bias epilogue on gfx950,
+    # and a bias prefill + beta = 1 costs a write and a read of the output (measured: -10 % on
+    # the bench).  The flag the consumer reads says whether THIS call left the bias out.
+    if self.bias is not None and self.__dict__.get("_defer_bias"):
+        y = linear(x, self.weight, None)
+        if y is not None:
+            self._bias_pending = True
+            return y
+    self._bias_pending = False
     return linear_or_torch(x, self.weight, self.bias)
+
+
+def take_pending_bias(mod):
+    """The bias `mod`'s last forward left out (None: the output carries it already)."""
+    if mod.__dict__.get("_bias_pending"):
+        mod._bias_pending = False
+        return mod.bias
+    return None
+
+
+def bias_gelu(a, bias):
+    """gelu(a + bias) for a Linear output without its bias (erf GELU; 16-bit, GPU)."""
+    ac = a if a.is_contiguous() else a.contiguous()
+    y = torch.empty_like(ac)
+    d = ac.shape[-1]
+    rc = _get().ecoflap_bias_gelu(ac.data_ptr(), bias.data_ptr(), y.data_ptr(), ac.numel() // d, d,
+                                  _hip.DTYPE_CODE[ac.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_bias_gelu failed ({rc})")
+    return y
+
+
+def bias_add_residual(x, m, bias):
+    """x + (m + bias) for a Linear output m without its bias (16-bit, GPU)."""
+    xc = x if x.is_contiguous() else x.contiguous()
+    mc = m if m.is_contiguous() else m.contiguous()
+    y = torch.empty_like(xc)
+    d = xc.shape[-1]
+    rc = _get().ecoflap_bias_add_residual(xc.data_ptr(), mc.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                          xc.numel() // d, d, _hip.DTYPE_CODE[xc.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_bias_add_residual failed ({rc})")
+    return y
 
 
 def pin_linears(model):
@@ -325,10 +397,15 @@ def pin_linears(model):
     `find_layers` tests `type(module) in [nn.Linear]`, wanda_pruner.py:33-52), with the same
     parameters and state_dict keys; deep copies (the loop's lanes) carry the method along."""
     import types
+    from .eva_vit import Block
     n = 0
     for mod in model.modules():
         if type(mod) is torch.nn.Linear and "forward" not in mod.__dict__:
             mod.forward = types.MethodType(_pinned_forward, mod)
             mod._ecoflap_pinned = True
             n += 1
+        if isinstance(mod, Block):          # its forward adds these biases in the consuming op
+            for lin in (mod.attn.proj, mod.mlp.fc1, mod.mlp.fc2):
+                if lin.bias is not None:
+                    lin._defer_bias = True
     return n

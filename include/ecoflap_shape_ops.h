@@ -34,6 +34,21 @@ int ecoflap_add_layernorm(const void* x, const void* residual, const float* w, c
                           void* sum_out, void* y, int64_t rows, int64_t d, float eps, int dtype,
                           void* stream);
 
+/* The consumers of a Linear output that arrives WITHOUT its bias (the pinned GEMM solutions of
+ * libecoflap_gemm.so have no bias epilogue on gfx950: every bias-epilogue solution of the library
+ * there is a Stream-K kernel).  `bias` is the Linear's own bias, [d] of `dtype`; the first step is
+ * always dtype(out + bias), the value the Linear would have returned from a rounded accumulator:
+ *   ecoflap_add_bias_layernorm: ecoflap_add_layernorm with residual' = dtype(residual + bias)
+ *   ecoflap_bias_gelu:          y = dtype(gelu(dtype(a + bias)))        (erf GELU, EVA Mlp)
+ *   ecoflap_bias_add_residual:  y = dtype(x + dtype(m + bias))          (EVA Block's MLP residual) */
+int ecoflap_add_bias_layernorm(const void* x, const void* residual, const void* residual_bias,
+                               const float* w, const float* b, void* sum_out, void* y,
+                               int64_t rows, int64_t d, float eps, int dtype, void* stream);
+int ecoflap_bias_gelu(const void* a, const void* bias, void* y, int64_t rows, int64_t d, int dtype,
+                      void* stream);
+int ecoflap_bias_add_residual(const void* x, const void* m, const void* bias, void* y, int64_t rows,
+                              int64_t d, int dtype, void* stream);
+
 /* EVA attention bias (eva_vit.py:123-128): qkv += cat(q_bias, zeros, v_bias).to(dtype), in
  * place; qkv: [rows, 3*dim] of `dtype` (F16/BF16), q_bias / v_bias: [dim] float; dim % 8 == 0. */
 int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias, int64_t rows,
@@ -72,15 +87,21 @@ int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_f
  * ecoflap_linear_pinned_plan: choose (or look up) the plan; allocates and synchronises, so call
  *   it OUTSIDE stream capture, before the first ecoflap_linear_pinned of that weight shape.
  *   m_probe = a row count the loop uses (the check runs at m_probe and 16 * m_probe).
- *   -> 0 and the solution's index / name, or ECOFLAP_ESIZE when no candidate survived (the
- *   caller then keeps the framework's GEMM for this shape).
+ *   -> 0 and the solution's index / name (the lowest index among the survivors within 25 % of the
+ *   fastest: the choice must not hang on timing noise), its time on the 16-slot problem (best_us)
+ *   and, for the record, the time of the library's own first choice on the same data
+ *   (default_us), or ECOFLAP_ESIZE when no candidate survived.
+ *   Bias: gfx950's bias-epilogue solutions are all Stream-K kernels, so the solution is a
+ *   no-bias one; ecoflap_linear_pinned with a bias prefills the output with the bias rows and runs
+ *   beta = 1 (one extra write + read of the output); the shape modules instead leave the bias to
+ *   the op that consumes the output (ecoflap_add_bias_layernorm / _bias_gelu / _bias_add_residual).
  * ecoflap_linear_pinned: the product; launches only (safe under capture once planned and once
  *   called with this M).  bias_dtype: dtype code of `bias` (the Linear's own dtype, or F32).
  *   workspace: >= 64 MiB recommended (the pinned solutions take none or little).
  *   ECOFLAP_EMODE: no plan for this weight shape. */
 int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias,
                                int bias_dtype, int* solution_index, int* tried, int* passed,
-                               float* best_us, char* name_out, int name_len);
+                               float* best_us, float* default_us, char* name_out, int name_len);
 int ecoflap_linear_pinned(const void* x, const void* w, const void* bias, void* y, int64_t M,
                           int64_t N, int64_t K, int dtype, int bias_dtype, void* workspace,
                           size_t workspace_bytes, void* stream);

@@ -57,3 +57,32 @@ def test_clip_closure_drives_stage1_like_the_reference(golden_dir):
     assert [table[k] for k in sorted(table)] == [float(v) for v in g["table_vals"]]
     for k, v in model.state_dict().items():
         assert np.array_equal(to_bits(v).ravel(), g[f"final::{k}"].ravel()), k
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_clip_closure_stage1_hip_equals_oracle(golden_dir):
+    """The same closure on the GPU: `LayerSparsity` on the HIP kernels vs the oracle's arithmetic
+    on the same GPU forward and the same draws (g15's model, images and prompts): loss table,
+    sparsity table and the drifted weights bit for bit."""
+    from ecoflap_amd import hip
+    res = []
+    for backend in (hip.HipKernels(), OracleKernels()):
+        g, model, batches, closure = _setup(golden_dir)
+        model = model.cuda()
+        batches = [{k: v.cuda() for k, v in b.items()} for b in batches]
+        mapping = {k: k for k, v in model.named_parameters() if v.dim() == 2 and "visual" in k}
+        np.random.seed(5)
+        ls = LayerSparsity(model, batches, lambda m, b, dev: closure(m, b, torch.device("cuda")),
+                           12, 0.5, 0.7, "MEZO-GradOnly_sum", 1, 1e-3, mapping, kernels=backend,
+                           z_source="torch", batch_len_fn=lambda b: b["label"].shape[0])
+        table = ls.return_sparsity()
+        torch.cuda.synchronize()
+        res.append((table, ls.loss_table.copy(), {k: v.detach().cpu() for k, v in model.state_dict().items()}))
+    (t_hip, l_hip, w_hip), (t_ref, l_ref, w_ref) = res
+    assert t_hip == t_ref and len(set(t_hip.values())) > 1
+    assert np.array_equal(l_hip, l_ref)
+    for k in w_hip:
+        assert torch.equal(w_hip[k], w_ref[k]), k

@@ -25,6 +25,7 @@ SHAPES = [  # (N, K, dtype, bias, rows of one evaluation)
 
 
 def _check_all():
+    os.environ["ECOFLAP_PINNED_GEMM"] = "1"      # every shape through its pinned solution, fast or not
     from ecoflap_amd.shapes import fused
     import torch.nn.functional as F
     report = {}
@@ -36,7 +37,7 @@ def _check_all():
         with torch.no_grad():
             whole = fused.linear(x, w, b)
             assert whole is not None, (N, K, "no pinned solution")
-            plan = fused.pinned_plans()[(N, K, dt, has_bias)]
+            plan = fused.pinned_plans()[(N, K, dt)]
             assert plan["index"] >= 0 and plan["passed"] >= 1
             name = plan["name"]
             assert "_SK" not in name or "_SK0" in name, name
@@ -66,7 +67,8 @@ def _check_all():
 def test_pinned_linears_are_batch_invariant_and_repeatable():
     report = _check_all()
     for k, v in report.items():
-        print(k, v["index"], f"{v['us_at_16_slots']:.0f} us", v["name"][:100])
+        print(k, v["index"], f"{v['us_at_16_slots']:.0f} us (library's first choice: "
+              f"{v['library_first_choice_us']:.0f} us)", v["name"][:100])
 
 
 def test_pinned_linears_do_not_depend_on_the_stream_k_variable():
@@ -81,12 +83,13 @@ def test_pinned_linears_do_not_depend_on_the_stream_k_variable():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
 
 
-def test_pinned_model_forward_equals_its_own_batched_form_at_batch_size_1():
+def test_pinned_model_forward_equals_its_own_batched_form_at_batch_size_1(monkeypatch):
     """BLIP-2's ViT-g block at batch size 1 (257 rows per evaluation): 16 concatenated evaluations
     == each alone, bit for bit — the case torch's own GEMM choice fails (different kernels for
     M = 257 and M = 4112) and the reason the loop could not share evaluations at batch size 1."""
     from ecoflap_amd.shapes.eva_vit import Block, half_linear_weights
     from ecoflap_amd.shapes.fused import pin_linears
+    monkeypatch.setenv("ECOFLAP_PINNED_GEMM", "1")
     torch.manual_seed(0)
     blk = Block(1408, 16, 6144).cuda().eval()
     half_linear_weights(blk)
@@ -96,3 +99,57 @@ def test_pinned_model_forward_equals_its_own_batched_form_at_batch_size_1():
         whole = blk(x, None)
         for i in (0, 9, 15):
             assert torch.equal(blk(x[i:i + 1], None), whole[i:i + 1]), i
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_bias_consumers_equal_the_torch_op_chains(dt):
+    """The ops that add a deferred Linear bias (shapes/fused.py): `dtype(a + bias)` first — the
+    Linear's own output from a rounded accumulator — then the consumer, against the same chain in
+    torch ops: residual add and LayerNorm input bit for bit, GELU within one unit in the last
+    place of the 16-bit result (two erf implementations)."""
+    from ecoflap_amd.shapes import fused
+    torch.manual_seed(3)
+    rows, d = 1031, 1408
+    a = (torch.randn(rows, d, device="cuda") * 0.7).to(dt)
+    x = (torch.randn(rows, d, device="cuda") * 0.7).to(dt)
+    b = (torch.randn(d, device="cuda") * 0.2).to(dt)
+    with torch.no_grad():
+        assert torch.equal(fused.bias_add_residual(x, a, b), x + (a + b))
+        got = fused.bias_gelu(a, b).float()
+        want = torch.nn.functional.gelu((a + b).float()).to(dt).float()
+        ulp = torch.finfo(dt).eps * want.abs().clamp_min(torch.finfo(dt).tiny)
+        assert ((got - want).abs() <= ulp).all()
+        norm = torch.nn.LayerNorm(d, eps=1e-6).cuda()
+        torch.nn.init.normal_(norm.weight, 1.0, 0.1)
+        torch.nn.init.normal_(norm.bias, 0.0, 0.1)
+        with torch.autocast("cuda", dtype=dt):
+            s, y = fused.add_layernorm(x, a, norm, residual_bias=b)
+            s2, y2 = fused.add_layernorm(x, a + b, norm)
+        assert torch.equal(s, x + (a + b)) and torch.equal(s, s2) and torch.equal(y, y2)
+
+
+def test_pinned_block_defers_its_biases_and_tracks_the_plain_block(monkeypatch):
+    """An EVA block with pinned Linears (biases of proj / fc1 / fc2 added by the consuming ops)
+    against the same block on torch's own GEMMs: same function to 16-bit rounding noise; and the
+    owning-Linear per-slot form of the loop gives the bits of the module's own forward."""
+    import copy
+    from ecoflap_amd.shapes.eva_vit import Block, half_linear_weights
+    from ecoflap_amd.shapes.fused import pin_linears
+    torch.manual_seed(1)
+    plain = Block(1408, 16, 6144).cuda().eval()
+    for p in plain.parameters():
+        if p.dim() == 1:
+            torch.nn.init.normal_(p, 0.0, 0.05)          # non-zero biases
+    plain.norm1.weight.data.add_(1.0)
+    plain.norm2.weight.data.add_(1.0)
+    half_linear_weights(plain)
+    pinned = copy.deepcopy(plain)
+    assert pin_linears(pinned) == 4
+    assert all(m.__dict__.get("_defer_bias") for m in (pinned.attn.proj, pinned.mlp.fc1, pinned.mlp.fc2))
+    x = (torch.randn(8, 257, 1408, device="cuda") * 0.5).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        y0 = plain(x, None).float()
+        y1 = pinned(x, None).float()
+    assert not any(m.__dict__.get("_bias_pending") for m in pinned.modules())      # every bias was taken
+    err = (y0 - y1).abs().max().item()
+    assert err <= 2e-2 * y0.abs().max().item(), err
