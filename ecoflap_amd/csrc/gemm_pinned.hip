@@ -13,8 +13,9 @@
 //     over workgroups (`_GSU<n>`, n > 1): their summation order depends on the grid;
 //   * the rest is MEASURED: the large problem twice (same bits?) and the probe problem alone
 //     against its first and last slot of the large one (same bits at every row offset?);
-//   * the fastest survivor is pinned: every later call of that weight shape, whatever M, runs
-//     that solution index (re-bound to the problem size through getAlgosFromIndex).
+//   * the survivor with the lowest solution index is pinned (no timing enters the choice: two
+//     ranks of one job must make the same one): every later call of that weight shape, whatever
+//     M, runs that solution index (re-bound to the problem size through getAlgosFromIndex).
 // With one macro tile and one K order for every M the result of a row no longer depends on how
 // many rows travel with it: batch invariance by construction, no environment variable involved.
 //
@@ -266,9 +267,8 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
                 fprintf(stderr, "[gemm_pinned]   %zu of %d distinct solutions are name-clean and support both sizes\n",
                         timed.size(), plan.tried);
             // stage 2: every survivor (fastest first, at most 8) is MEASURED: batch invariant and
-            // repeatable?  Among those that are, the choice must not hang on timing noise — two
-            // processes of one job (data-parallel ranks) have to pin the same solution —: the
-            // LOWEST INDEX whose time is within 25 % of the fastest.
+            // repeatable?  Among those that are, the choice must not hang on a timing — two
+            // processes of one job (data-parallel ranks) have to pin the same solution.
             std::vector<Timed> good;
             for (size_t c = 0; ok && c < timed.size() && c < 8; ++c) {
                 const Timed& t = timed[c];
@@ -290,11 +290,10 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
             }
             plan.passed = (int)good.size();
             if (!good.empty()) {
-                float fastest = good[0].us;
-                for (const Timed& t : good) fastest = t.us < fastest ? t.us : fastest;
-                const Timed* pick = nullptr;
+                // the LOWEST INDEX among the survivors: no timing enters the choice
+                const Timed* pick = &good[0];
                 for (const Timed& t : good)
-                    if (t.us <= 1.25f * fastest && (!pick || t.index < pick->index)) pick = &t;
+                    if (t.index < pick->index) pick = &t;
                 plan.index = pick->index;
                 plan.name = pick->name;
                 plan.best_us = pick->us;

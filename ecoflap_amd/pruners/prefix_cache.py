@@ -931,7 +931,7 @@ class PrefixCachedLoss:
             # makes alone —, with the bias left to the consuming op exactly when the module's own
             # forward would leave it there (`_defer_bias`): same kernel, same roundings, same bits
             if mod.bias is not None and mod.__dict__.get("_defer_bias"):
-                ys = [_pinned(x[i * B:(i + 1) * B], thetas[i], None) for i in range(k)]
+                ys = [_pinned(x[i * B:(i + 1) * B], thetas[i], None, library_bias=mod.bias) for i in range(k)]
                 if all(y is not None for y in ys):
                     mod._bias_pending = True
                     return torch.cat(ys, 0)

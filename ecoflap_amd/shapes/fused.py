@@ -234,7 +234,7 @@ def _gemm_lib():
     if _gemm is None:
         import os
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libecoflap_gemm.so")
-        if os.environ.get("ECOFLAP_PINNED_GEMM", "1") == "0":
+        if os.environ.get("ECOFLAP_PINNED_GEMM", "auto") == "0":
             _gemm = False
         elif not os.path.exists(path):
             raise _hip.EcoflapHipError(f"{path} is not built (make -C ecoflap_amd/csrc); set "
@@ -250,35 +250,48 @@ def _gemm_lib():
     return _gemm
 
 
-def _pinned_wanted(plan):
-    """A weight shape with a surviving solution runs it — always: which kernel a Linear runs must
-    not hang on a timing (two ranks of one job have to make the same choice).  The times are
-    recorded for the reader (`pinned_plans`)."""
-    return True
+def _pinned_wanted(plan, has_bias):
+    """Policy (deterministic: a bitwise property of the library's own choice, never a timing).
+    ECOFLAP_PINNED_GEMM=1: every weight shape with a surviving solution runs it — reproducibility
+    and batch invariance of the 16-bit Linears then hang on nothing outside this build, at a
+    price (one 256 x 256 macro tile for every row count: FlanT5's small decoder GEMMs lose a
+    third, a single evaluation's ViT-g GEMMs fill 60 % of the chip).  Default: the pinned
+    solution where the framework's own GEMM choice is NOT batch invariant for this weight shape
+    at the row counts the loop uses (measured when the shape first comes up: 16 slots against one
+    alone) — on gfx950 the ViT-g shapes at batch size 1, where the library picks different kernels
+    for 257 and 4112 rows; everything else stays on the library's choice under blas_guard's rules."""
+    import os
+    return (os.environ.get("ECOFLAP_PINNED_GEMM", "auto") == "1"
+            or not plan["library_batch_invariant"].get(has_bias, True))
 
 
 def pinned_plans():
     """{(N, K, dtype): {"index", "name", "tried", "passed", "us_at_16_slots"} or None} chosen so
     far, with `used` = what the policy makes of it now (bench.py and the run summaries record it: a
     solution index means something only together with the library version)."""
-    return {k: (None if v is None else dict(v, used=_pinned_wanted(v))) for k, v in _plans.items()}
+    return {k: (None if v is None else dict(
+        v, used={("bias" if hb else "no bias"): _pinned_wanted(v, hb) for hb in v["library_batch_invariant"]}))
+        for k, v in _plans.items()}
 
 
-def linear(x, weight, bias):
+def linear(x, weight, bias, library_bias=None):
     """F.linear(x, weight, bias) for a 16-bit weight on the GPU without autograd, through the
     pinned hipBLASLt solution of this weight shape -> tensor, or None (caller runs F.linear:
     CPU, fp32 weights, autograd on, no surviving candidate, ECOFLAP_PINNED_GEMM=0).  Under
-    autocast to the weight's dtype the input is cast as autocast would cast it."""
+    autocast to the weight's dtype the input is cast as autocast would cast it.
+    library_bias: the bias the caller's fallback `F.linear` would carry (a Linear that leaves its
+    bias to the consuming op asks with bias=None; whether the LIBRARY's choice is batch invariant
+    has to be probed with the epilogue it would really run)."""
     if (torch.is_grad_enabled() or weight.device.type != "cuda"
             or weight.dtype not in (torch.float16, torch.bfloat16) or weight.dim() != 2
             or not weight.is_contiguous()):
         return None
     if x.dtype != weight.dtype:
-        if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == weight.dtype
+        if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == weight.dtype
                 and x.is_floating_point()):
             return None
         x = x.to(weight.dtype)
-    elif torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() != weight.dtype:
+    elif torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != weight.dtype:
         return None
     if bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous()
                              or bias.data_ptr() % 16):
@@ -310,17 +323,34 @@ def linear(x, weight, bias):
                                             ctypes.byref(idx), ctypes.byref(tried), ctypes.byref(passed),
                                             ctypes.byref(us), ctypes.byref(default_us), name, 512)
         if rc == 0:
-            import os
-            plan = {"index": idx.value, "name": name.value.decode(errors="replace"),
-                    "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value,
-                    "library_first_choice_us": default_us.value}
-            _plans[key] = plan
+            _plans[key] = {"index": idx.value, "name": name.value.decode(errors="replace"),
+                           "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value,
+                           "library_first_choice_us": default_us.value, "library_batch_invariant": {}}
         elif rc == -3:          # ECOFLAP_ESIZE: no candidate survived; torch's GEMM for this shape
             _plans[key] = None
         else:
             raise _hip.EcoflapHipError(f"ecoflap_linear_pinned_plan failed ({rc}) for {N}x{K}")
     plan = _plans[key]
-    if plan is None or not _pinned_wanted(plan):
+    if plan is None:
+        return None
+    lib_bias = bias if bias is not None else library_bias
+    has_lib_bias = lib_bias is not None
+    if has_lib_bias not in plan["library_batch_invariant"]:
+        # what the framework's own choice does with this weight (and this epilogue) at the row
+        # counts the loop uses: 16 slots against one alone, bit for bit
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"pinned GEMM: weight shape {N}x{K} has not been probed yet and a "
+                               "graph is being captured (run the stage eagerly once)")
+        import torch.nn.functional as F
+        mp = M if M <= 4096 else 2048
+        with torch.no_grad():
+            xs = x2[:mp].contiguous()
+            alone = F.linear(xs, weight, lib_bias)
+            many = F.linear(xs.repeat(16, 1), weight, lib_bias)
+            plan["library_batch_invariant"][has_lib_bias] = bool(
+                torch.equal(many[:mp], alone) and torch.equal(many[15 * mp:], alone))
+            del alone, many
+    if not _pinned_wanted(plan, has_lib_bias):
         return None
     stream = torch.cuda.current_stream()
     ws = _gemm_ws.get(stream.cuda_stream)
@@ -349,7 +379,7 @@ def _pinned_forward(self, x):
     # and a bias prefill + beta = 1 costs a write and a read of the output (measured: -10 % on
     # the bench).  The flag the consumer reads says whether THIS call left the bias out.
     if self.bias is not None and self.__dict__.get("_defer_bias"):
-        y = linear(x, self.weight, None)
+        y = linear(x, self.weight, None, library_bias=self.bias)
         if y is not None:
             self._bias_pending = True
             return y

@@ -87,8 +87,8 @@ int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_f
  * ecoflap_linear_pinned_plan: choose (or look up) the plan; allocates and synchronises, so call
  *   it OUTSIDE stream capture, before the first ecoflap_linear_pinned of that weight shape.
  *   m_probe = a row count the loop uses (the check runs at m_probe and 16 * m_probe).
- *   -> 0 and the solution's index / name (the lowest index among the survivors within 25 % of the
- *   fastest: the choice must not hang on timing noise), its time on the 16-slot problem (best_us)
+ *   -> 0 and the solution's index / name (the lowest index among the survivors: no timing enters
+ *   the choice), its time on the 16-slot problem (best_us)
  *   and, for the record, the time of the library's own first choice on the same data
  *   (default_us), or ECOFLAP_ESIZE when no candidate survived.
  *   Bias: gfx950's bias-epilogue solutions are all Stream-K kernels, so the solution is a
