@@ -616,8 +616,10 @@ class _StageOneMixin:
         if hasattr(loss_func, "stats"):
             self.stage_stats["stage1"]["suffix_forward"] = {
                 k: v for k, v in loss_func.stats.items() if k != "stages_not_batch_invariant"}
-            self.stage_stats["stage1"]["stages_not_batch_invariant"] = len(
-                loss_func.stats.get("stages_not_batch_invariant", []))
+            names = sorted(loss_func.stats.get("stages_not_batch_invariant", []))
+            self.stage_stats["stage1"]["stages_not_batch_invariant"] = len(names)
+            self.stage_stats["stage1"]["stages_not_batch_invariant_names"] = names[:4] + names[-2:] \
+                if len(names) > 6 else names
         self.layer_sparsity_engine = ls
         return out
 

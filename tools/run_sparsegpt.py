@@ -24,4 +24,9 @@ zeros = sum(int((v == 0).sum()) for v in blocks.values())
 total = sum(v.numel() for v in blocks.values())
 print(json.dumps({"wall_seconds": time.time() - t0, "pruned_fraction": zeros / total,
                   "stage_stats": getattr(harness.main, "last_stage_stats", None),
-                  "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}, default=str))
+                  "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
+                  # which weight shapes ran a pinned hipBLASLt solution (shapes/fused.py)
+                  "pinned_gemm": {f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}": (None if v is None else {
+                      "used": v["used"], "index": v["index"], "name": v["name"][:96]})
+                      for k, v in __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).pinned_plans().items()}},
+                 default=str))
