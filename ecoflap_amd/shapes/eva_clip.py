@@ -37,8 +37,10 @@ class EVACLIP(nn.Module):
         out_dim = out_dim or vit_kwargs.get("embed_dim", 768)
         self.visual = _VisualTower(out_dim, **vit_kwargs)
         g = torch.Generator().manual_seed(1234)
-        cls = F.normalize(torch.randn(out_dim, num_classes, generator=g), dim=0)
-        self.register_buffer("classifier", cls)
+        # (drawn on the CPU whatever the default device: a CPU generator cannot feed a GPU draw,
+        # and the classifier must be the same on either device)
+        cls = F.normalize(torch.randn(out_dim, num_classes, generator=g, device="cpu"), dim=0)
+        self.register_buffer("classifier", cls.to(self.visual.cls_token.device))
 
     @property
     def device(self):

@@ -451,6 +451,28 @@ def test_colsqnorm_vs_oracle(kern, oracle, dt, tokens, cols):
     np.testing.assert_allclose(s.cpu().numpy(), s_ref.numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("dt,tokens,cols", [(torch.float16, 8 * 257, 1408), (torch.float16, 8 * 257, 6144),
+                                            (torch.bfloat16, 8 * 48, 5120), (torch.bfloat16, 16, 2048),
+                                            (torch.float32, 8 * 197, 768)])
+def test_colsqnorm_vs_the_reference_chain_on_this_gpu(kern, dt, tokens, cols):
+    """The reference's own op chain (wanda_pruner.py:71-84) evaluated by torch ON THE GPU — what a
+    reference run on this device computes — against the HIP kernel: both are float reductions in
+    their own order, so they agree to rounding (1e-5; the oracle, which restates torch's CPU
+    order, sits at the same distance from both)."""
+    torch.manual_seed(tokens + cols)
+    ref = torch.zeros(cols, device="cuda")
+    got = torch.zeros(cols, device="cuda")
+    n = 0
+    for _ in range(3):
+        x = (torch.randn(tokens, cols, device="cuda") * 1.3).to(dt)
+        inp = x.t().type(torch.float32)
+        ref *= n / (n + 8)
+        ref += torch.norm(inp, p=2, dim=1) ** 2 / (n + 8)
+        kern.colsqnorm_accum(got, x, n, 8)
+        n += 8
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+
+
 def test_colsqnorm_single_launch_shared_workspace_and_device_count(kern, oracle):
     """K6 is one launch: the last row chunk of a column block finishes the update (ticket counters
     at the head of the workspace, self-resetting).  A sequence of differently shaped inputs through
