@@ -109,17 +109,19 @@ bool grid_dependent_sum(const std::string& name) {
            name.find("StreamK") != std::string::npos;
 }
 
-__global__ void fill_pattern_kernel(uint16_t* p, int64_t n, int64_t period, uint32_t salt, int dt) {
+__global__ void fill_pattern_kernel(void* p_, int64_t n, int64_t period, uint32_t salt, int dt) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t h = (uint32_t)(i % period) * 2654435761u + salt;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         const float v = ((float)(h & 0xffff) / 65536.0f - 0.5f) * 0.25f;     // [-1/8, 1/8)
-        if (dt == ECOFLAP_F16) {
+        if (dt == ECOFLAP_F32) {
+            ((float*)p_)[i] = v;
+        } else if (dt == ECOFLAP_F16) {
             const _Float16 hv = (_Float16)v;
-            p[i] = __builtin_bit_cast(uint16_t, hv);
+            ((uint16_t*)p_)[i] = __builtin_bit_cast(uint16_t, hv);
         } else {
-            p[i] = (uint16_t)(__float_as_uint(v) >> 16);                    // bf16, truncated
+            ((uint16_t*)p_)[i] = (uint16_t)(__float_as_uint(v) >> 16);     // bf16, truncated
         }
     }
 }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void bias_fill_kernel(u32x4* __restrict__ y, c
 extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias,
                                           int bias_dtype, int* solution_index, int* tried, int* passed,
                                           float* best_us, float* default_us, char* name_out, int name_len) {
-    if ((dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) || m_probe <= 0 || N <= 0 || K <= 0) return ECOFLAP_EDTYPE;
+    if (!dtype_ok(dtype) || m_probe <= 0 || N <= 0 || K <= 0) return ECOFLAP_EDTYPE;
     std::lock_guard<std::mutex> lock(g_mu);
     (void)has_bias; (void)bias_dtype;
     const Key key{N, K, dtype, 0, 0};          // one plan per weight shape: the bias is not the GEMM's business
@@ -167,8 +169,8 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
         if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return ECOFLAP_ELIBRARY;
         constexpr int SLOTS = 16;
         const int64_t Mb = SLOTS * m_probe;
-        const size_t es = 2, ws_bytes = (size_t)64 << 20;
-        uint16_t *x = nullptr, *w = nullptr, *bias = nullptr, *yb = nullptr, *yb2 = nullptr, *ya = nullptr;
+        const size_t es = dtype == ECOFLAP_F32 ? 4 : 2, ws_bytes = (size_t)64 << 20;
+        char *x = nullptr, *w = nullptr, *bias = nullptr, *yb = nullptr, *yb2 = nullptr, *ya = nullptr;
         void* ws = nullptr;
         bool ok = hipMalloc(&x, Mb * K * es) == hipSuccess && hipMalloc(&w, N * K * es) == hipSuccess &&
                   hipMalloc(&bias, N * 4) == hipSuccess && hipMalloc(&yb, Mb * N * es) == hipSuccess &&
@@ -180,9 +182,7 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
             // every slot of the large input is a copy of the probe input (period = its size)
             hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, x, Mb * K, m_probe * K, 17u, dtype);
             hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, w, N * K, N * K, 91u, dtype);
-            // (N * 4 bytes of small bf16 patterns: a sane vector read as f16, bf16 or f32)
-            hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, s, bias, N * 2, N * 2, 5u,
-                               dtype == ECOFLAP_F16 && bias_dtype != ECOFLAP_F32 ? ECOFLAP_F16 : ECOFLAP_BF16);
+            hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, s, bias, N, N, 5u, dtype);
             Problem big, small;
             ok = big.make(Mb, N, K, dtype, false, 0, nullptr) && small.make(m_probe, N, K, dtype, false, 0, nullptr);
             // candidates: the library's heuristic list for the LARGE problem first (its own ranking),
@@ -208,7 +208,7 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
                     fprintf(stderr, "[gemm_pinned] %ldx%ld dt %d bias %d: %d heuristic + %zu library candidates\n",
                             (long)N, (long)K, dtype, has_bias, n_cand, all.size());
             }
-            std::vector<uint16_t> h_alone((size_t)m_probe * N), h_big((size_t)m_probe * N);
+            std::vector<char> h_alone((size_t)m_probe * N * es), h_big((size_t)m_probe * N * es);
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0);
             (void)hipEventCreate(&e1);
@@ -277,12 +277,12 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
                 if (run(small, t.small, x, w, ya, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
                 if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
                 bool same = true;
-                (void)hipMemcpy(h_alone.data(), ya, h_alone.size() * es, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h_alone.data(), ya, h_alone.size(), hipMemcpyDeviceToHost);
                 for (int slot : {0, SLOTS - 1}) {
-                    (void)hipMemcpy(h_big.data(), yb + (size_t)slot * m_probe * N, h_big.size() * es, hipMemcpyDeviceToHost);
-                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size() * es) == 0;
-                    (void)hipMemcpy(h_big.data(), yb2 + (size_t)slot * m_probe * N, h_big.size() * es, hipMemcpyDeviceToHost);
-                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size() * es) == 0;
+                    (void)hipMemcpy(h_big.data(), yb + (size_t)slot * m_probe * N * es, h_big.size(), hipMemcpyDeviceToHost);
+                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size()) == 0;
+                    (void)hipMemcpy(h_big.data(), yb2 + (size_t)slot * m_probe * N * es, h_big.size(), hipMemcpyDeviceToHost);
+                    same = same && memcmp(h_big.data(), h_alone.data(), h_big.size()) == 0;
                 }
                 if (debug_on())
                     fprintf(stderr, "[gemm_pinned]   %s %7.1f us  %d %s\n", same ? "PASS" : "fail", t.us, t.index, t.name.c_str());
@@ -325,7 +325,8 @@ extern "C" int ecoflap_linear_pinned(const void* x, const void* w, const void* b
                                      size_t workspace_bytes, void* stream) {
     if (M <= 0) return 0;
     if (!x || !w || !y) return ECOFLAP_ENULL;
-    if (bias && (bias_dtype != dtype || N % 8 != 0)) return ECOFLAP_EDTYPE;   // the bias rows are y's own dtype
+    const int per_vec = dtype == ECOFLAP_F32 ? 4 : 8;
+    if (bias && (bias_dtype != dtype || N % per_vec != 0)) return ECOFLAP_EDTYPE;   // the bias rows are y's own dtype
     std::lock_guard<std::mutex> lock(g_mu);
     const Key key{N, K, dtype, 0, 0};
     auto it = g_plans.find(key);
@@ -342,7 +343,7 @@ extern "C" int ecoflap_linear_pinned(const void* x, const void* w, const void* b
     }
     hipStream_t s = (hipStream_t)stream;
     if (bias) {
-        const int64_t nvec_row = N / 8, nvec = M * nvec_row;
+        const int64_t nvec_row = N / per_vec, nvec = M * nvec_row;
         int64_t blocks = (nvec + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (u32x4*)y, (const u32x4*)bias, nvec,

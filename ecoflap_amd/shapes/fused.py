@@ -275,7 +275,7 @@ def pinned_plans():
 
 
 def linear(x, weight, bias, library_bias=None):
-    """F.linear(x, weight, bias) for a 16-bit weight on the GPU without autograd, through the
+    """F.linear(x, weight, bias) for a 16-bit (or, outside autocast, fp32) weight on the GPU without autograd, through the
     pinned hipBLASLt solution of this weight shape -> tensor, or None (caller runs F.linear:
     CPU, fp32 weights, autograd on, no surviving candidate, ECOFLAP_PINNED_GEMM=0).  Under
     autocast to the weight's dtype the input is cast as autocast would cast it.
@@ -283,10 +283,14 @@ def linear(x, weight, bias, library_bias=None):
     bias to the consuming op asks with bias=None; whether the LIBRARY's choice is batch invariant
     has to be probed with the epilogue it would really run)."""
     if (torch.is_grad_enabled() or weight.device.type != "cuda"
-            or weight.dtype not in (torch.float16, torch.bfloat16) or weight.dim() != 2
+            or weight.dtype not in (torch.float16, torch.bfloat16, torch.float32) or weight.dim() != 2
             or not weight.is_contiguous()):
         return None
-    if x.dtype != weight.dtype:
+    if weight.dtype == torch.float32:
+        # (the fp32 Q-Former: outside autocast only — under autocast torch runs the Linear in 16 bits)
+        if torch.is_autocast_enabled("cuda") or x.dtype != torch.float32:
+            return None
+    elif x.dtype != weight.dtype:
         if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == weight.dtype
                 and x.is_floating_point()):
             return None
@@ -300,7 +304,8 @@ def linear(x, weight, bias, library_bias=None):
     if lib is False:
         return None
     N, K = weight.shape
-    if x.shape[-1] != K or K % 8 != 0 or N % 8 != 0:
+    per_vec = 4 if weight.dtype == torch.float32 else 8
+    if x.shape[-1] != K or K % per_vec != 0 or N % per_vec != 0:
         return None
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():

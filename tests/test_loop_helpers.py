@@ -373,3 +373,37 @@ def test_k6_collector_refuses_inputs_written_in_place_before_the_flush():
     col.flush()
     col.end_sample()
     assert col.private_workspace() and col.ws.numel() == 24
+
+
+def test_pinned_linear_plumbing_on_the_cpu():
+    """`pin_linears` (shapes/fused.py): the modules stay exactly nn.Linear (the reference's
+    find_layers tests the type), a CPU forward is F.linear bit for bit, a deep copy's forward is
+    bound to the COPY (the loop's lanes are deep copies with their own weights), the EVA block marks
+    its biased Linears for the deferred-bias path and a forward leaves no bias pending."""
+    import copy
+    from ecoflap_amd.pruners.wanda import find_layers
+    from ecoflap_amd.shapes import fused
+    from ecoflap_amd.shapes.eva_vit import Block
+    torch.manual_seed(0)
+    blk = Block(32, 4, 64).eval()
+    for p in blk.parameters():
+        if p.dim() == 1:
+            torch.nn.init.normal_(p, 0.0, 0.1)
+    x = torch.randn(2, 5, 32)
+    with torch.no_grad():
+        want = blk(x, None)
+    assert fused.pin_linears(blk) == 4 and fused.pin_linears(blk) == 0          # idempotent
+    assert sorted(find_layers(blk)) == ["attn.proj", "attn.qkv", "mlp.fc1", "mlp.fc2"]
+    assert all(type(m) is torch.nn.Linear for m in find_layers(blk).values())
+    assert [bool(m.__dict__.get("_defer_bias")) for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2)] \
+        == [False, True, True, True]
+    with torch.no_grad():
+        assert torch.equal(blk(x, None), want)
+        assert fused.linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias) is None       # CPU: the caller's F.linear
+    assert not any(m.__dict__.get("_bias_pending") for m in blk.modules())
+    twin = copy.deepcopy(blk)
+    assert twin.mlp.fc1.forward.__self__ is twin.mlp.fc1
+    with torch.no_grad():
+        twin.mlp.fc1.weight.mul_(2.0)
+        assert torch.equal(blk(x, None), want) and not torch.equal(twin(x, None), want)
+    assert set(blk.state_dict()) == set(Block(32, 4, 64).state_dict())

@@ -21,6 +21,9 @@ SHAPES = [  # (N, K, dtype, bias, rows of one evaluation)
     (6144, 1408, torch.float16, True, 257),            # batch size 1: the launchers' default
     (2048, 2048, torch.bfloat16, False, 8 * 48), (5120, 2048, torch.bfloat16, False, 8 * 48),
     (2048, 5120, torch.bfloat16, False, 8 * 48), (32128, 2048, torch.bfloat16, False, 8 * 16),
+    # the fp32 Q-Former (32 queries per image; cross-attention keys from 257 image tokens)
+    (768, 768, torch.float32, True, 8 * 32), (3072, 768, torch.float32, True, 8 * 32),
+    (768, 3072, torch.float32, True, 32), (768, 1408, torch.float32, True, 8 * 257),
 ]
 
 
@@ -36,6 +39,9 @@ def _check_all():
         x = (torch.randn(16 * rows, K, device="cuda", generator=g) * 0.7).to(dt)
         with torch.no_grad():
             whole = fused.linear(x, w, b)
+            if whole is None and dt == torch.float32:
+                report[f"{N}x{K} float32 bias={has_bias}"] = None      # no clean fp32 solution: recorded
+                continue
             assert whole is not None, (N, K, "no pinned solution")
             plan = fused.pinned_plans()[(N, K, dt)]
             assert plan["index"] >= 0 and plan["passed"] >= 1
@@ -43,7 +49,8 @@ def _check_all():
             assert "_SK" not in name or "_SK0" in name, name
             ref = F.linear(x.float(), w.float(), None if b is None else b.float())
             err = (whole.float() - ref).abs().max().item()
-            assert err <= 2e-2 * ref.abs().max().item() + 1e-3, (N, K, err)
+            tol = 1e-5 if dt == torch.float32 else 2e-2
+            assert err <= tol * ref.abs().max().item() + (1e-5 if dt == torch.float32 else 1e-3), (N, K, err)
             for slot in (0, 7, 15):
                 alone = fused.linear(x[slot * rows:(slot + 1) * rows].contiguous(), w, b)
                 assert torch.equal(alone, whole[slot * rows:(slot + 1) * rows]), (N, K, rows, slot)
@@ -67,6 +74,9 @@ def _check_all():
 def test_pinned_linears_are_batch_invariant_and_repeatable():
     report = _check_all()
     for k, v in report.items():
+        if v is None:
+            print(k, "no pinned solution (the library's choice stays)")
+            continue
         print(k, v["index"], f"{v['us_at_16_slots']:.0f} us (library's first choice: "
               f"{v['library_first_choice_us']:.0f} us)", v["name"][:100])
 
