@@ -32,6 +32,7 @@ def _get():
         lib.ecoflap_add_bias_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_bias_gelu.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_bias_add_residual.argtypes = [vp, vp, vp, vp, i64, i64, ci, vp]
+        lib.ecoflap_linear_f32.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
         lib.ecoflap_qkv_bias_add.argtypes = [vp, vp, vp, i64, i64, ci, vp]
         lib.ecoflap_vit_attention.argtypes = [vp, vp, i64, i64, i64, i64, f32, ci, vp]
         lib.ecoflap_multi_copy.argtypes = [vp, ci, vp]
@@ -316,6 +317,13 @@ def linear(x, weight, bias, library_bias=None):
     dt = _hip.DTYPE_CODE[weight.dtype]
     bdt = _hip.DTYPE_CODE[bias.dtype] if bias is not None else 0
     key = (N, K, weight.dtype)              # one plan per weight shape (the bias is added around the GEMM)
+    if key not in _plans and weight.dtype == torch.float32:
+        # no library solution to pin (gfx950: every fp32 solution is a Stream-K kernel): the
+        # build's own MFMA GEMM, for the shapes it tiles
+        _plans[key] = ({"index": -1, "name": "gemm_f32_nt_kernel (csrc/gemm_f32.hip)", "tried": 0,
+                        "passed": 0, "us_at_16_slots": 0.0, "library_first_choice_us": 0.0,
+                        "library_batch_invariant": {}}
+                       if (N % 128 == 0 and K % 32 == 0) else None)
     if key not in _plans:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError(f"pinned GEMM: the solution for weight shape {N}x{K} has not been "
@@ -352,12 +360,26 @@ def linear(x, weight, bias, library_bias=None):
             xs = x2[:mp].contiguous()
             alone = F.linear(xs, weight, lib_bias)
             many = F.linear(xs.repeat(16, 1), weight, lib_bias)
+            # fp32 (the Q-Former): the library treats the LAST rows of a problem differently at any
+            # size, which the loop's padding slots absorb at no cost; what the padding cannot absorb
+            # is a difference in the other slots (batch size 1)
+            last = 7 if weight.dtype == torch.float32 else 15
             plan["library_batch_invariant"][has_lib_bias] = bool(
-                torch.equal(many[:mp], alone) and torch.equal(many[15 * mp:], alone))
+                torch.equal(many[:mp], alone) and torch.equal(many[last * mp:(last + 1) * mp], alone))
             del alone, many
     if not _pinned_wanted(plan, has_lib_bias):
         return None
     stream = torch.cuda.current_stream()
+    if weight.dtype == torch.float32:
+        if bias is not None and (bias.data_ptr() % 4 or not bias.is_contiguous()):
+            return None
+        y = torch.empty((M, N), dtype=torch.float32, device=weight.device)
+        rc = _get().ecoflap_linear_f32(x2.data_ptr(), weight.data_ptr(),
+                                       None if bias is None else bias.data_ptr(), y.data_ptr(), M, N, K,
+                                       ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise _hip.EcoflapHipError(f"ecoflap_linear_f32 failed ({rc}) for [{M}, {K}] x {N}x{K}")
+        return y.view(*x.shape[:-1], N)
     ws = _gemm_ws.get(stream.cuda_stream)
     if ws is None or ws.device != weight.device:
         ws = _gemm_ws[stream.cuda_stream] = torch.empty(64 << 20, dtype=torch.uint8, device=weight.device)

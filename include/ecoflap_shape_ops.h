@@ -75,6 +75,14 @@ int ecoflap_multi_copy(const ecoflap_copy_item* items, int n, void* stream);
  * launch: *mismatch_flag |= 1 when any byte differs (the caller zeroes it). */
 int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_flag, void* stream);
 
+/* y[M,N] = x[M,K] W[N,K]^T (+ bias[N]) in fp32 on v_mfma_f32_32x32x2_f32 (csrc/gemm_f32.hip): the
+ * forward's fp32 Linears (BLIP-2's Q-Former), for which hipBLASLt has only Stream-K solutions on
+ * gfx950.  Every output element is one k-ordered fp32 fma chain, the bias added last: a row's
+ * result does not depend on the rows that travel with it.  N % 128 == 0, K % 32 == 0 (else
+ * ECOFLAP_ESIZE: the caller keeps the framework's GEMM); x, w 16-byte aligned. */
+int ecoflap_linear_f32(const float* x, const float* w, const float* bias, float* y, int64_t M,
+                       int64_t N, int64_t K, void* stream);
+
 /* ---- libecoflap_gemm.so (csrc/gemm_pinned.hip) ------------------------------------------------
  * y[M,N] = x[M,K] W[N,K]^T (+ bias[N]) for F16 / BF16 (fp32 accumulation) through hipBLASLt with
  * the SOLUTION PINNED per (N, K, dtype, bias): chosen once, among the library's own candidates

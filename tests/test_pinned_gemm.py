@@ -163,3 +163,34 @@ def test_pinned_block_defers_its_biases_and_tracks_the_plain_block(monkeypatch):
     assert not any(m.__dict__.get("_bias_pending") for m in pinned.modules())      # every bias was taken
     err = (y0 - y1).abs().max().item()
     assert err <= 2e-2 * y0.abs().max().item(), err
+
+
+def test_f32_mfma_gemm_is_exact_to_rounding_batch_invariant_and_repeatable(monkeypatch):
+    """csrc/gemm_f32.hip (the Q-Former's fp32 Linears: no library solution to pin on gfx950):
+    equals torch's fp32 GEMM to fp32 rounding, a row's result is the same bits alone, in a ragged
+    problem and in a 16-slot one, and on every repeated call; shapes it does not tile fall back."""
+    from ecoflap_amd.shapes import fused
+    import torch.nn.functional as F
+    monkeypatch.setenv("ECOFLAP_PINNED_GEMM", "1")
+    for N, K, rows in [(768, 768, 8 * 32), (3072, 768, 32), (768, 3072, 8 * 32), (768, 1408, 257), (2048, 768, 33)]:
+        g = torch.Generator(device="cuda").manual_seed(N + K + rows)
+        w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+        b = torch.randn(N, device="cuda", generator=g) * 0.1
+        x = torch.randn(16 * rows, K, device="cuda", generator=g)
+        with torch.no_grad():
+            whole = fused.linear(x, w, b)
+            assert whole is not None and whole.dtype == torch.float32
+            ref = F.linear(x.double(), w.double(), b.double())
+            err = (whole.double() - ref).abs().max().item()
+            assert err <= 2e-6 * ref.abs().max().item() * (K / 768) ** 0.5 + 1e-6, (N, K, err)
+            for slot in (0, 7, 15):
+                alone = fused.linear(x[slot * rows:(slot + 1) * rows].contiguous(), w, b)
+                assert torch.equal(alone, whole[slot * rows:(slot + 1) * rows]), (N, K, rows, slot)
+            ragged = fused.linear(x[3:3 + 130].contiguous(), w, b)          # 130 rows: a partial tile
+            assert torch.equal(ragged, whole[3:133])
+            nobias = fused.linear(x[:rows].contiguous(), w, None)
+            assert torch.allclose(nobias + b, whole[:rows], rtol=0, atol=1e-6 * float(whole.abs().max()))
+            for _ in range(20):
+                assert torch.equal(fused.linear(x, w, b), whole)
+    with torch.no_grad():                                                   # N % 128 != 0: not tiled
+        assert fused.linear(torch.randn(8, 64, device="cuda"), torch.randn(100, 64, device="cuda"), None) is None
