@@ -402,6 +402,7 @@ def golden_true_width(registry, lavis, only=None):
       t5xl_first       FlanT5-XL width, 2 + 2 blocks, `t5_wanda_pruner`, GradMagAbs_sum (configs[1]'s
                        method), 8 sequences bs 1
       t5xl_zeroth      the same model, MEZO-GradOnly_avg (scripts/t5/ecoflap.py's method)
+      blipvqa          BASELINE configs[4] at its own shape, UPop's pruner as shipped (see below)
     """
     import argparse
     from ecoflap_amd import harness as H
@@ -445,7 +446,7 @@ def golden_true_width(registry, lavis, only=None):
         print(tag, f"{time.time() - t0:.1f} s", len(names), "table entries,", len(out[f"{tag}_losses"]),
               "losses,", len(set(sp.values())), "distinct ratios")
 
-    cases = only or ["vitb16", "blip2_slice", "t5xl_first", "t5xl_zeroth"]
+    cases = only or ["vitb16", "blip2_slice", "t5xl_first", "t5xl_zeroth", "blipvqa"]
     if "vitb16" in cases:
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import run_config
@@ -468,6 +469,41 @@ def golden_true_width(registry, lavis, only=None):
                  t5_pruning_method="none", vit_pruning_method="none", num_samples=4,
                  max_sparsity_per_layer=0.6, num_data_first_stage=4,
                  sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum"))
+    if "blipvqa" in cases:
+        # BASELINE configs[4] at ITS OWN SHAPE: BLIP VQA base (ViT-B/16 @ 480 = 901 tokens,
+        # BERT-base question encoder + answer decoder with cross-attention, fp32, 288 prunable
+        # matrices) through UPop's own pruner AS SHIPPED (stage 1 degenerates to the
+        # uniform ratio; stage 2 = matrix-mode Wanda on the ViT, rows-mode on both BERTs);
+        # 4 samples in one batch keep the CPU replay under a minute
+        sys.path.insert(0, os.path.join(REF, "UPop"))
+        from pruners.wanda_pruner import BLIPBertLayerWandaPruner  # type: ignore
+        from ecoflap_amd.shapes.blip_bert import blip_vqa_base, vqa_batches
+        import time
+        t0 = time.time()
+        tag = "blipvqa"
+        for k in [k for k in out if k.startswith(tag + "_")]:
+            del out[k]
+        np.random.seed(42)
+        torch.manual_seed(31)
+        model = blip_vqa_base().eval()
+        batches = vqa_batches(4, 4, img_size=480, vocab=30524, seed=9)
+        out[f"{tag}_init_sha"] = np.array(sha_of(torch.cat(
+            [v.detach().reshape(-1).view(torch.uint8) for v in model.state_dict().values()])))
+        pruner = BLIPBertLayerWandaPruner(
+            model, batches, bert_prune_spec="0-0.5-1.0-1.0", vit_prune_spec="0-0.5-1.0-1.0",
+            num_samples=4, bert_model_prefix="text_decoder", vit_model_prefix="visual_encoder",
+            sparsity_ratio_granularity="block", max_sparsity_per_layer=0.6,
+            score_method="MEZO-GradOnly_sum", num_data_first_stage=4, task="vqa")
+        model2, sp = pruner.prune()
+        assert not isinstance(sp, dict) or len(sp) == 0            # as shipped: no table (uniform ratio)
+        sd = model2.state_dict()
+        keys = [k for k, v in sd.items() if v.dim() == 2 and (".blocks." in k or ".layer." in k)]
+        out[f"{tag}_final_names"] = np.array(keys)
+        out[f"{tag}_final_sha"] = np.array([sha_of(sd[k]) for k in keys])
+        out[f"{tag}_final_zeros"] = np.array([int((sd[k] == 0).sum()) for k in keys], dtype=np.int64)
+        out[f"{tag}_threads"] = np.array([TRUE_WIDTH_THREADS])
+        print(tag, f"{time.time() - t0:.1f} s", len(keys), "matrices,",
+              sum(int(z > 0) for z in out[f"{tag}_final_zeros"]), "pruned")
     for tag, method in (("t5xl_first", "GradMagAbs_sum"), ("t5xl_zeroth", "MEZO-GradOnly_avg")):
         if tag not in cases:
             continue
