@@ -423,7 +423,10 @@ def take_pending_bias(mod):
 
 
 def bias_gelu(a, bias):
-    """gelu(a + bias) for a Linear output without its bias (erf GELU; 16-bit, GPU)."""
+    """gelu(a + bias) for a Linear output without its bias (erf GELU): one fused kernel for
+    16-bit GPU tensors, the torch op chain otherwise (an fp32 Linear on the build's own GEMM)."""
+    if a.dtype not in (torch.float16, torch.bfloat16) or a.device.type != "cuda" or a.shape[-1] % 8:
+        return torch.nn.functional.gelu(a + bias)
     ac = a if a.is_contiguous() else a.contiguous()
     y = torch.empty_like(ac)
     d = ac.shape[-1]
@@ -435,7 +438,11 @@ def bias_gelu(a, bias):
 
 
 def bias_add_residual(x, m, bias):
-    """x + (m + bias) for a Linear output m without its bias (16-bit, GPU)."""
+    """x + (m + bias) for a Linear output m without its bias: one fused kernel for 16-bit GPU
+    tensors, the torch ops otherwise."""
+    if (x.dtype not in (torch.float16, torch.bfloat16) or x.device.type != "cuda" or x.shape[-1] % 8
+            or m.dtype != x.dtype or m.shape != x.shape):
+        return x + (m + bias)
     xc = x if x.is_contiguous() else x.contiguous()
     mc = m if m.is_contiguous() else m.contiguous()
     y = torch.empty_like(xc)
