@@ -67,6 +67,11 @@ def build_parser():
                    help="loss evaluations of a layer per pass of the batch-invariant suffix (1: one "
                         "suffix per evaluation)")
     p.add_argument("--lanes", type=int, default=2, help="concurrent evaluation lanes (weight replicas)")
+    p.add_argument("--stage1_checkpoint", type=str, default=None,
+                   help="zeroth-order stage 1: file that receives the loss table of the finished "
+                        "layers every 32 layers; a rerun of the same command resumes behind the last "
+                        "saved layer and ends with the same table and weights (the reference has no "
+                        "mid-stage-1 resume)")
     return p
 
 
@@ -164,6 +169,7 @@ def config_dict(args):
         "k1_form": getattr(args, "k1_form", "block"),
         "eval_batch": getattr(args, "eval_batch", 16),
         "n_lanes": getattr(args, "lanes", 2),
+        "stage1_checkpoint": getattr(args, "stage1_checkpoint", None),
     }
     if str(args.pruning_method).startswith("blipt5_"):
         cfg.update(t5_prune_spec=args.t5_prune_spec, vit_prune_spec=args.vit_prune_spec,

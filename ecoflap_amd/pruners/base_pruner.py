@@ -63,7 +63,7 @@ class LayerWiseBasePruner(BasePruner):
                  num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
                  prune_per_model=False, kernels=None, z_source="torch", process_group=None,
                  prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, k1_form="block",
-                 k6_immediate=False, **kwargs):
+                 k6_immediate=False, stage1_checkpoint=None, **kwargs):
         super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
                          importance_scores_cache=importance_scores_cache,
                          keep_indices_or_masks_cache=keep_indices_or_masks_cache,
@@ -94,6 +94,9 @@ class LayerWiseBasePruner(BasePruner):
         # reference does) instead of one launch per block — for models that write their
         # activations in place after the Linear ran (pruners/wanda.py::_K6Collector.add)
         self.k6_immediate = k6_immediate
+        # zeroth-order stage 1: path of a resumable checkpoint of the loss table (LayerSparsity's
+        # `checkpoint_path`)
+        self.stage1_checkpoint = stage1_checkpoint
         self.stage_stats = {}
 
     def model_setup_and_record_attributes(self, model):

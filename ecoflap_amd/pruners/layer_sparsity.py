@@ -76,6 +76,8 @@ class LayerSparsity:
         k1_form="block",
         couple_torch_rng=False,
         grad_graphs=True,
+        checkpoint_path=None,
+        checkpoint_every=32,
     ):
         """Positional arguments are the reference's (:120-135).  Keyword-only extras:
 
@@ -96,6 +98,12 @@ class LayerSparsity:
                       "triple" one fused launch per (layer, batch, noise) unit;
                       "single" three in-place launches per unit, the reference's call pattern.
                       All three are bit-identical.
+        checkpoint_path  zeroth order: every `checkpoint_every` layers the loss table of the layers
+                      done so far goes to this file (the reference has no mid-stage-1
+                      resume although a run takes 100 min); a later run with the same model, batches,
+                      seeds and path picks up behind the last saved layer — the finished layers'
+                      weights get their K1 drift back from the seeds (no forwards) — and ends with
+                      the same table and the same weights, bit for bit.
         """
         self.importance_measure = {}
         self.model = model
@@ -125,6 +133,8 @@ class LayerSparsity:
         # graph and replayed (the eager loop is launch-bound at batch 1: thousands of tiny kernels)
         self.grad_graphs = grad_graphs
         self.process_group = process_group
+        self.checkpoint_path = checkpoint_path
+        self.checkpoint_every = max(1, int(checkpoint_every))
         self.emulate_rank_world = None      # (rank, world): see `_dist`
         assert k1_form in ("units", "block", "triple", "single")
         self.k1_form = k1_form
@@ -230,6 +240,43 @@ class LayerSparsity:
                     accum += lens[bi]
         return batches, units
 
+    # ------------------------------------------------------------------ stage-1 checkpoint
+    def _checkpoint_file(self, rank, world):
+        if not self.checkpoint_path:
+            return None
+        return self.checkpoint_path if world == 1 else f"{self.checkpoint_path}.rank{rank}of{world}"
+
+    def _save_stage1_checkpoint(self, path, done, names, units, table):
+        """Layers [0, done) are finished: their rows of the loss table (this rank's entries) and
+        what identifies the run (layer names, seeds).  One stream sync; written atomically."""
+        import os
+        host = table.detach().float().cpu().numpy() if table is not None else np.zeros(self._table_shape,
+                                                                                       np.float32)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, done=np.array([done]), names=np.array(names), seeds=np.array([u[3] for u in units],
+                 dtype=np.int64), table=host,
+                 table_dtype=np.array(str(table.dtype) if table is not None else "torch.float32"))
+        os.replace(tmp, path)
+        self.stats_checkpoints = getattr(self, "stats_checkpoints", 0) + 1
+
+    def _load_stage1_checkpoint(self, path, names, units, device):
+        """-> (layers already finished, their loss table on `device` or None)"""
+        import os
+        import warnings
+        if not path or not os.path.exists(path):
+            return 0, None
+        with np.load(path, allow_pickle=False) as ck:
+            same = (list(ck["names"]) == list(names)
+                    and np.array_equal(ck["seeds"], np.array([u[3] for u in units], dtype=np.int64))
+                    and tuple(ck["table"].shape) == tuple(self._table_shape))
+            if not same:
+                warnings.warn(f"stage-1 checkpoint {path} belongs to another run (layers / seeds "
+                              "differ): ignored")
+                return 0, None
+            dtype = getattr(torch, str(ck["table_dtype"]).split(".")[-1])
+            table = torch.from_numpy(ck["table"].copy()).to(device=device, dtype=dtype)
+            return int(ck["done"][0]), table
+
     # ------------------------------------------------------------------ zeroth order
     def compute_importance_scores_mezo(self, layer_to_group_mapping):
         t0 = time.time()
@@ -270,9 +317,26 @@ class LayerSparsity:
                         groups[start] = list(range(start, li))
                     start = li
         max_units = getattr(self.kernels, "MAX_UNITS", 32)
+        ck_file = self._checkpoint_file(rank, world)
+        resume_done, resumed = self._load_stage1_checkpoint(ck_file, names, units, device)
+        if resumed is not None:
+            table = resumed
+        self.resumed_layers = resume_done
         for li, (name, param) in enumerate(zip(names, params)):
             home = param.data
             layer_units = by_layer.get(li, [])
+            if li < resume_done:
+                # finished before the interruption: its losses are in the table; its weights get
+                # the drift of its K1 chain back — a function of the original weights and the
+                # seeds alone — without a forward
+                if layer_units:
+                    seeds_ = [units[u][3] for u in layer_units]
+                    none_ = [None] * len(layer_units)
+                    zs_ = None if self.z_source == "philox" else [self._draw_z(sd_, param) for sd_ in seeds_]
+                    self.kernels.zo_perturb_units(home, zo_eps, seeds_, none_, list(none_), zs_)
+                continue
+            if (ck_file and li > resume_done and (li - resume_done) % self.checkpoint_every == 0):
+                self._save_stage1_checkpoint(ck_file, li, names, units, table)
             if begin_layer is not None:
                 begin_layer(name)     # exact suffix-only re-forward (pruners/prefix_cache.py)
             owned = [(units[u][1] % world) == rank for u in layer_units]

@@ -609,10 +609,13 @@ class _StageOneMixin:
             mapping, prune_per_model=self.prune_per_model, per_model_group=list(per_model_group),
             kernels=self.kernels, z_source=self.z_source, process_group=self.process_group,
             k1_form=getattr(self, "k1_form", "block"),
-            grad_graphs=bool(getattr(self, "use_graphs", True)))
+            grad_graphs=bool(getattr(self, "use_graphs", True)),
+            checkpoint_path=getattr(self, "stage1_checkpoint", None))
         self.kernels = ls.kernels
         out = ls.return_sparsity()
         self.stage_stats["stage1"] = dict(ls.stats)
+        if getattr(ls, "resumed_layers", 0):
+            self.stage_stats["stage1"]["resumed_layers"] = ls.resumed_layers
         if hasattr(loss_func, "stats"):
             self.stage_stats["stage1"]["suffix_forward"] = {
                 k: v for k, v in loss_func.stats.items() if k != "stages_not_batch_invariant"}

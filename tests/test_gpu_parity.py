@@ -1170,6 +1170,53 @@ def test_prefix_cache_and_graph_replay_are_exact_on_gpu(kern, fp32):
             assert torch.equal(res[0][2][k], other[2][k]), k
 
 
+@pytest.mark.parametrize("z_source", ["philox", "torch"])
+def test_stage1_checkpoint_resume_on_the_hip_path(kern, tmp_path, z_source):
+    """Zeroth-order stage 1 interrupted and resumed from its checkpoint (graph-replayed prefix
+    cache, lanes, batched evaluations, block-batched K1): same loss table, sparsity table and
+    drifted weights as the uninterrupted run, bit for bit; only the remaining layers are evaluated."""
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+
+    def run(ck, die_after=None):
+        torch.manual_seed(0)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6,
+                                       device="cuda")
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        loss = PrefixCachedLoss(model, use_graphs=True, n_lanes=2, eval_batch=4)
+        if die_after is not None:
+            real, seen = loss.begin_layer, [0]
+
+            def begin_layer(name):
+                seen[0] += 1
+                if seen[0] > die_after:
+                    raise KeyboardInterrupt("simulated crash")
+                return real(name)
+            loss.begin_layer = begin_layer
+        np.random.seed(3)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=kern, z_source=z_source, checkpoint_path=ck, checkpoint_every=4)
+        sp = ls.return_sparsity()
+        torch.cuda.synchronize()
+        return ls, sp, {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    whole = run(None)
+    ck = str(tmp_path / "ck.npz")
+    with pytest.raises(KeyboardInterrupt):
+        run(ck, die_after=14)                               # dies when layer 14 comes up
+    assert int(np.load(ck)["done"][0]) == 12
+    ls, sp, w = run(ck)
+    assert ls.resumed_layers == 12 and ls.stats["forwards"] < whole[0].stats["forwards"]
+    assert sp == whole[1] and np.array_equal(ls.loss_table, whole[0].loss_table)
+    for k in w:
+        assert torch.equal(w[k], whole[2][k]), k
+
+
 def test_guard_tells_a_transient_mismatch_from_a_repeating_one(kern, monkeypatch):
     """One loss of one check differs ONCE (injected): the guard re-does both sides and finds
     them equal the second time = a forward of the run was not reproducible.  By default that is

@@ -405,3 +405,60 @@ def test_global_pruners_match_reference(golden_dir, tag):
             want = init.clone()
             want[torch.from_numpy(diff.reshape(tuple(v.shape)))] *= 0     # pruned = w * 0
             assert np.array_equal(to_bits(v), to_bits(want)), k
+
+
+@pytest.mark.parametrize("k1_form,cached", [("units", False), ("block", True)])
+def test_stage1_resumes_from_its_checkpoint_bit_for_bit(golden_dir, tmp_path, k1_form, cached):
+    """the reference has no mid-stage-1 resume.  Here an interrupted zeroth-order run
+    (the loss closure dies in the middle of a layer) restarted on the ORIGINAL weights with the
+    same checkpoint file picks up behind the last saved layer — the finished layers' weights get
+    their K1 drift back from the seeds alone, no forward — and ends with the reference's table,
+    losses and drifted weights bit for bit (g2), having evaluated only the remaining layers."""
+    from ecoflap_amd.pruners.prefix_cache import PrefixCachedLoss
+    tag, method, num_noise, num_samples = "blip2", "MEZO-GradOnly_sum", 1, 8
+    g = np.load(os.path.join(golden_dir, "g2_scoring.npz"))
+    names = [str(n) for n in g[f"{tag}_names"]]
+    mapping = dict(zip(names, [str(x) for x in g[f"{tag}_groups"]]))
+    key = f"{tag}_{method}_n{num_noise}_s{num_samples}"
+    ck = str(tmp_path / "stage1.npz")
+
+    def fresh(die_after=None):
+        model, batches, loss_fn = _setup(tag)
+        load_state(model, g, f"{tag}_init")
+        base = PrefixCachedLoss(model, kind="vision_language") if cached else loss_fn
+        calls = [0]
+
+        class Closure:            # (attribute access falls through: begin_layer / stage_of / stats)
+            def __call__(self, m, b, c):
+                calls[0] += 1
+                if die_after is not None and calls[0] > die_after:
+                    raise KeyboardInterrupt("simulated crash")
+                return base(m, b, c)
+
+            def __getattr__(self, name):
+                return getattr(base, name)
+
+        np.random.seed(int(g[key + "_cfg"][0]))
+        ls = LayerSparsity(model, batches, Closure(), num_samples, 0.5, 0.6, method, num_noise, 1e-3,
+                           mapping, kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form=k1_form,
+                           checkpoint_path=ck, checkpoint_every=5)
+        return model, ls, calls
+
+    _, ls, calls = fresh(die_after=8 * 13 + 3)          # dies inside layer 13 (8 losses per layer)
+    with pytest.raises(KeyboardInterrupt):
+        ls.return_sparsity()
+    assert os.path.exists(ck) and int(np.load(ck)["done"][0]) == 10
+    model, ls, calls = fresh()
+    sp = ls.return_sparsity()
+    assert ls.resumed_layers == 10 and calls[0] == 8 * (len(names) - 10)
+    assert np.array_equal(np.array([sp[k] for k in names]), g[key + "_sparsity"])
+    np.testing.assert_allclose(ls.loss_table.reshape(-1), g[key + "_losses"], rtol=1e-6)
+    sd = model.state_dict()
+    for k in names:
+        assert np.array_equal(to_bits(sd[k]).ravel(), g[key + f"_final::{k}"].ravel()), k
+    # a checkpoint of another run (other seeds) is ignored, loudly
+    model, ls, calls = fresh()
+    np.random.seed(7)
+    with pytest.warns(UserWarning, match="belongs to another run"):
+        ls.return_sparsity()
+    assert ls.resumed_layers == 0
