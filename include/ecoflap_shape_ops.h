@@ -77,8 +77,8 @@ int ecoflap_multi_compare(const ecoflap_copy_item* items, int n, int* mismatch_f
 
 /* y[M,N] = x[M,K] W[N,K]^T (+ bias[N]) in fp32 on v_mfma_f32_32x32x2_f32 (csrc/gemm_f32.hip): the
  * forward's fp32 Linears (BLIP-2's Q-Former), for which hipBLASLt has only Stream-K solutions on
- * gfx950.  Every output element is one k-ordered fp32 fma chain, the bias added last: a row's
- * result does not depend on the rows that travel with it.  N % 128 == 0, K % 32 == 0 (else
+ * gfx950.  Every output element is one fp32 accumulation chain in a fixed k order, the bias added
+ * last: a row's result does not depend on the rows that travel with it, nor on M.  N % 128 == 0, K % 32 == 0 (else
  * ECOFLAP_ESIZE: the caller keeps the framework's GEMM); x, w 16-byte aligned. */
 int ecoflap_linear_f32(const float* x, const float* w, const float* bias, float* y, int64_t M,
                        int64_t N, int64_t K, void* stream);

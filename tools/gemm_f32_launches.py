@@ -31,7 +31,6 @@ def timed(fn, reps=15, per=10):
     return statistics.median(out)
 
 
-SWEEP = "--sweep" in sys.argv          # every tile shape x both instruction orders, not just the launcher's pick
 for name, M, N, K in [("self-attn q/k/v/o, 16 x 8 x 32 rows", 4096, 768, 768),
                       ("intermediate, 16 x 8 x 32 rows", 4096, 3072, 768),
                       ("output, 16 x 8 x 32 rows", 4096, 768, 3072),
@@ -48,17 +47,9 @@ for name, M, N, K in [("self-attn q/k/v/o, 16 x 8 x 32 rows", 4096, 768, 768),
         ref = F.linear(x.double(), w.double(), b.double())
         t_lib = timed(lambda: F.linear(x, w, b))
         lib_err = ((F.linear(x, w, b).double() - ref).abs().max() / ref.abs().max()).item()
-        combos = [("auto", "1")] + ([(t, s) for t in ("22", "21", "11") for s in ("1", "0")] if SWEEP else [])
-        for tile, sched in combos:
-            os.environ.pop("ECOFLAP_GEMM_F32_TILE", None)
-            if tile != "auto":
-                os.environ["ECOFLAP_GEMM_F32_TILE"] = tile
-            os.environ["ECOFLAP_GEMM_F32_SCHED"] = sched
-            y = fused.linear(x, w, b)
-            err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
-            t_own = timed(lambda: fused.linear(x, w, b))
-            print(f"{name:42s} [{M:6d} x {K:4d}] x {N:4d} tile {tile:4s} sched {sched}: own {t_own:7.1f} us = "
-                  f"{fl / t_own / 1e6:6.1f} TFLOP/s ({fl / t_own / 1e6 / 157 * 100:4.1f} % of 157) err {err:.1e}   "
-                  f"library {t_lib:7.1f} us = {fl / t_lib / 1e6:6.1f} TFLOP/s err {lib_err:.1e}", flush=True)
-        os.environ.pop("ECOFLAP_GEMM_F32_TILE", None)
-        os.environ.pop("ECOFLAP_GEMM_F32_SCHED", None)
+        y = fused.linear(x, w, b)
+        err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+        t_own = timed(lambda: fused.linear(x, w, b))
+        print(f"{name:42s} [{M:6d} x {K:4d}] x {N:4d} own {t_own:7.1f} us = "
+              f"{fl / t_own / 1e6:6.1f} TFLOP/s ({fl / t_own / 1e6 / 157 * 100:4.1f} % of 157) err {err:.1e}   "
+              f"library {t_lib:7.1f} us = {fl / t_lib / 1e6:6.1f} TFLOP/s err {lib_err:.1e}", flush=True)
