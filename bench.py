@@ -771,14 +771,7 @@ def main():
 def _pinned_gemm_report():
     try:
         from ecoflap_amd.shapes import fused
-        import torch.version
-        return {"hip": getattr(torch.version, "hip", None),
-                "shapes": {f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}":
-                           (None if v is None else {"used": v["used"], "index": v["index"],
-                                                    "us_at_16_slots": round(v["us_at_16_slots"], 1),
-                                                    "library_first_choice_us": round(v["library_first_choice_us"], 1),
-                                                    "name": v["name"][:96]})
-                           for k, v in fused.pinned_plans().items()}}
+        return fused.gemm_report()
     except Exception as e:          # never let the report break the line
         return {"error": repr(e)}
 

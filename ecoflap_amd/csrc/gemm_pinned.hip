@@ -83,7 +83,16 @@ struct Problem {                     // descriptors of y[M,N] = x[M,K] W[N,K]^T 
         const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
         hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
         hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
-        (void)has_bias; (void)bias_dt; (void)bias;      // (bias: see the header — beta = 1 on a prefilled y)
+        if (has_bias) {
+            // bias epilogue (the tuning sweep only — ecoflap_linear_tune: the product adds the bias
+            // around the GEMM): one value per row of y^T = per output feature, added to the fp32
+            // accumulator before the rounding
+            const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+            const hipDataType bt = hip_type(bias_dt);
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+            hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+        }
         return hipblasLtMatrixLayoutCreate(&a, t, (uint64_t)K, (uint64_t)N, K) == HIPBLAS_STATUS_SUCCESS &&
                hipblasLtMatrixLayoutCreate(&b, t, (uint64_t)K, (uint64_t)M, K) == HIPBLAS_STATUS_SUCCESS &&
                hipblasLtMatrixLayoutCreate(&c, t, (uint64_t)N, (uint64_t)M, N) == HIPBLAS_STATUS_SUCCESS;
@@ -353,4 +362,153 @@ extern "C" int ecoflap_linear_pinned(const void* x, const void* w, const void* b
                                    bias ? 1.f : 0.f);
     if (st == HIPBLAS_STATUS_ALLOC_FAILED) return ECOFLAP_EWORKSPACE;
     return st == HIPBLAS_STATUS_SUCCESS ? 0 : ECOFLAP_ELIBRARY;
+}
+
+
+// ---- tuning (tools/tune_gemm.py): every solution of the library for this problem, timed ----------
+// For one weight shape: all candidates (heuristic list + getAllAlgos) that support both the
+// 16-slot problem and the probe problem, each timed on both (3 runs after a warm-up), then the
+// `top` fastest by t(16 m) + t(m) checked for repeatability and batch invariance bit for bit
+// (with the bias epilogue when has_bias).  No name filter: under TENSILE_STREAMK_DATA_PARALLEL=1
+// (ecoflap_amd/blas_guard.py) the Stream-K kernels hand every workgroup whole tiles, and whether
+// that holds for a candidate is exactly what is measured.  Fills, fastest first, up to `top` rows of
+// (index, us at 16 m, us at m, flags: 1 = repeatable, 2 = batch invariant), names packed at
+// name_len bytes each.  -> number of rows in *n_out.
+extern "C" int ecoflap_linear_tune(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias, int bias_dtype,
+                                   int top, int* index_out, float* us_big_out, float* us_small_out, int* flags_out,
+                                   char* names_out, int name_len, int* n_out, int* n_candidates) {
+    if (!dtype_ok(dtype) || m_probe <= 0 || N <= 0 || K <= 0 || top <= 0) return ECOFLAP_EDTYPE;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return ECOFLAP_ELIBRARY;
+    constexpr int SLOTS = 16;
+    const int64_t Mb = SLOTS * m_probe;
+    const size_t es = dtype == ECOFLAP_F32 ? 4 : 2, ws_bytes = (size_t)64 << 20;
+    char *x = nullptr, *w = nullptr, *bias = nullptr, *yb = nullptr, *yb2 = nullptr, *ya = nullptr;
+    void* ws = nullptr;
+    bool ok = hipMalloc(&x, Mb * K * es) == hipSuccess && hipMalloc(&w, N * K * es) == hipSuccess &&
+              hipMalloc(&bias, N * 4) == hipSuccess && hipMalloc(&yb, Mb * N * es) == hipSuccess &&
+              hipMalloc(&yb2, Mb * N * es) == hipSuccess && hipMalloc(&ya, m_probe * N * es) == hipSuccess &&
+              hipMalloc(&ws, ws_bytes) == hipSuccess;
+    int rows = 0;
+    if (ok) {
+        hipStream_t s = nullptr;
+        hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, x, Mb * K, m_probe * K, 17u, dtype);
+        hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, w, N * K, N * K, 91u, dtype);
+        hipLaunchKernelGGL(fill_pattern_kernel, dim3(64), dim3(256), 0, s, bias, N, N, 5u, has_bias ? bias_dtype : dtype);
+        Problem big, small;
+        ok = big.make(Mb, N, K, dtype, has_bias != 0, bias_dtype, bias) &&
+             small.make(m_probe, N, K, dtype, has_bias != 0, bias_dtype, bias);
+        std::vector<hipblasLtMatmulHeuristicResult_t> cand(64);
+        if (ok) {
+            int n_cand = 0;
+            hipblasLtMatmulPreference_t pref;
+            hipblasLtMatmulPreferenceCreate(&pref);
+            hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes));
+            if (hipblasLtMatmulAlgoGetHeuristic(g_handle, big.desc, big.a, big.b, big.c, big.c, pref, (int)cand.size(),
+                                                cand.data(), &n_cand) != HIPBLAS_STATUS_SUCCESS)
+                n_cand = 0;
+            hipblasLtMatmulPreferenceDestroy(pref);
+            cand.resize((size_t)n_cand);
+            std::vector<hipblasLtMatmulHeuristicResult_t> all;
+            const hipDataType t = hip_type(dtype);
+            if (hipblaslt_ext::getAllAlgos(g_handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N,
+                                           t, t, t, t, HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS)
+                cand.insert(cand.end(), all.begin(), all.end());
+        }
+        struct Timed { int index; std::string name; float us_big, us_small; Bound big, small; int flags; };
+        std::vector<Timed> timed;
+        std::vector<int> seen;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        auto time3 = [&](const Problem& pr, const Bound& b, void* y, float& us) {
+            if (run(pr, b, x, w, y, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) return false;
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < 3; ++r)
+                if (run(pr, b, x, w, y, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) return false;
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) return false;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            us = ms * 1e3f / 3.f;
+            return true;
+        };
+        int first_index = -1;
+        for (size_t c = 0; ok && c < cand.size(); ++c) {
+            if (cand[c].state != HIPBLAS_STATUS_SUCCESS) continue;
+            const int index = hipblaslt_ext::getIndexFromAlgo(cand[c].algo);
+            if (index < 0 || std::find(seen.begin(), seen.end(), index) != seen.end()) continue;
+            seen.push_back(index);
+            if (first_index < 0) first_index = index;
+            Timed t;
+            t.index = index;
+            t.flags = index == first_index ? 4 : 0;                   // 4: the heuristic's own first choice
+            if (!bind(index, big, t.big) || !bind(index, small, t.small)) continue;
+            if (!time3(big, t.big, yb, t.us_big) || !time3(small, t.small, ya, t.us_small)) {
+                (void)hipGetLastError();
+                continue;
+            }
+            t.name = hipblaslt_ext::getSolutionNameFromAlgo(g_handle, cand[c].algo);
+            timed.push_back(t);
+        }
+        if (n_candidates) *n_candidates = (int)timed.size();
+        std::sort(timed.begin(), timed.end(), [](const Timed& a, const Timed& b) {
+            return a.us_big + a.us_small < b.us_big + b.us_small;
+        });
+        // the heuristic's first choice always makes the list (as its last row if it is not among the fastest)
+        std::vector<Timed> pick;
+        for (size_t c = 0; c < timed.size() && (int)pick.size() < top - 1; ++c) pick.push_back(timed[c]);
+        bool has_first = false;
+        for (const Timed& t : pick) has_first = has_first || (t.flags & 4);
+        for (size_t c = pick.size(); c < timed.size() && (int)pick.size() < top; ++c)
+            if (has_first || (timed[c].flags & 4)) pick.push_back(timed[c]);
+        std::vector<char> h_alone((size_t)m_probe * N * es), h_big((size_t)m_probe * N * es);
+        for (Timed& t : pick) {
+            if (!ok) break;
+            if (run(big, t.big, x, w, yb, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+            if (run(big, t.big, x, w, yb2, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+            if (run(small, t.small, x, w, ya, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
+            if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
+            bool invariant = true, repeatable = true;
+            (void)hipMemcpy(h_alone.data(), ya, h_alone.size(), hipMemcpyDeviceToHost);
+            for (int slot : {0, 7, SLOTS - 1}) {
+                (void)hipMemcpy(h_big.data(), yb + (size_t)slot * m_probe * N * es, h_big.size(), hipMemcpyDeviceToHost);
+                invariant = invariant && memcmp(h_big.data(), h_alone.data(), h_big.size()) == 0;
+                std::vector<char> again(h_big.size());
+                (void)hipMemcpy(again.data(), yb2 + (size_t)slot * m_probe * N * es, again.size(), hipMemcpyDeviceToHost);
+                repeatable = repeatable && memcmp(h_big.data(), again.data(), again.size()) == 0;
+            }
+            t.flags |= (repeatable ? 1 : 0) | (invariant ? 2 : 0);
+            index_out[rows] = t.index;
+            us_big_out[rows] = t.us_big;
+            us_small_out[rows] = t.us_small;
+            flags_out[rows] = t.flags;
+            if (names_out && name_len > 0) {
+                strncpy(names_out + (size_t)rows * name_len, t.name.c_str(), (size_t)name_len - 1);
+                names_out[(size_t)rows * name_len + name_len - 1] = 0;
+            }
+            ++rows;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    for (void* p : {(void*)x, (void*)w, (void*)bias, (void*)yb, (void*)yb2, (void*)ya, ws})
+        if (p) (void)hipFree(p);
+    if (n_out) *n_out = rows;
+    return ok ? 0 : ECOFLAP_ELIBRARY;
+}
+
+
+// "<hipblasLtGetVersion>-<git revision>" of the hipBLASLt that serves this process: solution
+// indices mean something only together with it.
+extern "C" int ecoflap_linear_library_version(char* out, int len) {
+    if (!out || len <= 0) return ECOFLAP_ENULL;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return ECOFLAP_ELIBRARY;
+    int v = 0;
+    char rev[128] = {0};
+    (void)hipblasLtGetVersion(g_handle, &v);
+    (void)hipblasLtGetGitRevision(g_handle, rev);
+    snprintf(out, (size_t)len, "%d-%.100s", v, rev);
+    return 0;
 }

@@ -247,8 +247,39 @@ def _gemm_lib():
             lib.ecoflap_linear_pinned_plan.argtypes = [i64, i64, i64, ci, ci, ci, ip, ip, ip, fp, fp,
                                                        ctypes.c_char_p, ci]
             lib.ecoflap_linear_pinned.argtypes = [vp, vp, vp, vp, i64, i64, i64, ci, ci, vp, sz, vp]
+            lib.ecoflap_linear_library_version.argtypes = [ctypes.c_char_p, ci]
             _gemm = lib
     return _gemm
+
+
+_library_version = None
+
+
+def library_version():
+    """"<hipblasLtGetVersion>-<git revision>" of the hipBLASLt serving this process (None without
+    the GEMM library): what a solution index is an index INTO."""
+    global _library_version
+    lib = _gemm_lib()
+    if _library_version is None and lib:
+        buf = ctypes.create_string_buffer(256)
+        if lib.ecoflap_linear_library_version(buf, 256) == 0:
+            _library_version = buf.value.decode(errors="replace")
+    return _library_version
+
+
+def gemm_report():
+    """What ran the Linears, for the run summaries: library version and the plans of `pinned_plans`."""
+    def label(k):
+        return f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}"
+    shapes = {label(k): (None if v is None else {
+        "used": v["used"], "index": v["index"], "us_at_16_slots": round(v["us_at_16_slots"], 1),
+        "library_first_choice_us": round(v["library_first_choice_us"], 1), "name": v["name"][:96]})
+        for k, v in pinned_plans().items()}
+    try:
+        version = library_version()
+    except Exception:           # (the GEMM library is not built: nothing was pinned either)
+        version = None
+    return {"hip": getattr(torch.version, "hip", None), "hipblaslt": version, "shapes": shapes}
 
 
 def _pinned_wanted(plan, has_bias):

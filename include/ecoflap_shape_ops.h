@@ -113,6 +113,17 @@ int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K, int dtype,
 int ecoflap_linear_pinned(const void* x, const void* w, const void* bias, void* y, int64_t M,
                           int64_t N, int64_t K, int dtype, int bias_dtype, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* Measurement only (tools/tune_gemm.py): every solution of the library that supports the problem
+ * at m_probe and 16 * m_probe rows (heuristic list + all algorithms, no name filter; bias in the
+ * GEMM's epilogue when has_bias), each timed on both, the `top` fastest by t(16 m) + t(m) checked
+ * bit for bit for repeatability (flag 1) and batch invariance (flag 2); flag 4 = the heuristic's
+ * first choice (always listed).  Rows fastest first; names packed at name_len bytes each. */
+int ecoflap_linear_tune(int64_t m_probe, int64_t N, int64_t K, int dtype, int has_bias, int bias_dtype,
+                        int top, int* index_out, float* us_big_out, float* us_small_out, int* flags_out,
+                        char* names_out, int name_len, int* n_out, int* n_candidates);
+/* "<hipblasLtGetVersion>-<git revision>" of the hipBLASLt serving this process: a solution index
+ * means something only together with it (recorded by the run summaries). */
+int ecoflap_linear_library_version(char* out, int len);
 
 #ifdef __cplusplus
 }

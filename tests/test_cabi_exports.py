@@ -29,9 +29,10 @@ def test_every_declared_symbol_is_exported():
     # plumbing ops of the shape modules: in the same library, except the pinned-solution Linears,
     # which sit in a library of their own (it links hipBLASLt; the pruner ABI library does not)
     gemm = ctypes.CDLL(os.path.join(os.path.dirname(hip.LIB_PATH), "libecoflap_gemm.so"))
+    in_gemm = ("ecoflap_linear_pinned", "ecoflap_linear_tune", "ecoflap_linear_library_version")
     for n in shape_ops:
-        assert hasattr(gemm if n.startswith("ecoflap_linear_pinned") else lib, n), n
-    assert len([n for n in shape_ops if n.startswith("ecoflap_linear_pinned")]) == 2
+        assert hasattr(gemm if n.startswith(in_gemm) else lib, n), n
+    assert len([n for n in shape_ops if n.startswith(in_gemm)]) == 4
     lib.ecoflap_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.ecoflap_version()
 

@@ -70,11 +70,7 @@ def run(which, extra=()):
         "max_sparsity": vals[-1] if vals else None,
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
         "stage_stats": getattr(harness.main, "last_stage_stats", None),
-        "pinned_gemm": {f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}":
-                        (None if v is None else {"used": v["used"], "index": v["index"], "name": v["name"][:96],
-                                                 "us_at_16_slots": v["us_at_16_slots"],
-                                                 "library_first_choice_us": v["library_first_choice_us"]})
-                        for k, v in __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).pinned_plans().items()}}
+        "pinned_gemm": __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).gemm_report()}
 
 
 def main():

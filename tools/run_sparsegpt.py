@@ -26,7 +26,5 @@ print(json.dumps({"wall_seconds": time.time() - t0, "pruned_fraction": zeros / t
                   "stage_stats": getattr(harness.main, "last_stage_stats", None),
                   "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
                   # which weight shapes ran a pinned hipBLASLt solution (shapes/fused.py)
-                  "pinned_gemm": {f"{k[0]}x{k[1]} {str(k[2]).split('.')[-1]}": (None if v is None else {
-                      "used": v["used"], "index": v["index"], "name": v["name"][:96]})
-                      for k, v in __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).pinned_plans().items()}},
+                  "pinned_gemm": __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).gemm_report()},
                  default=str))
