@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _run_case(method, k1_form, rank, world, cached, n_samples=8, batch=2):
+def _run_case(method, k1_form, rank, world, cached, n_samples=8, batch=2, checkpoint=None, die_after=None):
     from oracle_backend import OracleKernels, torch_cpu_normal
     from ecoflap_amd.pruners import LayerSparsity
     from ecoflap_amd.pruners.losses import loss_vision_language
@@ -34,20 +34,35 @@ def _run_case(method, k1_form, rank, world, cached, n_samples=8, batch=2):
                if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
     np.random.seed(42)
     loss = PrefixCachedLoss(model) if cached else loss_vision_language
+    if die_after is not None:
+        inner, calls = loss, [0]
+
+        def loss(m, b, c):                     # a crash in the middle of a layer
+            calls[0] += 1
+            if calls[0] > die_after:
+                raise KeyboardInterrupt("simulated crash")
+            return inner(m, b, c)
     ls = LayerSparsity(model, batches, loss, n_samples, 0.5, 0.6, method, 1, 1e-3, mapping,
-                       kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form=k1_form)
-    sp = ls.return_sparsity()
+                       kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form=k1_form,
+                       checkpoint_path=checkpoint, checkpoint_every=3)
+    try:
+        sp = ls.return_sparsity()
+    except KeyboardInterrupt:
+        return None
+    ls.stats["resumed_layers"] = ls.resumed_layers
     weights = {k: v.detach().clone() for k, v in model.state_dict().items() if k in mapping}
     sums = {k: float(v.sum()) for k, v in ls.importance_measure.items()}
     return sp, ls.loss_table, weights, sums, dict(ls.stats)
 
 
-def _worker(rank, world, port, method, k1_form, cached, out_dir, n_samples=8, batch=2):
+def _worker(rank, world, port, method, k1_form, cached, out_dir, n_samples=8, batch=2, checkpoint=None,
+            die_after=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run_case(method, k1_form, rank, world, cached, n_samples, batch)
+        res = _run_case(method, k1_form, rank, world, cached, n_samples, batch, checkpoint,
+                        None if die_after is None else die_after[rank])
         torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -73,6 +88,31 @@ def test_two_ranks_reproduce_single_process(tmp_path, method, k1_form, cached):
             for k, v in sums.items():                                  # double sums re-associate
                 assert abs(v - single[3][k]) <= 1e-6 * abs(v)
             assert sp == single[0]
+
+
+def test_two_ranks_resume_from_their_own_checkpoints(tmp_path):
+    """Stage-1 resume under data parallelism: each rank keeps its own checkpoint file
+    (`<path>.rank<r>of<n>`: its own entries of the loss table).  Both ranks crash, at DIFFERENT
+    layers; the restarted job — every rank resuming behind ITS last saved layer — ends with the
+    one-process table, sparsities and weights bit for bit (the loop holds no collective, the one
+    all-reduce comes after it)."""
+    method, k1_form = "MEZO-GradOnly_sum", "units"
+    single = _run_case(method, k1_form, 0, 1, False)
+    ck = str(tmp_path / "stage1.npz")
+    port = 31500 + os.getpid() % 2000
+    # 4 batches over 2 ranks = 2 losses pairs per layer and rank -> 4 loss calls per layer
+    mp.spawn(_worker, args=(2, port, method, k1_form, False, str(tmp_path), 8, 2, ck, (4 * 7 + 1, 4 * 4 + 2)),
+             nprocs=2, join=True)
+    done = [int(np.load(f"{ck}.rank{r}of2")["done"][0]) for r in range(2)]
+    assert done == [6, 3], done
+    mp.spawn(_worker, args=(2, port + 1, method, k1_form, False, str(tmp_path), 8, 2, ck, None),
+             nprocs=2, join=True)
+    for r in range(2):
+        sp, table, weights, sums, stats = torch.load(tmp_path / f"rank{r}.pt", weights_only=False)
+        assert stats["resumed_layers"] == done[r]
+        assert np.array_equal(table, single[1]) and sp == single[0]
+        for k in weights:
+            assert torch.equal(weights[k], single[2][k]), k
 
 
 @pytest.mark.parametrize("world,n_samples,batch,k1_form", [
