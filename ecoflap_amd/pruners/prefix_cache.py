@@ -19,6 +19,7 @@ cuda_enabled) -> (loss, batch_len)`; `LayerSparsity` tells it which matrix is be
 perturbed through the optional `begin_layer(name)` hook.
 """
 import os
+import time
 
 import torch
 
@@ -962,7 +963,10 @@ class PrefixCachedLoss:
             fa, fb = [], []
             _map_tensors(alone, lambda t: fa.append(t) or t)
             _map_tensors(_slice_state(out, pick, B, k), lambda t: fb.append(t) or t)
+            t0 = time.time()             # (the read-back waits for everything queued so far)
             same = not bool(_differ_flag(fa, fb).item())
+            self.stats["host_blocked_seconds"] = (self.stats.get("host_blocked_seconds", 0.0)
+                                                  + time.time() - t0)
             self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
             self._owner_ok[(fam, name)] = same
             if not same:
