@@ -4,9 +4,16 @@
 #include "common.h"
 #include "../../include/ecoflap_shape_ops.h"
 
+// T5's RMS norm, optionally preceded by the residual add that produces its input:
+//   s = dtype(x + r)            (written to sum_out)      [if r != nullptr]
+//   y = w * dtype(float(s) * rsqrt(mean(float(s)^2) + eps))
+// — the bits of the separate add and norm (the sum is rounded to the storage dtype before the
+// statistics are taken).  One wave per row.
 template <int DT>
 __global__ __launch_bounds__(256) void t5_rmsnorm_kernel(const void* __restrict__ x,
+                                                         const void* __restrict__ r,
                                                          const void* __restrict__ w,
+                                                         void* __restrict__ sum_out,
                                                          void* __restrict__ y, int64_t rows,
                                                          int64_t d, float eps) {
     constexpr int N = Vec<DT>::N;
@@ -19,15 +26,23 @@ __global__ __launch_bounds__(256) void t5_rmsnorm_kernel(const void* __restrict_
     for (int64_t v = lane; v < nvec; v += 64) {
         float f[N];
         Vec<DT>::unpack(ld16(x, base + v), f);
+        if (r) {
+            float g[N];
+            Vec<DT>::unpack(ld16(r, base + v), g);
+#pragma unroll
+            for (int i = 0; i < N; ++i) f[i] = Vec<DT>::round(f[i] + g[i]);
+            st16(sum_out, base + v, Vec<DT>::pack(f));
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) ss += f[i] * f[i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     const float inv = rsqrtf(ss / (float)d + eps);
+    const void* src = r ? sum_out : x;       // (this lane's own stores of a moment ago)
     for (int64_t v = lane; v < nvec; v += 64) {
         float f[N], g[N];
-        Vec<DT>::unpack(ld16(x, base + v), f);
+        Vec<DT>::unpack(ld16(src, base + v), f);
         Vec<DT>::unpack(ld16(w, v), g);
 #pragma unroll
         for (int i = 0; i < N; ++i) f[i] = g[i] * Vec<DT>::round(f[i] * inv);
@@ -147,20 +162,32 @@ __global__ __launch_bounds__(256) void gelu_mul_kernel(const void* __restrict__ 
     }
 }
 
-extern "C" int ecoflap_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t d,
-                                  float eps, int dtype, void* stream) {
+static int t5_rmsnorm_impl(const void* x, const void* residual, const void* w, void* sum_out, void* y,
+                           int64_t rows, int64_t d, float eps, int dtype, void* stream) {
     if (dtype != ECOFLAP_F16 && dtype != ECOFLAP_BF16) return ECOFLAP_EDTYPE;
     if (rows <= 0 || d <= 0 || d % 8 != 0) return ECOFLAP_ESIZE;
-    if (!x || !w || !y) return ECOFLAP_ENULL;
-    if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return ECOFLAP_EALIGN;
+    if (!x || !w || !y || (residual && !sum_out)) return ECOFLAP_ENULL;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (residual && (!aligned16(residual) || !aligned16(sum_out))))
+        return ECOFLAP_EALIGN;
     const dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ECOFLAP_F16)
-        hipLaunchKernelGGL((t5_rmsnorm_kernel<ECOFLAP_F16>), grid, dim3(256), 0, s, x, w, y, rows, d, eps);
+        hipLaunchKernelGGL((t5_rmsnorm_kernel<ECOFLAP_F16>), grid, dim3(256), 0, s, x, residual, w, sum_out, y, rows, d, eps);
     else
-        hipLaunchKernelGGL((t5_rmsnorm_kernel<ECOFLAP_BF16>), grid, dim3(256), 0, s, x, w, y, rows, d, eps);
+        hipLaunchKernelGGL((t5_rmsnorm_kernel<ECOFLAP_BF16>), grid, dim3(256), 0, s, x, residual, w, sum_out, y, rows, d, eps);
     ECO_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ecoflap_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t d,
+                                  float eps, int dtype, void* stream) {
+    return t5_rmsnorm_impl(x, nullptr, w, nullptr, y, rows, d, eps, dtype, stream);
+}
+
+extern "C" int ecoflap_t5_add_rmsnorm(const void* x, const void* residual, const void* w, void* sum_out,
+                                      void* y, int64_t rows, int64_t d, float eps, int dtype, void* stream) {
+    if (!residual) return ECOFLAP_ENULL;
+    return t5_rmsnorm_impl(x, residual, w, sum_out, y, rows, d, eps, dtype, stream);
 }
 
 extern "C" int ecoflap_gelu_mul(const void* a, const void* b, void* y, int64_t n, int dtype,

@@ -27,6 +27,7 @@ def _get():
         lib = _hip.load_library()
         vp, i64, f32, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
         lib.ecoflap_t5_rmsnorm.argtypes = [vp, vp, vp, i64, i64, f32, ci, vp]
+        lib.ecoflap_t5_add_rmsnorm.argtypes = [vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_gelu_mul.argtypes = [vp, vp, vp, i64, ci, vp]
         lib.ecoflap_add_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
         lib.ecoflap_add_bias_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, ci, vp]
@@ -67,6 +68,24 @@ def t5_rmsnorm(x, weight, eps):
     if rc != 0:
         raise _hip.EcoflapHipError(f"ecoflap_t5_rmsnorm failed ({rc})")
     return y
+
+
+def t5_add_rmsnorm(x, residual, weight, eps):
+    """(x + residual, rmsnorm(x + residual) * weight) in one pass -> (sum, y), or None (caller runs
+    the add and the norm: CPU, autograd, other dtypes).  Same bits as the two separate ops."""
+    if (not _usable(x, weight) or not _usable(residual, weight) or x.shape != residual.shape
+            or x.dtype != residual.dtype or x.shape[-1] % 8 != 0):
+        return None
+    xc = x if x.is_contiguous() else x.contiguous()
+    rc_ = residual if residual.is_contiguous() else residual.contiguous()
+    s, y = torch.empty_like(xc), torch.empty_like(xc)
+    d = xc.shape[-1]
+    rc = _get().ecoflap_t5_add_rmsnorm(xc.data_ptr(), rc_.data_ptr(), weight.data_ptr(), s.data_ptr(),
+                                       y.data_ptr(), xc.numel() // d, d, float(eps),
+                                       _hip.DTYPE_CODE[xc.dtype], _stream())
+    if rc != 0:
+        raise _hip.EcoflapHipError(f"ecoflap_t5_add_rmsnorm failed ({rc})")
+    return s, y
 
 
 def gelu_mul(a, b):

@@ -164,16 +164,36 @@ class T5Block(nn.Module):
                 encoder_hidden_states=None, encoder_attention_mask=None,
                 encoder_decoder_position_bias=None, layer_head_mask=None,
                 cross_attn_layer_head_mask=None, **unused):
-        h, bias = self.layer[0](hidden_states, attention_mask=attention_mask,
-                                position_bias=position_bias)
+        # The sublayers' own forwards, written out so that each residual add can run in the pass
+        # that normalises its result for the NEXT sublayer (`_add_norm`: one kernel on the GPU,
+        # the same two ops otherwise — same values either way):
+        #   h1 = x + SelfAttention(norm0(x));  [h2 = h1 + EncDecAttention(norm1(h1), enc)];
+        #   out = h + FF(normF(h))
+        sa, ff = self.layer[0], self.layer[-1]
+        y, bias = sa.SelfAttention(sa.layer_norm(hidden_states), mask=attention_mask,
+                                   position_bias=position_bias)
         outputs = (bias,)
         if self.is_decoder and encoder_hidden_states is not None:
-            h, xbias = self.layer[1](h, encoder_hidden_states,
-                                     attention_mask=encoder_attention_mask,
-                                     position_bias=encoder_decoder_position_bias)
+            ca = self.layer[1]
+            h, normed = _add_norm(hidden_states, y, ca.layer_norm)
+            y, xbias = ca.EncDecAttention(normed, mask=encoder_attention_mask,
+                                          key_value_states=encoder_hidden_states,
+                                          position_bias=encoder_decoder_position_bias)
             outputs = outputs + (xbias,)
-        h = self.layer[-1](h)
+            h, normed = _add_norm(h, y, ff.layer_norm)
+        else:
+            h, normed = _add_norm(hidden_states, y, ff.layer_norm)
+        h = h + ff.DenseReluDense(normed)
         return (h,) + outputs
+
+
+def _add_norm(x, y, norm):
+    """(x + y, norm(x + y))"""
+    both = fused.t5_add_rmsnorm(x, y, norm.weight, norm.variance_epsilon)
+    if both is not None:
+        return both
+    s = x + y
+    return s, norm(s)
 
 
 class T5Stack(nn.Module):

@@ -19,6 +19,11 @@ extern "C" {
  * x, y: [rows, d] of `dtype` (F16/BF16), w: [d] of `dtype`; d % 8 == 0. */
 int ecoflap_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t d,
                        float eps, int dtype, void* stream);
+/* The same preceded by the residual add that produces its input (T5 block: h = x + sublayer(x),
+ * then the NEXT sublayer's norm of h): sum_out = dtype(x + residual), y = rmsnorm(sum_out) * w —
+ * the bits of the separate add and norm, one pass instead of two. */
+int ecoflap_t5_add_rmsnorm(const void* x, const void* residual, const void* w, void* sum_out, void* y,
+                           int64_t rows, int64_t d, float eps, int dtype, void* stream);
 
 /* gated GELU of T5DenseGatedActDense (modeling_t5.py:296-330): y = gelu(a) * b
  * (erf GELU in fp32, rounded to dtype, then the product rounded to dtype). n % 8 == 0. */

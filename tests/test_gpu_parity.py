@@ -1787,6 +1787,16 @@ def test_fused_shape_ops_match_torch_chain():
             want = ln(x).detach()
         err = (got.float() - want.float()).abs().max().item()
         assert err <= 2 * torch.finfo(dt).eps * want.float().abs().max().item(), err
+        # residual add + the next sublayer's RMS norm (T5 block) == the add, then the norm kernel
+        # alone, bit for bit (the sum is rounded to the storage dtype before the statistics)
+        r = (0.5 * torch.randn(3, 48, 2048, device="cuda")).to(dt)
+        with torch.no_grad():
+            s_, y_ = fused.t5_add_rmsnorm(x, r, ln.weight, ln.variance_epsilon)
+            assert torch.equal(s_, x + r) and torch.equal(y_, ln(x + r))
+            ragged = fused.t5_add_rmsnorm(x[:, :5], r[:, :5], ln.weight, ln.variance_epsilon)   # not contiguous
+            assert torch.equal(ragged[0], x[:, :5] + r[:, :5]) and torch.equal(ragged[1], ln(x[:, :5] + r[:, :5]))
+        with torch.enable_grad():
+            assert fused.t5_add_rmsnorm(x, r, ln.weight, ln.variance_epsilon) is None
         a = (torch.randn(384, 5120, device="cuda")).to(dt)
         b = (torch.randn(384, 5120, device="cuda")).to(dt)
         with torch.no_grad():
