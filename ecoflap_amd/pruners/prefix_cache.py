@@ -937,7 +937,9 @@ class PrefixCachedLoss:
                     mod._bias_pending = True
                     return torch.cat(ys, 0)
             mod._bias_pending = False
-            return torch.cat([_linear(x[i * B:(i + 1) * B], thetas[i], mod.bias)
+            # (`_call_bias`: EVA's qkv Linear is handed its q / v biases per call by the Attention)
+            bias = mod.bias if mod.bias is not None else mod.__dict__.get("_call_bias")
+            return torch.cat([_linear(x[i * B:(i + 1) * B], thetas[i], bias)
                               for i in range(k)], 0)
 
         had = "forward" in mod.__dict__

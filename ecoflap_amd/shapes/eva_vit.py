@@ -38,10 +38,38 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=False)
         self.proj = nn.Linear(dim, dim)
 
+    def _epilogue_bias(self, x):
+        """cat(q_bias, 0, v_bias) in the qkv weight's 16-bit dtype, cached — the bias the reference
+        hands to F.linear (eva_vit.py:119-141) — when the qkv Linear can add it in its own GEMM
+        (a pinned-forward Linear on the GPU, no autograd, 16-bit weights); None otherwise."""
+        w = self.qkv.weight
+        if (self.q_bias is None or torch.is_grad_enabled() or w.device.type != "cuda"
+                or w.dtype not in (torch.float16, torch.bfloat16)
+                or not getattr(self.qkv, "_ecoflap_pinned", False)):
+            return None
+        key = (self.q_bias._version, self.v_bias._version, self.q_bias.data_ptr(), self.v_bias.data_ptr(),
+               w.dtype, w.device)
+        cached = self.__dict__.get("_qkv_bias_cache")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                b = torch.cat((self.q_bias, torch.zeros_like(self.v_bias), self.v_bias)).to(w.dtype)
+            cached = self.__dict__["_qkv_bias_cache"] = (key, b)
+        return cached[1]
+
     def forward(self, x, rel_pos_bias=None):
         B, N, C = x.shape
-        qkv = self.qkv(x)
-        if self.q_bias is not None:
+        bias = self._epilogue_bias(x)
+        if bias is not None:
+            # the qkv Linear's forward (shapes/fused.py::_pinned_forward, or the loop's per-slot
+            # form of it) adds it in the GEMM's epilogue: one rounding, as in the reference's call
+            self.qkv._call_bias = bias
+            try:
+                qkv = self.qkv(x)
+            finally:
+                self.qkv._call_bias = None
+        else:
+            qkv = self.qkv(x)
+        if self.q_bias is not None and bias is None:
             from . import fused
             if fused.qkv_bias_add(qkv, self.q_bias, self.v_bias) is None:
                 qkv = qkv + torch.cat(

@@ -461,7 +461,9 @@ def _pinned_forward(self, x):
             self._bias_pending = True
             return y
     self._bias_pending = False
-    return linear_or_torch(x, self.weight, self.bias)
+    # (`_call_bias`: a bias that is not the module's own parameter, handed over for this call by
+    # the parent — EVA's qkv Linear has bias=False and its q / v biases live in the Attention)
+    return linear_or_torch(x, self.weight, self.bias if self.bias is not None else self.__dict__.get("_call_bias"))
 
 
 def take_pending_bias(mod):

@@ -55,7 +55,9 @@ int ecoflap_bias_add_residual(const void* x, const void* m, const void* bias, vo
                               int64_t d, int dtype, void* stream);
 
 /* EVA attention bias (eva_vit.py:123-128): qkv += cat(q_bias, zeros, v_bias).to(dtype), in
- * place; qkv: [rows, 3*dim] of `dtype` (F16/BF16), q_bias / v_bias: [dim] float; dim % 8 == 0. */
+ * place; qkv: [rows, 3*dim] of `dtype` (F16/BF16), q_bias / v_bias: [dim] float; dim % 8 == 0.
+ * (The pinned-forward qkv Linear of shapes/eva_vit.py adds this bias in its GEMM's epilogue
+ * instead; this pass serves the other cases.) */
 int ecoflap_qkv_bias_add(void* qkv, const float* q_bias, const float* v_bias, int64_t rows,
                          int64_t dim, int dtype, void* stream);
 

@@ -147,12 +147,18 @@ _port = [41000 + os.getpid() % 1500]
 
 
 def _launch(tmp_path, world, job, **kwargs):
-    """-> ([per-rank result], the one-process result).  Children first: the parent touches the
-    GPU only afterwards (they are spawned, not forked)."""
+    """-> ([per-rank result], the one-process result).  The one-process run is a spawned child as
+    well: every run starts from a fresh process, like the ranks — the test process may carry GEMM
+    plans and probes of earlier tests (shapes/fused.py decides per process, when a weight shape
+    first comes up, whether the library's choice is batch invariant for it)."""
     _port[0] += 7
     mp.spawn(_worker, args=(world, _port[0], job, kwargs, str(tmp_path)), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(world)]
-    return ranks, _run(job, 0, 1, kwargs)
+    one = tmp_path / "one_process"
+    one.mkdir(exist_ok=True)
+    _port[0] += 7
+    mp.spawn(_worker, args=(1, _port[0], job, kwargs, str(one)), nprocs=1, join=True)
+    return ranks, torch.load(one / "r0.pt", weights_only=False)
 
 
 def _assert_equal_runs(ranks, single, world):

@@ -108,6 +108,45 @@ def test_pinned_model_forward_equals_its_own_batched_form_at_batch_size_1(monkey
             assert torch.equal(blk(x[i:i + 1], None), whole[i:i + 1]), i
 
 
+def test_eva_qkv_bias_rides_in_the_gemm_epilogue_as_in_the_reference():
+    """EVA's q / v biases (the synthetic models leave them at zero: here they are not).  A
+    pinned-forward qkv Linear adds cat(q_bias, 0, v_bias) in its GEMM — the reference's own
+    `F.linear(x, weight, qkv_bias)` (eva_vit.py:119-141), bit for bit —; the block's output is the
+    un-pinned block's (GEMM, then the separate bias pass: one rounding more) within fp16 rounding,
+    a changed bias is picked up, and the block stays batch invariant."""
+    import torch.nn.functional as F
+    from ecoflap_amd.shapes.eva_vit import Block, half_linear_weights
+    from ecoflap_amd.shapes.fused import pin_linears
+    torch.manual_seed(1)
+    blk = Block(1408, 16, 6144).cuda().eval()
+    half_linear_weights(blk)
+    with torch.no_grad():
+        blk.attn.q_bias.normal_(0, 0.3)
+        blk.attn.v_bias.normal_(0, 0.3)
+    x = (torch.randn(8, 257, 1408, device="cuda") * 0.5).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        plain = blk(x, None)                                   # nn.Linear forwards + ecoflap_qkv_bias_add
+        assert blk.attn._epilogue_bias(x) is None
+        assert pin_linears(blk) == 4
+        bias = blk.attn._epilogue_bias(x)
+        assert bias is not None and bias.dtype == torch.float16 and blk.attn._epilogue_bias(x) is bias
+        want = F.linear(x, blk.attn.qkv.weight, bias)
+        blk.attn.qkv._call_bias = bias
+        got = blk.attn.qkv(x)
+        blk.attn.qkv._call_bias = None
+        assert torch.equal(got, want)
+        assert not torch.equal(blk.attn.qkv(x), want)          # (without the hand-over: no bias)
+        pinned = blk(x, None)
+        err = (pinned.float() - plain.float()).abs().max().item()
+        assert 0 < err <= 4e-3 * plain.float().abs().max().item(), err
+        assert torch.equal(blk(x[3:4], None), pinned[3:4])
+        blk.attn.v_bias.add_(1.0)                              # in place: the cache follows the version
+        assert blk.attn._epilogue_bias(x) is not bias
+        assert not torch.equal(blk(x, None), pinned)
+    with torch.enable_grad():
+        assert blk.attn._epilogue_bias(x) is None              # autograd: the torch op chain
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_bias_consumers_equal_the_torch_op_chains(dt):
     """The ops that add a deferred Linear bias (shapes/fused.py): `dtype(a + bias)` first — the
