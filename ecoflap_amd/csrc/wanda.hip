@@ -39,6 +39,7 @@ struct ColsqArgs {
     int first_wg;            // multi-input launch: first workgroup of this input
     int vector;              // 16-byte column vectors usable
     int raw;                 // 1: scaler_row[c] = ||x_c||^2 of THIS input only (no running mean)
+    int small;               // 1: few rows — one workgroup per 64 columns reduces ALL rows (colsq_small_body)
 };
 
 // the work of workgroup (bx = column block, by = row chunk) of one hooked input
@@ -162,11 +163,96 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
     }
 }
 
+// Few rows (tokens <= COLSQ_SMALL_TOKENS: one calibration batch of a FlanT5 block is 128-384
+// rows of 2048-5120 columns, 0.5-4 MB): the two-stage scheme above is all latency there — partial
+// sums to memory, a ticket, the last arriver's reload (12.5 us for a block's 13 MB).  Here a
+// workgroup owns 64 columns (8 lanes x 8) and reduces ALL rows itself: lane (row slot, column
+// vector) takes rows wave * 8 + slot + 32 p — at most 16 16-byte loads, four in flight at a time —, the wave's 8
+// row slots are added by a fixed butterfly, the 4 waves through LDS in a fixed order, and the same
+// workgroup applies the update: no partials, no ticket to wait for.  One path per (tokens, cols):
+// a given input is always summed in the same order.
+#define COLSQ_SMALL_TOKENS 512
+template <int DT>
+__device__ __forceinline__ void colsq_small_body(const ColsqArgs& a, const int bx, float (*lds)[64 * 8]) {
+    constexpr int N = Vec<DT>::N;
+    const void* __restrict__ x = a.x;
+    const int64_t tokens = a.tokens, cols = a.cols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 7, slot = lane >> 3;
+    const int64_t ncvec = cols / N;
+    const int64_t cvec = (int64_t)bx * 8 + cl;
+    float acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    if (cvec < ncvec) {
+        int64_t r = wave * 8 + slot;
+        for (; r + 96 < tokens; r += 128) {          // four loads in flight (all sixteen at once: slower, measured)
+            float f0[N], f1[N], f2[N], f3[N];
+            const u32x4 va = ld16(x, r * ncvec + cvec), vb = ld16(x, (r + 32) * ncvec + cvec);
+            const u32x4 vc = ld16(x, (r + 64) * ncvec + cvec), vd = ld16(x, (r + 96) * ncvec + cvec);
+            Vec<DT>::unpack(va, f0); Vec<DT>::unpack(vb, f1);
+            Vec<DT>::unpack(vc, f2); Vec<DT>::unpack(vd, f3);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {            // same order as the one-row-at-a-time loop below
+                acc[i] += f0[i] * f0[i];
+                acc[i] += f1[i] * f1[i];
+                acc[i] += f2[i] * f2[i];
+                acc[i] += f3[i] * f3[i];
+            }
+        }
+        for (; r < tokens; r += 32) {
+            float f[N];
+            Vec<DT>::unpack(ld16(x, r * ncvec + cvec), f);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] += f[i] * f[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float v = acc[i];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (slot == 0) lds[wave][cl * N + i] = v;
+    }
+    __syncthreads();
+    float decay = a.decay, n_new = a.n_new;
+    if (a.n_dev) {                         // formed as the host form does (double, then float)
+        const int64_t n0 = a.n_dev[0];
+        decay = (float)((double)n0 / (double)(n0 + a.batch));
+        n_new = (float)(n0 + a.batch);
+    }
+    const int64_t c = (int64_t)bx * 8 * N + threadIdx.x;
+    if (threadIdx.x < 8 * N && c < cols) {
+        const float s = (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+        const float nrm = __builtin_sqrtf(s);  // torch.norm(...): sqrt of the sum of squares
+        const float sq = nrm * nrm;            // ... ** 2
+        if (a.raw) {
+            a.scaler_row[c] = sq;
+        } else {
+            const float r = a.scaler_row[c] * decay;  // scaler_row *= n / (n + b)
+            a.scaler_row[c] = r + sq / n_new;         // += ... / nsamples
+        }
+    }
+    if (a.n_dev) {
+        // every wave of this workgroup has read n_dev before thread 0 takes the grid-level
+        // ticket: the workgroup that takes the LAST one bumps the count
+        __syncthreads();
+        if (threadIdx.x == 0 &&
+            __hip_atomic_fetch_add(&a.tickets[a.colblocks], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                (unsigned)a.colblocks - 1u) {
+            __hip_atomic_store(&a.tickets[a.colblocks], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.n_dev[0] += a.batch;
+        }
+    }
+}
+
 template <int DT, bool VECTOR>
 __global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
     __shared__ float lds[4][64 * 8];
     __shared__ unsigned last;
-    colsq_body<DT, VECTOR>(a, blockIdx.x, blockIdx.y, lds, &last);
+    if (VECTOR && a.small) colsq_small_body<DT>(a, blockIdx.x, lds);
+    else colsq_body<DT, VECTOR>(a, blockIdx.x, blockIdx.y, lds, &last);
 }
 
 // ALL hooked inputs of a transformer block for one calibration sample in ONE launch (the
@@ -175,7 +261,8 @@ __global__ __launch_bounds__(256) void colsq_kernel(const ColsqArgs a) {
 // laid out one input after another; same arithmetic per input as the one-input kernel.
 struct ColsqMultiArgs {
     ColsqArgs it[ECOFLAP_COLSQ_MAX_ITEMS];
-    int n;
+    int first[ECOFLAP_COLSQ_MAX_ITEMS];      // first workgroup of input i (INT_MAX past the last): one
+    int n;                                   // vector load, no walk over the 100-byte records
 };
 
 template <int DT>
@@ -184,12 +271,13 @@ __global__ __launch_bounds__(256) void colsq_multi_kernel(const ColsqMultiArgs m
     __shared__ unsigned last;
     int i = 0;
     const int wg = blockIdx.x;
-#pragma unroll 1
-    while (i + 1 < m.n && wg >= m.it[i + 1].first_wg) ++i;
+#pragma unroll
+    for (int j = 1; j < ECOFLAP_COLSQ_MAX_ITEMS; ++j) i += wg >= m.first[j] ? 1 : 0;     // (ascending)
     const ColsqArgs& a = m.it[i];
     const int local = wg - a.first_wg;
     const int bx = local % a.colblocks, by = local / a.colblocks;
-    if (a.vector) colsq_body<DT, true>(a, bx, by, lds, &last);
+    if (a.small) colsq_small_body<DT>(a, bx, lds);
+    else if (a.vector) colsq_body<DT, true>(a, bx, by, lds, &last);
     else colsq_body<DT, false>(a, bx, by, lds, &last);
 }
 
@@ -284,6 +372,13 @@ static int colsq_fill(ColsqArgs& a, float* scaler_row, const void* x, int64_t to
     a.first_wg = 0;
     a.vector = vector ? 1 : 0;
     a.raw = raw;
+    a.small = 0;
+    if (vector && tokens <= COLSQ_SMALL_TOKENS && (ncv + 7) / 8 <= COLSQ_MAX_COLBLOCKS) {
+        a.small = 1;                       // one workgroup per 64 (fp32: 32) columns, all rows: colsq_small_body
+        a.colblocks = (int)((ncv + 7) / 8);
+        a.nchunks = 1;
+        a.rows_per_chunk = (int)tokens;
+    }
     return 0;
 }
 
@@ -348,9 +443,11 @@ extern "C" int ecoflap_colsqnorm_accum_multi(const ecoflap_colsq_item* items, in
         m.it[i].tickets = (unsigned*)((char*)workspace + (size_t)i * colsq_ticket_bytes(0));
         m.it[i].partial = (float*)((char*)workspace + off);
         m.it[i].first_wg = wg;
+        m.first[i] = wg;
         wg += m.it[i].colblocks * m.it[i].nchunks;
         off += colsq_item_partial_bytes(it.tokens, it.cols);
     }
+    for (int i = n; i < ECOFLAP_COLSQ_MAX_ITEMS; ++i) m.first[i] = 0x7fffffff;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ECOFLAP_F32)
         hipLaunchKernelGGL((colsq_multi_kernel<ECOFLAP_F32>), dim3((unsigned)wg), dim3(256), 0, s, m);
