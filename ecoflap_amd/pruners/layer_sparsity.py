@@ -135,6 +135,7 @@ class LayerSparsity:
         self.process_group = process_group
         self.checkpoint_path = checkpoint_path
         self.checkpoint_every = max(1, int(checkpoint_every))
+        self.resumed_layers = 0            # layers a zeroth-order run took over from its checkpoint
         self.emulate_rank_world = None      # (rank, world): see `_dist`
         assert k1_form in ("units", "block", "triple", "single")
         self.k1_form = k1_form
