@@ -52,7 +52,10 @@ class SparseGPT:
                 and hasattr(self.kernels, "hessian_accum")):
             # fp16 / bf16 activations (the forward under autocast): beta*H + alpha*x^T x on the
             # matrix cores, upper triangle once (csrc/syrk.hip), several samples per call
-            self._pending.append((x if x.is_contiguous() else x.contiguous(), tmp))
+            # (held as it is, not cloned, until the buffer is flushed: an op that writes this Linear's
+            # input in place later in the forward would change H silently — checked at the flush)
+            xc = x if x.is_contiguous() else x.contiguous()
+            self._pending.append((xc, tmp, xc._version))
             if len(self._pending) >= self.samples_per_call:
                 self.flush()
             return
@@ -67,8 +70,15 @@ class SparseGPT:
         read: merge across ranks, twin detection, `fasterprune`)."""
         if not self._pending:
             return
-        xs = [x for x, _ in self._pending]
-        b = sum(n for _, n in self._pending)
+        for x, _, version in self._pending:
+            if x._version != version:
+                self._pending = []
+                raise RuntimeError(
+                    "SparseGPT: a hooked Linear input was modified in place after the hook saw it "
+                    "(the reference reduces it inside the hook, sparsegpt_pruner.py:71-82); set "
+                    "SparseGPT.samples_per_call = 1 for a model that writes activations in place")
+        xs = [x for x, _, _ in self._pending]
+        b = sum(n for _, n, _ in self._pending)
         self._pending = []
         x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
         self.kernels.hessian_accum(self.H, x, self.nsamples, b)

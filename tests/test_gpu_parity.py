@@ -1459,6 +1459,29 @@ def test_sparsegpt_16bit_activations_use_the_mfma_hessian(kern, monkeypatch):
     assert abs((outs["hip"] == 0).float().mean().item() - 0.5) < 0.02
 
 
+def test_sparsegpt_buffered_inputs_written_in_place_are_refused(kern):
+    """The MFMA Hessian path keeps a hooked input (not a copy) until `samples_per_call` samples
+    are there; an op that writes that tensor in place in the meantime would change H silently
+    (the reference reduces inside the hook): the flush refuses, and `samples_per_call = 1`
+    reduces inside the hook."""
+    from ecoflap_amd.pruners.sparsegpt import SparseGPT
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(256, 96, bias=False).to("cuda").to(torch.float16)
+    w = SparseGPT(lin, kernels=kern)
+    x = torch.randn(8, 40, 256, device="cuda").half()
+    w.add_batch(x, None)
+    x.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        w.flush()
+    w2 = SparseGPT(lin, kernels=kern)
+    w2.samples_per_call = 1
+    x = torch.randn(8, 40, 256, device="cuda").half()
+    w2.add_batch(x, None)                 # reduced here
+    x.mul_(2.0)
+    w2.flush()
+    assert w2.nsamples == 8 and float(w2.H.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("tag", ["vit", "blip2"])
 def test_sparsegpt_pruners_hip_equals_oracle(kern, golden_dir, tag, monkeypatch):
     """Same Hessians on both sides (the library expression: the MFMA Hessian agrees with it to
