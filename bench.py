@@ -99,8 +99,17 @@ def parse():
                          "about xGMI / RCCL is measured: the line says what one rank's GPU would "
                          "spend per step, not what N GPUs achieve")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--z-source", default="torch", choices=["torch", "philox"],
+                    help="torch (default, what every entrypoint defaults to): the reference's own draw, "
+                         "torch.manual_seed(seed) + torch.normal on the device (layer_single_base_pruner.py:"
+                         "482-485), regenerated in registers by K1; philox: the build's own cheaper "
+                         "in-register stream (no reference run can equal its table)")
+    ap.add_argument("--unstaged", action="store_true",
+                    help="analysis: the same model with its stage_plan() hidden — what a reference user "
+                         "who swaps the import hands the pruners (INTEGRATION.md §A) — scored through "
+                         "pruners/hooked_prefix.py (no HIP graphs; the chunk's evaluations in lock step)")
     ap.add_argument("--no-parity-leg", action="store_true",
-                    help="skip the short z_source='torch' leg after the timed region")
+                    help="skip the short leg after the timed region that scores two blocks in each z mode")
     ap.add_argument("--no-k1-events", action="store_true",
                     help="no event pairs, no blocker: the uninstrumented loop (rocprofv3 "
                          "cross-check of the K1 durations; the line then carries no roofline)")
@@ -226,7 +235,7 @@ class TimedKernels:
             pair = self.hip_events.pair()
             # per launch: read W, write theta+/theta- of its owned units, write the drifted W
             # (+ one read of z per unit when z comes from memory: the parity mode)
-            zr = (c1 - c0) if z is not None else 0
+            zr = (c1 - c0) if (z is not None and not isinstance(z, str)) else 0
             self.unit_records.append((pair[0], pair[1], (2 * owned + 2 + zr) * s * n))
             return pair
         return self.inner.zo_perturb_units(w, zo_eps, seeds, w_plus, w_minus, z, events=events)
@@ -239,7 +248,7 @@ class TimedKernels:
         # per layer: read W, write theta+/theta- of its owned units, write the drifted W
         # (+ one read of z per unit when z comes from memory: the parity mode)
         nbytes = sum((2 * sum(1 for t in it[3] if t is not None) + 2
-                      + (len(it[5]) if len(it) > 5 and it[5] is not None else 0))
+                      + (len(it[5]) if len(it) > 5 and isinstance(it[5], (list, tuple)) else 0))
                      * it[0].element_size() * it[0].numel() for it in layers)
         pair = self.hip_events.pair()
         self.unit_records.append((pair[0], pair[1], nbytes))
@@ -406,6 +415,10 @@ def main():
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import blip2_flant5xl, blip2_toy
 
+    if args.unstaged:
+        from ecoflap_amd.shapes.blip2_t5 import Blip2T5
+        from ecoflap_amd.shapes.unstaged import hide_stage_plan
+        hide_stage_plan(Blip2T5)
     torch.manual_seed(0)
     t_build = time.time()
     with torch.device(dev):
@@ -457,12 +470,23 @@ def main():
     # one loss closure for warm-up and timed region: graph captures, library heuristics for the
     # new GEMM shapes and the batch-invariance probe are one-time costs of a pruning run (588
     # layers), so the warm-up steps absorb them; the prefix cache itself is reset in between
-    shared_loss = (loss_vision_language if args.full_forward
-                   else PrefixCachedLoss(model, use_graphs=not args.no_graphs,
-                                        n_lanes=args.lanes, eval_batch=args.eval_batch,
-                                        batched_advance=not args.no_batched_advance))
+    if args.full_forward:
+        shared_loss = loss_vision_language
+    elif args.unstaged:
+        # what `blipt5_wanda_pruner` builds for a model without stage_plan() (pruners/wanda.py)
+        from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+        assert not hasattr(model, "stage_plan")
+        shared_loss = HookedPrefixLoss(model, loss_vision_language,
+                                       ["visual_encoder.blocks", "t5_model.encoder.block",
+                                        "t5_model.decoder.block"], ["ln_vision", "Qformer", "t5_proj"],
+                                       eval_batch=args.eval_batch)
+    else:
+        shared_loss = PrefixCachedLoss(model, use_graphs=not args.no_graphs,
+                                       n_lanes=args.lanes, eval_batch=args.eval_batch,
+                                       batched_advance=not args.no_batched_advance)
 
-    def run(layer_ids, timed, z_source="philox", reset=None, events=True):
+    def run(layer_ids, timed, z_source=None, reset=None, events=True):
+        z_source = args.z_source if z_source is None else z_source
         mapping = {prunable[i]: full_mapping[prunable[i]] for i in layer_ids}
         np.random.seed(42)
         loss_fn = shared_loss
@@ -475,7 +499,8 @@ def main():
             # 588-matrix run like the graph captures)
             for key in ("stage_calls", "stage_calls_full", "advance_calls", "graph_captures",
                         "graph_replays", "capture_seconds", "batched_evals", "batched_checks",
-                        "host_blocked_seconds", "guard_gpu_seconds"):
+                        "host_blocked_seconds", "guard_gpu_seconds", "lockstep_seconds", "lockstep_evals",
+                        "events_total", "events_served", "forwards", "events_shared", "events_per_evaluation"):
                 if key in loss_fn.stats:
                     loss_fn.stats[key] = 0
         run.loss_fns.append(loss_fn)
@@ -487,9 +512,11 @@ def main():
         kern.enabled = timed and events and not args.no_k1_events
         out = ls.return_sparsity()
         kern.enabled = False
+        run.z_modes.append(ls.stats.get("z_mode"))
         return ls, out
 
     run.loss_fns = []
+    run.z_modes = []
     # ---- warmup (untimed) ---------------------------------------------------------------
     if args.warmup > 0:
         # the first matrix of the model (every later stage gets captured / probed once) plus the
@@ -516,6 +543,7 @@ def main():
         prof.dump_stats(args.profile_host)
     else:
         ls, table = run(layer_ids, timed=True)
+    run.z_mode_timed = run.z_modes[-1]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -532,24 +560,25 @@ def main():
     class _Snap:
         stats = timed_stats or {}
     snap = _Snap() if timed_stats is not None else object()
-    # ---- outside the timed region: the price of the reference's own z ----------------------
-    # (`z_source="torch"`: torch.manual_seed + torch.normal per unit on the device, z materialised,
-    # K1 one launch per layer fed from memory — the entrypoints' `--z_source torch`).  One ViT-g
-    # block and one FlanT5 decoder block, each scored twice from the same cached prefix: first
-    # with torch's draws, then with the in-register stream.
-    parity_mode = None
+    # ---- outside the timed region: the three ways K1 can get its z, on the same matrices ----
+    # One ViT-g block and one FlanT5 decoder block, each scored three times from the same cached
+    # prefix: "torch" = the reference's draw regenerated in registers (the default, the timed
+    # region's mode unless --z-source says otherwise), "torch_materialised" = every z drawn by
+    # torch.normal itself and read from memory (round 4's default; what the start-up probe falls
+    # back to), "philox" = the build's own in-register stream.
+    z_modes = None
     if not args.no_parity_leg and not args.full_forward and world == 1 and not emulated:
         kern.enabled = False
-        legs = {}
         vit_blocks = [b for b in block_starts if prunable[b].startswith("visual_encoder")]
         dec_blocks = [b for b in block_starts if ".decoder." in prunable[b]]
         picks = [bs[len(bs) // 2] for bs in (vit_blocks, dec_blocks) if bs]
         ends = {b: (block_starts[block_starts.index(b) + 1]
                     if block_starts.index(b) + 1 < len(block_starts) else n_total) for b in picks}
+
         class DrawTimer:
             """The reference's draw (layer_single_base_pruner.py:482-485) with a torch event pair
-            around it: what the z tensors cost to produce (torch.normal's own kernels write each
-            z once; K1 reads it once)."""
+            around it: what the z tensors cost to produce when torch.normal's own kernels write
+            each z once and K1 reads it once."""
 
             def __init__(self):
                 self.pairs, self.bytes = [], 0
@@ -567,69 +596,51 @@ def main():
 
         draws = DrawTimer()
         main_records, main_lpl = kern.unit_records, kern.layers_per_launch
-        kern.unit_records, kern.layers_per_launch = [], []
+        legs, k1_of, lpl_of, seen_mode = {}, {}, {}, {}
+        modes = [("torch", "torch"), ("torch_materialised", draws), ("philox", "philox")]
         for b in picks:
             ids = list(range(b, ends[b]))
             run([b], timed=False, reset=True)               # prefix cache -> this block, untimed
-            for mode in ("torch", "philox"):
+            for mode, src in modes:
+                kern.unit_records, kern.layers_per_launch = k1_of.setdefault(mode, []), lpl_of.setdefault(mode, [])
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                # (the K1 launches of the torch leg carry their event pair: same instrumentation
-                # as the timed region's, it costs the loop nothing)
-                run(ids, timed=True, z_source=draws if mode == "torch" else mode, reset=False,
-                    events=(mode == "torch"))
+                # (the K1 launches carry their event pair: same instrumentation as the timed
+                # region's, it costs the loop nothing)
+                run(ids, timed=True, z_source=src, reset=False)
                 torch.cuda.synchronize()
                 legs.setdefault(mode, []).append((len(ids), time.perf_counter() - t1))
-        parity_k1 = kern.summary(args.k1_form if args.k1_form in ("units", "block") else "units") \
-            if kern.unit_records else None
-        parity_lpl = kern.layers_per_launch
+                seen_mode[mode] = run.z_modes[-1]
+        z_modes = {"what": "one ViT-g block and one FlanT5 decoder block scored in each z mode from the "
+                           "same cached prefix, outside the timed region",
+                   "first_matrices": [prunable[b] for b in picks], "modes": {}}
+        for mode, _ in modes:
+            kern.unit_records, kern.layers_per_launch = k1_of[mode], lpl_of[mode]
+            ksum = kern.summary(args.k1_form if args.k1_form in ("units", "block") else "units") \
+                if kern.unit_records else None
+            n_l = sum(n for n, _ in legs[mode])
+            entry = {"z_mode": seen_mode[mode], "layers": n_l,
+                     "layers_per_s": n_l / sum(t for _, t in legs[mode]),
+                     "ms_per_layer": [1e3 * t / n for n, t in legs[mode]]}
+            if ksum:
+                entry["k1"] = {"achieved": ksum["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ksum["gbs"] / HBM_PEAK_GBS, "launches": ksum["launches"],
+                               "avg_launch_us": ksum["avg_us"],
+                               "algorithmic_bytes_per_launch": ksum["bytes_per_launch"],
+                               "bytes_rule": ("sum over the launch's layers of (3*U+2)*s*numel: z read "
+                                              "from memory per unit" if mode == "torch_materialised" else
+                                              "sum over the launch's layers of (2*U+2)*s*numel: no z bytes"),
+                               "per_launch": ksum["per_launch"]}
+            if mode == "torch_materialised":
+                draw_s = sum(a_.elapsed_time(b_) for a_, b_ in draws.pairs) * 1e-3
+                entry["z_draws"] = {"count": len(draws.pairs), "bytes_written": draws.bytes, "seconds": draw_s,
+                                    "gbs": (draws.bytes / draw_s / 1e9) if draw_s > 0 else None}
+                if ksum and draw_s > 0:
+                    tot_b = ksum["bytes_per_launch"] * ksum["launches"] + draws.bytes
+                    tot_s = ksum["avg_us"] * ksum["launches"] * 1e-6 + draw_s
+                    entry["k1_plus_draws_frac_of_peak"] = tot_b / tot_s / 1e9 / HBM_PEAK_GBS
+            z_modes["modes"][mode] = entry
         kern.unit_records, kern.layers_per_launch = main_records, main_lpl
-        draw_s = sum(a.elapsed_time(b_) for a, b_ in draws.pairs) * 1e-3
-        n_l = sum(n for n, _ in legs["torch"])
-        parity_mode = {
-            "what": "z drawn as the reference does (torch.manual_seed(seed); torch.normal on the "
-                    "device) instead of in registers: same loop, K1 fed from memory, one launch "
-                    "per layer; measured outside the timed region on one ViT-g block and one "
-                    "FlanT5 decoder block, philox leg on the same matrices right after",
-            "layers": n_l,
-            "parity_mode_layers_per_s": n_l / sum(t for _, t in legs["torch"]),
-            "philox_same_layers_per_s": n_l / sum(t for _, t in legs["philox"]),
-            "per_block": [{"first_matrix": prunable[b], "matrices": legs["torch"][i][0],
-                           "torch_ms_per_layer": 1e3 * legs["torch"][i][1] / legs["torch"][i][0],
-                           "philox_ms_per_layer": 1e3 * legs["philox"][i][1] / legs["philox"][i][0]}
-                          for i, b in enumerate(picks)],
-        }
-        parity_mode["slowdown"] = (parity_mode["philox_same_layers_per_s"]
-                                   / parity_mode["parity_mode_layers_per_s"])
-        if parity_k1:
-            parity_mode["roofline"] = {
-                "kernel": ("zo_perturb_layers_kernel<HAS_Z> (ecoflap_zo_perturb_layers_z: one launch "
-                           "per transformer block, every unit's z read from memory)"
-                           if args.k1_form == "block" else "zo_perturb_units_kernel<HAS_Z>"),
-                "bound": "hbm",
-                "achieved": parity_k1["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": parity_k1["gbs"] / HBM_PEAK_GBS,
-                "launches": parity_k1["launches"], "avg_launch_us": parity_k1["avg_us"],
-                "layers_per_launch": parity_lpl,
-                "algorithmic_bytes_per_launch": parity_k1["bytes_per_launch"],
-                "bytes_rule": "sum over the launch's layers of (3*U+2)*s*numel: read W once, per unit "
-                              "read z and write theta+/theta-, write the drifted W",
-                "timing": "kernel begin/end timestamps in HIP events attached to the launch",
-                "per_launch": parity_k1["per_launch"],
-                # producing z is torch.normal's work (library kernels, as in the reference): one
-                # write of s*numel per unit, outside K1; timed by a torch event pair per draw
-                "z_draws": {"count": len(draws.pairs), "bytes_written": draws.bytes,
-                            "seconds": draw_s,
-                            "gbs": (draws.bytes / draw_s / 1e9) if draw_s > 0 else None,
-                            "frac_of_peak": (draws.bytes / draw_s / 1e9 / HBM_PEAK_GBS) if draw_s > 0 else None},
-                # K1 + the draws together against the bytes both move
-                "k1_plus_draws": {
-                    "bytes": parity_k1["bytes_per_launch"] * parity_k1["launches"] + draws.bytes,
-                    "seconds": parity_k1["avg_us"] * parity_k1["launches"] * 1e-6 + draw_s,
-                    "frac_of_peak": ((parity_k1["bytes_per_launch"] * parity_k1["launches"] + draws.bytes)
-                                     / (parity_k1["avg_us"] * parity_k1["launches"] * 1e-6 + draw_s)
-                                     / 1e9 / HBM_PEAK_GBS) if draw_s > 0 else None},
-            }
 
     kind = args.k1_form
     k1 = kern.summary(kind)
@@ -667,7 +678,14 @@ def main():
             "batch_size": args.batch_size,
             "forwards_per_step": 2 * nb_local,
             "k1_form": args.k1_form,
+            "z_source": args.z_source,
+            "z_mode": run.z_mode_timed,
+            "model_protocol": ("un-staged: stage_plan() hidden, block lists only (pruners/hooked_prefix.py)"
+                               if args.unstaged else "staged: stage_plan() (pruners/prefix_cache.py)"),
             "forward_form": ("2 full forwards per unit" if args.full_forward else
+                             (f"exact suffix-only re-forward through forward patches on the block lists, "
+                              f"{args.eval_batch} evaluations in lock step (blocks behind the owner once "
+                              "per chunk, eager launches)") if args.unstaged else
                              "exact suffix-only re-forward from the owning block (activations "
                              "at the block boundary cached per batch)"
                              + ("" if args.no_graphs else ", suffix replayed as a HIP graph")
@@ -696,6 +714,10 @@ def main():
             "guard_gpu_ms_per_step": (1e3 * getattr(snap, "stats", {}).get(
                 "guard_gpu_seconds", 0.0) / args.steps),
             "cpu_model": _cpu_model_name(),
+            # stage 1's one exchange: the [units, 2] loss table, all-reduced once per pass (N > 1)
+            "allreduce_ms": ((ls.stats.get("loss_table_allreduce") or {}).get("stream_ms")
+                             or (ls.stats.get("loss_table_allreduce") or {}).get("host_wall_ms")),
+            "allreduce": ls.stats.get("loss_table_allreduce"),
             "k1_ms_per_step": (k1["avg_us"] * k1["launches"] / args.steps / 1e3) if k1 else None,
             "drift_only": drift,
             "suffix_forward": (_compact_stats(snap.stats) if hasattr(snap, "stats") else None),
@@ -706,16 +728,22 @@ def main():
     }
     if k1:
         out["roofline"] = {
-            "kernel": {"units": "zo_perturb_units_kernel", "triple": "zo_perturb_triple_kernel",
-                       "single": "zo_perturb_kernel",
-                       "block": "zo_perturb_layers_kernel (+ zo_perturb_units_kernel for a layer "
-                                "that is alone in its block within the sample)"}[kind],
+            "kernel": ("zo_torch_layers_kernel (ecoflap_zo_perturb_layers_torch: torch.normal's own "
+                       "device stream regenerated in registers; every K1 form goes through it)"
+                       if run.z_mode_timed == "torch-registers" else
+                       {"units": "zo_perturb_units_kernel", "triple": "zo_perturb_triple_kernel",
+                        "single": "zo_perturb_kernel",
+                        "block": "zo_perturb_layers_kernel (+ zo_perturb_units_kernel for a layer "
+                                 "that is alone in its block within the sample)"}[kind]
+                       + ("<HAS_Z>" if run.z_mode_timed == "torch-materialised" else "")),
+            "z_mode": run.z_mode_timed,
             "bound": "hbm",
             "achieved": k1["gbs"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": k1["gbs"] / HBM_PEAK_GBS,
-            "traffic": load_pmc_traffic(kind, k1["bytes_per_launch"]),
+            "traffic": load_pmc_traffic("torch_" + kind if run.z_mode_timed == "torch-registers" else kind,
+                                        k1["bytes_per_launch"]),
             # NOT a reading of this run (PMC counters cannot be collected from inside the process):
             # this run's algorithmic bytes x the traffic/algorithmic ratio the committed rocprofv3
             # --pmc passes measured for the same kernel (FETCH_SIZE and WRITE_SIZE in separate
@@ -757,9 +785,8 @@ def main():
             "k1_units_chained_per_matrix": nb_local * s_world,
             "k1_units_owned_per_matrix": nb_local,
         }
-    if parity_mode is not None:
-        out["parity_mode_layers_per_s"] = parity_mode["parity_mode_layers_per_s"]
-        out["parity_mode"] = parity_mode
+    if z_modes is not None:
+        out["z_modes"] = z_modes
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, prunable, batches_local, args)
     if rank == 0:
@@ -800,7 +827,8 @@ def load_pmc_traffic(kind, algorithmic_bytes_per_launch=None):
         return None
     try:
         doc = json.load(open(path))
-        ratio = (doc.get(kind) or doc.get("units", {})).get("traffic_over_algorithmic")
+        ratio = (doc.get(kind) or ({} if kind.startswith("torch_") else doc.get("units", {}))).get(
+            "traffic_over_algorithmic")
         return None if ratio is None else ratio * algorithmic_bytes_per_launch
     except Exception:
         return None

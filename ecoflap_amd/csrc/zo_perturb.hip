@@ -527,6 +527,260 @@ __global__ __launch_bounds__(256) void philox_u32_kernel(uint32_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- torch's own device stream, in registers
+// The reference draws z with torch.manual_seed(seed); torch.normal(0, 1, size, device, dtype)
+// (P:482-485).  On this device that is ATen's distribution_elementwise_grid_stride_kernel
+// <float, 4> (torch/include/ATen/native/cuda/DistributionTemplates.h:50-100, shipped with the
+// wheel) over rocRAND's Philox4x32-10 state: T = 256 * grid threads, grid = min(SMs *
+// (maxThreadsPerSM / 256), ceil(n / 256)); thread idx draws rocrand_normal4 once per round j
+// from Philox(counter = {j, 0, idx, 0}, key = {seed_lo, seed_hi}) (curand_init(seed,
+// subsequence = idx, offset = 0): manual_seed resets the generator's offset) and writes the four
+// values to elements idx + T*(4j + ii), ii = 0..3.  Values: rocrand_device::detail::box_muller
+// (rocrand_normal.h:53-68) as hipcc compiled it into libtorch_hip.so for gfx950 — restated
+// below instruction for instruction from that kernel's disassembly (fma contractions, the
+// v_log_f32-based logf with its two-constant ln2 product, the correctly-rounded sqrtf fix-up,
+// __sincosf = v_sin_f32 / v_cos_f32 of v * (1/2pi)), then ATen's transform fma(std, x, mean)
+// with std = 1, mean = 0 and one rounding to the storage dtype.  Nothing here is "close to"
+// torch's stream: tests/test_gpu_parity.py holds it to torch.normal bit for bit, and
+// pruners/layer_sparsity.py probes that equality at start-up before it trusts this path (a
+// torch / rocRAND upgrade that changes the stream sends the run back to materialised draws).
+//
+// Lane geometry: the four values of one Philox call lie T elements apart, so a lane takes the
+// N subsequences idx0 .. idx0+N-1 of one round (N = elements per 16-byte vector) and owns FOUR
+// vectors, one in each of the round's four rows — every global access of the wave is still a
+// contiguous 1 KiB.  Work item I of a layer = (round j, wave chunk c): I = j * wpr + c,
+// wpr = ceil(T / N / 64).
+static __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                     uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// rocrand box_muller(x, y) -> (sin(v) * s, cos(v) * s), as compiled into torch's kernel
+static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, float& zs, float& zc) {
+    const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+    // logf(u) (ocml, u is never subnormal here: u >= 2^-32)
+    const float r = __builtin_amdgcn_logf(u);                       // v_log_f32: log2
+    const float yl = r * 0.693147182464599609375f;                  // 0x3f317217
+    float t = __builtin_fmaf(r, 0.693147182464599609375f, -yl);
+    t = __builtin_fmaf(__uint_as_float(0x3377d1cfu), r, t);
+    const float ln = yl + t;
+    const float x2 = -2.0f * ln;
+    // sqrtf(x2), correctly rounded: v_sqrt_f32 and one step either way (x2 is 0 or >= 1e-7:
+    // ocml's rescaling of tiny arguments never triggers; for x2 = -0 every comparison below is
+    // false and s stays -0, which the final "+ 0" turns into torch's +0)
+    const float s0 = __builtin_amdgcn_sqrtf(x2);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    const float rm = __builtin_fmaf(-sm, s0, x2), rp = __builtin_fmaf(-sp, s0, x2);
+    float s = (0.0f >= rm) ? sm : s0;
+    s = (0.0f < rp) ? sp : s;
+    const float v = __builtin_fmaf((float)y, __uint_as_float(0x30c90fdbu), __uint_as_float(0x30c90fdbu));
+    const float a = v * 0.15915494f;                                // revolutions for v_sin / v_cos
+    // rocRAND's product, then ATen's transform fma(std = 1, x, mean = 0) = x + 0 (a -0 becomes
+    // +0).  The product is an exact zero or a normal number (|sin|, |cos| >= 1e-9 unless 0,
+    // s >= 3e-4 unless 0), so ONE fma with a +0 addend rounds to the same bits as the multiply
+    // followed by the add.
+    zs = __builtin_fmaf(__builtin_amdgcn_sinf(a), s, 0.0f);
+    zc = __builtin_fmaf(__builtin_amdgcn_cosf(a), s, 0.0f);
+}
+
+// z (rounded to the storage dtype, held as f32) of a lane's four vectors in round j:
+// z[ii * N + t] = element idx0 + t + T * (4j + ii)
+template <int DT>
+static __device__ __forceinline__ void torch_z_tile(uint32_t j, uint32_t idx0, uint32_t k0, uint32_t k1,
+                                                    float* z) {
+    constexpr int N = Vec<DT>::N;
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        uint32_t w[4];
+        philox4x32_10(j, 0u, idx0 + t, 0u, k0, k1, w);
+        torch_box_muller(w[0], w[1], z[0 * N + t], z[1 * N + t]);
+        torch_box_muller(w[2], w[3], z[2 * N + t], z[3 * N + t]);
+    }
+    // ATen: static_cast<scalar_t>(...), one rounding to the storage dtype
+    if constexpr (DT != ECOFLAP_F32) {
+#pragma unroll
+        for (int i = 0; i < 4 * N; i += 2) Vec<DT>::round_pair(z[i], z[i + 1], z[i], z[i + 1]);
+    }
+}
+
+// one element (ragged tails, the scalar restatement the tile is tested against)
+template <int DT>
+static __device__ __forceinline__ float torch_z1(int64_t e, int64_t T, uint32_t k0, uint32_t k1) {
+    const int64_t q = e / T;
+    const uint32_t idx = (uint32_t)(e - q * T), j = (uint32_t)(q >> 2);
+    uint32_t w[4];
+    philox4x32_10(j, 0u, idx, 0u, k0, k1, w);
+    float zs, zc;
+    if (q & 2) torch_box_muller(w[2], w[3], zs, zc);
+    else torch_box_muller(w[0], w[1], zs, zc);
+    return Vec<DT>::round((q & 1) ? zc : zs);
+}
+
+struct TorchLane {
+    int64_t v[4];
+    bool ok[4];
+    uint32_t j, idx0;
+};
+// work item I of a tensor of nvec full vectors drawn by T threads
+template <int N>
+static __device__ __forceinline__ TorchLane torch_lane(int64_t I, int64_t T, int64_t nvec) {
+    TorchLane L;
+    const int64_t vpr = T / N, wpr = (vpr + 63) >> 6;
+    const int64_t j = I / wpr, c = I - j * wpr;
+    const int64_t vr = (c << 6) + (threadIdx.x & 63);
+    L.j = (uint32_t)j;
+    L.idx0 = (uint32_t)(vr * N);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        L.v[ii] = (4 * j + ii) * vpr + vr;
+        L.ok[ii] = vr < vpr && L.v[ii] < nvec;
+    }
+    return L;
+}
+static inline int64_t torch_items(int64_t n, int64_t T, int N) {
+    const int64_t rounds = (n + 4 * T - 1) / (4 * T), vpr = T / N;
+    return rounds * ((vpr + 63) / 64);
+}
+static inline int torch_threads_ok(int64_t n, int64_t T) {
+    // T = 256 * grid, grid <= ceil(n / 256); 32-bit subsequence indices
+    return T >= 256 && (T % 256) == 0 && T <= ((n + 255) / 256) * 256 && T < ((int64_t)1 << 31);
+}
+
+#define ECO_XCD_ITEM(I, total)                                                                \
+    const int64_t per__ = (int64_t)(gridDim.x / ECO_XCDS);                                     \
+    const int64_t I = (int64_t)(blockIdx.x % ECO_XCDS) * per__ + blockIdx.x / ECO_XCDS;        \
+    if (I >= (total)) return
+
+// z = torch.normal's draw for (seed, n, dtype), materialised (tests, the start-up probe)
+template <int DT>
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_fill_kernel(void* __restrict__ zout, int64_t n,
+                                                                     int64_t T, int64_t items,
+                                                                     uint32_t k0, uint32_t k1) {
+    constexpr int N = Vec<DT>::N;
+    ECO_XCD_ITEM(I, items);
+    const int64_t nvec = n / N;
+    const TorchLane L = torch_lane<N>(I, T, nvec);
+    float z[4 * N];
+    torch_z_tile<DT>(L.j, L.idx0, k0, k1, z);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+        if (L.ok[ii]) st16(zout, L.v[ii], Vec<DT>::pack(z + ii * N));
+    const int64_t tail0 = nvec * N;
+    if (I == 0 && threadIdx.x < (unsigned)(n - tail0)) {
+        const int64_t e = tail0 + threadIdx.x;
+        Vec<DT>::store1(zout, e, torch_z1<DT>(e, T, k0, k1));
+    }
+}
+
+// one reference K1 call, in place (P:473-486), z = torch's draw
+template <int DT>
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_perturb_kernel(void* __restrict__ w, int64_t n,
+                                                                        int64_t T, int64_t items, float sf,
+                                                                        float eps, uint32_t k0, uint32_t k1) {
+    constexpr int N = Vec<DT>::N;
+    ECO_XCD_ITEM(I, items);
+    const int64_t nvec = n / N;
+    const TorchLane L = torch_lane<N>(I, T, nvec);
+    u32x4 s[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) s[ii] = ld16_if(L.ok[ii], w, L.v[ii]);
+    float z[4 * N];
+    torch_z_tile<DT>(L.j, L.idx0, k0, k1, z);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        float wf[N];
+        Vec<DT>::unpack(s[ii], wf);
+#pragma unroll
+        for (int i = 0; i < N; ++i) wf[i] = k1_step<DT>(wf[i], z[ii * N + i], sf, eps);
+        if (L.ok[ii]) st16(w, L.v[ii], Vec<DT>::pack(wf));
+    }
+    const int64_t tail0 = nvec * N;
+    if (I == 0 && threadIdx.x < (unsigned)(n - tail0)) {
+        const int64_t e = tail0 + threadIdx.x;
+        Vec<DT>::store1(w, e, k1_step<DT>(Vec<DT>::load1(w, e), torch_z1<DT>(e, T, k0, k1), sf, eps));
+    }
+}
+
+// Block-batched K1 (every unit of every layer of a transformer block in ONE launch) with torch's
+// draw in registers.  Device table, one row of ECO_LAYER_ROW_T int64 per layer:
+//   [0] w_in  [1] w_final (may equal w_in: each lane reads its elements before it writes them)
+//   [2] numel  [3] n_units  [4] first work item of the layer in the launch  [5] T
+//   [6 .. 6+U) seeds   [6+U .. 6+2U) theta+ pointers   [6+2U .. 6+3U) theta- pointers
+// A unit's theta+ may alias w_in as well (the triple form).  Algorithmic bytes:
+// (2*U_owned + 2) * s per element — the same as the build's own in-register stream: no z bytes.
+#define ECO_LAYER_ROW_T (6 + 3 * ECOFLAP_MAX_UNITS)
+
+template <int DT>
+__global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_layers_kernel(
+    const int64_t* __restrict__ table, int n_layers, int64_t total_items, float eps) {
+    constexpr int N = Vec<DT>::N;
+    ECO_XCD_ITEM(Ig, total_items);
+    int l = 0;                                     // wave-uniform scan: scalar loads
+    while (l + 1 < n_layers && Ig >= table[(int64_t)(l + 1) * ECO_LAYER_ROW_T + 4]) ++l;
+    const int64_t* __restrict__ row = table + (int64_t)l * ECO_LAYER_ROW_T;
+    const void* win = (const void*)row[0];
+    void* wout = (void*)row[1];
+    const int64_t n = row[2];
+    const int n_units = (int)row[3];
+    const int64_t I = Ig - row[4];
+    const int64_t T = row[5];
+    const int64_t nvec = n / N;
+    const TorchLane L = torch_lane<N>(I, T, nvec);
+    u32x4 s[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) s[ii] = ld16_if(L.ok[ii], win, L.v[ii]);
+    for (int u = 0; u < n_units; ++u) {
+        const uint64_t seed = (uint64_t)row[6 + u];
+        float z[4 * N];
+        torch_z_tile<DT>(L.j, L.idx0, (uint32_t)seed, (uint32_t)(seed >> 32), z);
+        void* dp = (void*)row[6 + ECOFLAP_MAX_UNITS + u];
+        void* dm = (void*)row[6 + 2 * ECOFLAP_MAX_UNITS + u];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            u32x4 p, m;
+            unit_update<DT, true>(s[ii], z + ii * N, eps, p, m);
+            if (dp && L.ok[ii]) {   // dp wave-uniform: not-owned units only carry the drift
+                st16_nt(dp, L.v[ii], p);
+                st16_nt(dm, L.v[ii], m);
+            }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+        if (L.ok[ii]) st16(wout, L.v[ii], s[ii]);
+    const int64_t tail0 = nvec * N;                // ragged tail of this layer: its first wave
+    if (I == 0 && threadIdx.x < (unsigned)(n - tail0)) {
+        const int64_t e = tail0 + threadIdx.x;
+        float a = Vec<DT>::load1(win, e);
+        for (int u = 0; u < n_units; ++u) {
+            const uint64_t seed = (uint64_t)row[6 + u];
+            const float z = torch_z1<DT>(e, T, (uint32_t)seed, (uint32_t)(seed >> 32));
+            a = k1_step<DT>(a, z, 1.0f, eps);
+            const float b = k1_step<DT>(a, z, -2.0f, eps);
+            void* dp = (void*)row[6 + ECOFLAP_MAX_UNITS + u];
+            if (dp) {
+                Vec<DT>::store1(dp, e, a);
+                Vec<DT>::store1((void*)row[6 + 2 * ECOFLAP_MAX_UNITS + u], e, b);
+            }
+            a = k1_step<DT>(b, z, 1.0f, eps);
+        }
+        Vec<DT>::store1(wout, e, a);
+    }
+}
+
 // ---------------------------------------------------------------- launch helpers
 // one single-wave workgroup per super-row of 128 vectors (two 16-byte vectors per lane),
 // rounded up to a multiple of the XCD count for the remap in ECO_FOR_SUPER_ROWS
@@ -741,6 +995,76 @@ extern "C" int ecoflap_philox_u32(uint32_t* out, int64_t n, uint64_t seed, void*
     if (!out) return ECOFLAP_ENULL;
     hipLaunchKernelGGL(philox_u32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, out, n, (uint32_t)seed, (uint32_t)(seed >> 32));
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------- torch's stream: entry points
+extern "C" int64_t ecoflap_torch_normal_threads(int64_t n, int multiprocessors, int max_threads_per_mp) {
+    // ATen calc_execution_policy (DistributionTemplates.h:50-62): block 256
+    if (n <= 0 || multiprocessors <= 0 || max_threads_per_mp < 256) return 0;
+    int64_t grid = (n + 255) / 256;
+    const int64_t cap = (int64_t)multiprocessors * (max_threads_per_mp / 256);
+    if (grid > cap) grid = cap;
+    return grid * 256;
+}
+
+static inline unsigned grid_items(int64_t items) {
+    return (unsigned)((items + ECO_XCDS - 1) / ECO_XCDS * ECO_XCDS);
+}
+
+extern "C" int ecoflap_zo_fill_normal_torch(void* z_out, int64_t n, int dtype, uint64_t seed,
+                                            int64_t threads, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS) return ECOFLAP_ESIZE;
+    if (n == 0) return 0;
+    if (!torch_threads_ok(n, threads)) return ECOFLAP_ESIZE;
+    if (!z_out) return ECOFLAP_ENULL;
+    if (!aligned16(z_out)) return ECOFLAP_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    DISPATCH_DT(dtype, {
+        const int64_t items = torch_items(n, threads, Vec<DT>::N);
+        hipLaunchKernelGGL((zo_torch_fill_kernel<DT>), dim3(grid_items(items)), dim3(ECO_K1_THREADS), 0, s,
+                           z_out, n, threads, items, k0, k1);
+    });
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_zo_perturb_torch(void* w, int64_t n, int dtype, float scaling_factor,
+                                        float zo_eps, uint64_t seed, int64_t threads, void* stream) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (n < 0 || n > ECO_K1_MAX_ELEMS) return ECOFLAP_ESIZE;
+    if (n == 0) return 0;
+    if (!torch_threads_ok(n, threads)) return ECOFLAP_ESIZE;
+    if (!w) return ECOFLAP_ENULL;
+    if (!aligned16(w)) return ECOFLAP_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    DISPATCH_DT(dtype, {
+        const int64_t items = torch_items(n, threads, Vec<DT>::N);
+        hipLaunchKernelGGL((zo_torch_perturb_kernel<DT>), dim3(grid_items(items)), dim3(ECO_K1_THREADS), 0, s,
+                           w, n, threads, items, scaling_factor, zo_eps, k0, k1);
+    });
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ecoflap_zo_perturb_layers_torch(const int64_t* table, int n_layers, int64_t total_items,
+                                               int dtype, float zo_eps, void* stream,
+                                               void* start_event, void* stop_event) {
+    if (!dtype_ok(dtype)) return ECOFLAP_EDTYPE;
+    if (n_layers < 0 || total_items < 0 || total_items > 0x7ffffff0LL) return ECOFLAP_ESIZE;
+    if (n_layers == 0 || total_items == 0) return 0;
+    if (!table) return ECOFLAP_ENULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return ECOFLAP_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DT(dtype, {
+        hipExtLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items(total_items)), dim3(ECO_K1_THREADS),
+                              0, s, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, table, n_layers,
+                              total_items, zo_eps);
+    });
     ECO_CHECK_LAUNCH();
     return 0;
 }

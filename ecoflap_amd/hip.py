@@ -21,7 +21,8 @@ RED_ABSW_ABSG, RED_SQW_SQG, RED_ABSG, RED_ABSW, RED_SQW = 0, 1, 2, 3, 4
 EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
     "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
-    "ecoflap_zo_perturb_layers_z",
+    "ecoflap_zo_perturb_layers_z", "ecoflap_torch_normal_threads", "ecoflap_zo_fill_normal_torch",
+    "ecoflap_zo_perturb_torch", "ecoflap_zo_perturb_layers_torch",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_absprod_reduce_mixed", "ecoflap_colsqnorm_workspace_bytes",
@@ -90,6 +91,11 @@ def load_library():
     lib.ecoflap_zo_perturb_layers.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_zo_perturb_layers_z.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_zo_fill_normal.argtypes = [vp, i64, ci, u64, vp]
+    lib.ecoflap_torch_normal_threads.restype = i64
+    lib.ecoflap_torch_normal_threads.argtypes = [i64, ci, ci]
+    lib.ecoflap_zo_fill_normal_torch.argtypes = [vp, i64, ci, u64, i64, vp]
+    lib.ecoflap_zo_perturb_torch.argtypes = [vp, i64, ci, f32, f32, u64, i64, vp]
+    lib.ecoflap_zo_perturb_layers_torch.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
     lib.ecoflap_absprod_reduce_workspace_bytes.argtypes = [i64]
@@ -176,6 +182,9 @@ class Workspace:
         return self.buf
 
 
+TORCH_Z = "torch"      # z argument of the K1 methods: torch.normal's own device stream, in registers
+
+
 class HipKernels:
     """The HIP backend behind LayerSparsity / the Wanda pruners."""
 
@@ -211,6 +220,13 @@ class HipKernels:
     # ---- K1 ---------------------------------------------------------------------------
     def zo_perturb(self, w, scaling_factor, zo_eps, seed, z=None):
         _gpu(w, "w")
+        if isinstance(z, str):
+            assert z == TORCH_Z
+            _check(self.lib.ecoflap_zo_perturb_torch(
+                _ptr(w), w.numel(), DTYPE_CODE[w.dtype], float(scaling_factor), float(zo_eps),
+                int(seed), self.torch_normal_threads(w.numel(), w.device), _stream()),
+                "ecoflap_zo_perturb_torch")
+            return
         if z is not None:
             _gpu(z, "z")
             if z.dtype != w.dtype or z.numel() != w.numel():
@@ -227,6 +243,10 @@ class HipKernels:
             _gpu(t, n)
             if t.dtype != w_in.dtype or t.numel() != w_in.numel():
                 raise EcoflapHipError("triple buffers must match w_in in dtype and numel")
+        if isinstance(z, str):
+            assert z == TORCH_Z
+            self.zo_perturb_layers_torch([(w_in, w_restored, [seed], [w_plus], [w_minus])], zo_eps)
+            return
         if z is not None:
             _gpu(z, "z")
         _check(self.lib.ecoflap_zo_perturb_triple(
@@ -244,6 +264,13 @@ class HipKernels:
         _gpu(w, "w")
         n_units = len(seeds)
         assert len(w_plus) == n_units and len(w_minus) == n_units
+        if isinstance(z, str):
+            assert z == TORCH_Z
+            for c0 in range(0, n_units, self.MAX_UNITS):
+                c1 = min(n_units, c0 + self.MAX_UNITS)
+                self.zo_perturb_layers_torch([(w, w, seeds[c0:c1], w_plus[c0:c1], w_minus[c0:c1])],
+                                             zo_eps, events=events)
+            return
         for t in list(w_plus) + list(w_minus) + (list(z) if z is not None else []):
             if t is not None:
                 _gpu(t, "unit buffer")
@@ -276,6 +303,9 @@ class HipKernels:
         all of one dtype and one of the two forms, each with at most MAX_UNITS units (None, None
         = drift only); one launch for all of them, drifted weights into w_final (w_in is left
         untouched).  events: optional callable -> (start, stop) raw hipEvent_t handles."""
+        if len(layers[0]) > 5 and isinstance(layers[0][5], str):
+            assert all(item[5] == TORCH_Z for item in layers)
+            return self.zo_perturb_layers_torch([item[:5] for item in layers], zo_eps, events=events)
         has_z = len(layers[0]) > 5 and layers[0][5] is not None
         U = self.MAX_UNITS
         row_len = 5 + (4 if has_z else 3) * U
@@ -328,6 +358,102 @@ class HipKernels:
         _check(fn(_ptr(table), len(rows), total, DTYPE_CODE[dt], float(zo_eps), _stream(),
                   ev[0], ev[1]),
                "ecoflap_zo_perturb_layers_z" if has_z else "ecoflap_zo_perturb_layers")
+
+    # ---- K1 with the reference's own draw (torch.normal's device stream) in registers ---------
+    def torch_normal_threads(self, n, device):
+        """Threads of the launch torch.normal(size = n) makes on `device` (ATen's
+        calc_execution_policy): the element -> (Philox subsequence, round, word) map hangs on it."""
+        key = torch.device(device).index
+        props = getattr(self, "_dev_props", None)
+        if props is None:
+            props = self._dev_props = {}
+        if key not in props:
+            pr = torch.cuda.get_device_properties(device)
+            props[key] = (int(pr.multi_processor_count), int(pr.max_threads_per_multi_processor))
+        return int(self.lib.ecoflap_torch_normal_threads(int(n), *props[key]))
+
+    def zo_fill_normal_torch(self, z_out, seed):
+        """z_out <- what torch.manual_seed(seed); torch.normal(0, 1, z_out.shape, dtype) returns on
+        this device (regenerated by this library, not by torch)."""
+        _gpu(z_out, "z_out")
+        _check(self.lib.ecoflap_zo_fill_normal_torch(
+            _ptr(z_out), z_out.numel(), DTYPE_CODE[z_out.dtype], int(seed),
+            self.torch_normal_threads(z_out.numel(), z_out.device), _stream()),
+            "ecoflap_zo_fill_normal_torch")
+
+    def torch_stream_matches(self, device):
+        """Does `zo_fill_normal_torch` reproduce THIS torch's torch.normal on THIS device bit for
+        bit?  Checked once per device and process (three dtypes, a ragged single-round size and
+        a size that spans rounds, two seeds); torch's generators are left as they were found."""
+        key = ("torch_stream", torch.device(device).index)
+        cache = getattr(self, "_probe_cache", None)
+        if cache is None:
+            cache = self._probe_cache = {}
+        if key in cache:
+            return cache[key]
+        cpu_state = torch.get_rng_state()
+        gpu_state = torch.cuda.get_rng_state(device)
+        ok = True
+        try:
+            t_full = self.torch_normal_threads(1 << 40, device)
+            for dt in (torch.float32, torch.float16, torch.bfloat16):
+                for n, seed in ((1003, 123456789), (4 * t_full + 4104, 987654321)):
+                    torch.manual_seed(seed)
+                    want = torch.normal(mean=0, std=1, size=(n,), device=device, dtype=dt)
+                    got = torch.empty_like(want)
+                    self.zo_fill_normal_torch(got, seed)
+                    ok = ok and bool(torch.equal(want.view(torch.int16 if dt != torch.float32 else torch.int32),
+                                                 got.view(torch.int16 if dt != torch.float32 else torch.int32)))
+        finally:
+            torch.set_rng_state(cpu_state)
+            torch.cuda.set_rng_state(gpu_state, device)
+        cache[key] = ok
+        return ok
+
+    def zo_perturb_layers_torch(self, layers, zo_eps, events=None):
+        """Block-batched K1 with z = torch.normal's draw regenerated in registers: layers =
+        [(w_in, w_final, seeds, w_plus, w_minus)], one dtype, at most MAX_UNITS units per layer;
+        w_final may be w_in, a unit's w_plus may alias w_in."""
+        U = self.MAX_UNITS
+        row_len = 6 + 3 * U
+        dt = layers[0][0].dtype
+        rows, total = [], 0
+        for w_in, w_final, seeds, w_plus, w_minus in layers:
+            _gpu(w_in, "w_in")
+            _gpu(w_final, "w_final")
+            n_units = len(seeds)
+            if n_units > U or len(w_plus) != n_units or len(w_minus) != n_units:
+                raise EcoflapHipError("zo_perturb_layers_torch: at most MAX_UNITS units per layer")
+            if w_in.dtype != dt or w_final.dtype != dt or w_final.numel() != w_in.numel():
+                raise EcoflapHipError("zo_perturb_layers_torch: one dtype per launch, w_final like w_in")
+            if w_in.data_ptr() % 16 or w_final.data_ptr() % 16:
+                raise EcoflapHipError("weights must be 16-byte aligned")
+            for t in list(w_plus) + list(w_minus):
+                if t is not None:
+                    _gpu(t, "unit buffer")
+                    if t.dtype != dt or t.numel() != w_in.numel() or t.data_ptr() % 16:
+                        raise EcoflapHipError("unit buffers must match w_in in dtype and numel, 16-byte aligned")
+            for a, b in zip(w_plus, w_minus):
+                if (a is None) != (b is None):
+                    raise EcoflapHipError("theta+ and theta- of a unit: both or neither")
+            n = w_in.numel()
+            per_vec = 16 // w_in.element_size()
+            threads = self.torch_normal_threads(n, w_in.device)
+            items = -(-n // (4 * threads)) * -(-(threads // per_vec) // 64)
+            row = [w_in.data_ptr(), w_final.data_ptr(), n, n_units, total, threads]
+            row += [(int(x) & (2 ** 64 - 1)) - (2 ** 64 if (int(x) & (2 ** 63)) else 0) for x in seeds]
+            row += [0] * (U - n_units)
+            row += [t.data_ptr() if t is not None else 0 for t in w_plus] + [0] * (U - n_units)
+            row += [t.data_ptr() if t is not None else 0 for t in w_minus] + [0] * (U - n_units)
+            assert len(row) == row_len
+            rows.append(row)
+            total += items
+        table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(layers[0][0].device,
+                                                                      non_blocking=True)
+        ev = events() if events is not None else (None, None)
+        _check(self.lib.ecoflap_zo_perturb_layers_torch(
+            _ptr(table), len(rows), total, DTYPE_CODE[dt], float(zo_eps), _stream(), ev[0], ev[1]),
+            "ecoflap_zo_perturb_layers_torch")
 
     def zo_fill_normal(self, z_out, seed):
         _gpu(z_out, "z_out")

@@ -164,10 +164,37 @@ class LayerSparsity:
         return t
 
     # ------------------------------------------------------------------ K1
-    def _draw_z(self, seed, param):
+    def _torch_z_in_registers(self, param):
+        """z_source="torch" on the GPU: the kernels regenerate torch.normal's own device stream in
+        registers (no z tensor, no library launch) — when the backend has that form and its
+        start-up probe finds it equal to THIS torch's draw on THIS device bit for bit
+        (`HipKernels.torch_stream_matches`); otherwise, or with ECOFLAP_TORCH_Z=materialised,
+        every z is drawn by torch itself and read back from memory."""
+        if self.z_source != "torch":
+            return False
+        mode = getattr(self, "_torch_z_mode", None)
+        if mode is None:
+            import os
+            mode = "materialised"
+            probe = getattr(self.kernels, "torch_stream_matches", None)
+            if (probe is not None and param.data.device.type == "cuda"
+                    and os.environ.get("ECOFLAP_TORCH_Z", "registers") != "materialised"):
+                if probe(param.data.device):
+                    mode = "registers"
+                else:
+                    import warnings
+                    warnings.warn("this torch's torch.normal stream is not the one the K1 kernels "
+                                  "regenerate (torch / rocRAND changed?): z is drawn by torch and "
+                                  "read from memory")
+            self._torch_z_mode = mode
+        return mode == "registers"
+
+    def _draw_z(self, seed, param, materialise=False):
         if self.z_source == "philox":
             return None
         if self.z_source == "torch":
+            if not materialise and self._torch_z_in_registers(param):
+                return _hip.TORCH_Z
             torch.manual_seed(seed)
             return torch.normal(mean=0, std=1, size=param.data.size(), device=param.data.device,
                                 dtype=param.data.dtype)
@@ -189,6 +216,15 @@ class LayerSparsity:
             self.kernels.zo_perturb(param.data, scaling_factor, zo_eps, random_seed, z)
 
     # ------------------------------------------------------------------ schedule
+    def _draw_zs(self, seeds, param):
+        """z argument of a multi-unit K1 call: None (the build's own in-register stream), the
+        TORCH_Z marker (torch's stream in registers) or one tensor per unit."""
+        if self.z_source == "philox":
+            return None
+        if self._torch_z_in_registers(param):
+            return _hip.TORCH_Z
+        return [self._draw_z(sd, param) for sd in seeds]
+
     def _select(self, layer_to_group_mapping):
         names, params = [], []
         for k, v in self.model.named_parameters():
@@ -304,6 +340,8 @@ class LayerSparsity:
             by_layer.setdefault(unit[0], []).append(u)
 
         n_forward = 0
+        if hasattr(self.loss_func, "set_working_set"):
+            self.loss_func.set_working_set(len(batches))
         begin_layer = getattr(self.loss_func, "begin_layer", None)
         # "block": consecutive layers owned by the same stage of the forward share one K1 launch
         groups, stash = {}, {}
@@ -333,8 +371,8 @@ class LayerSparsity:
                 if layer_units:
                     seeds_ = [units[u][3] for u in layer_units]
                     none_ = [None] * len(layer_units)
-                    zs_ = None if self.z_source == "philox" else [self._draw_z(sd_, param) for sd_ in seeds_]
-                    self.kernels.zo_perturb_units(home, zo_eps, seeds_, none_, list(none_), zs_)
+                    self.kernels.zo_perturb_units(home, zo_eps, seeds_, none_, list(none_),
+                                                  self._draw_zs(seeds_, param))
                 continue
             if (ck_file and li > resume_done and (li - resume_done) % self.checkpoint_every == 0):
                 self._save_stage1_checkpoint(ck_file, li, names, units, table)
@@ -363,7 +401,7 @@ class LayerSparsity:
                         # parity mode: every unit's z drawn as the reference draws it (each draw
                         # re-seeds, :482-485, so drawing the block's layers ahead of their turn
                         # changes no value); not-owned units need theirs for the drift
-                        item += ([self._draw_z(units[u][3], params[g]) for u in g_units],)
+                        item += (self._draw_zs([units[u][3] for u in g_units], params[g]),)
                     batch.append(item)
                 self.kernels.zo_perturb_layers(batch, zo_eps)
                 del batch, item
@@ -371,11 +409,14 @@ class LayerSparsity:
                 # one launch: theta+/theta- of every owned unit into scratch, final drifted theta
                 # back into the parameter's own storage; then only forwards remain
                 static_w = bool(getattr(self.loss_func, "requires_static_weights", False))
-                paired = static_w and bool(getattr(self.loss_func, "supports_pairs", lambda: False)())
+                # (a closure without graphs may batch evaluations too: pruners/hooked_prefix.py)
+                paired = bool(getattr(self.loss_func, "supports_pairs", lambda: False)())
                 if paired and self.couple_torch_rng:
-                    raise RuntimeError(
-                        "couple_torch_rng needs one loss at a time (the torch RNG is re-seeded "
-                        "before each loss, :482): use a loss closure without lanes / batching")
+                    if static_w:
+                        raise RuntimeError(
+                            "couple_torch_rng needs one loss at a time (the torch RNG is re-seeded "
+                            "before each loss, :482): use a loss closure without lanes / batching")
+                    paired = False
                 ahead = stash.pop(li, None)
                 if ahead is not None:        # K1 ran with its block: `home` still holds the originals
                     plus, minus, final, scratch = ahead
@@ -384,16 +425,15 @@ class LayerSparsity:
                     n_owned = sum(owned)
                     scratch = torch.empty((2 * max(n_owned, 1),) + tuple(home.shape), dtype=home.dtype,
                                           device=home.device)
-                    plus, minus, zs, k = [], [], [], 0
+                    plus, minus, k = [], [], 0
                     for u, mine in zip(layer_units, owned):
                         plus.append(scratch[2 * k] if mine else None)
                         minus.append(scratch[2 * k + 1] if mine else None)
                         k += int(mine)
-                        zs.append(self._draw_z(units[u][3], param))
+                    zs = self._draw_zs([units[u][3] for u in layer_units], param)
                     if layer_units:
                         self.kernels.zo_perturb_units(
-                            home, zo_eps, [units[u][3] for u in layer_units], plus, minus,
-                            None if self.z_source == "philox" else zs)
+                            home, zo_eps, [units[u][3] for u in layer_units], plus, minus, zs)
                     final = home.clone() if static_w else None   # graphs bake the address of `home`
                 if paired:
                     self.loss_func.begin_layer_weights(name, home)
@@ -477,16 +517,37 @@ class LayerSparsity:
             param.data = home
             del spare
 
+        if getattr(self, "_torch_z_mode", None) == "registers" and units and params:
+            # leave torch's generators where the reference's last K1 call leaves them (:482-485)
+            self._draw_z(units[-1][3], params[units[-1][0]], materialise=True)
         t_enqueued = time.time() - t0            # host done; the device may still be replaying
+        if hasattr(self.loss_func, "finish_run"):
+            self.loss_func.finish_run()
         if table is None:                        # this rank evaluated nothing (more ranks than batches)
             table = torch.zeros(self._table_shape, dtype=torch.float32, device=device)
+        t_ar = None
         if world > 1:
-            self._all_reduce_sum(table)          # each entry is written by exactly one rank
+            # each entry is written by exactly one rank.  Timed for the bench line (BASELINE.md §3
+            # row 4): an event pair on the stream the collective is ordered on (RCCL), and the
+            # host's wall time of the call (gloo blocks the host instead)
+            ev = None
+            if table.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            t_ar = time.time()
+            self._all_reduce_sum(table)
+            t_ar = time.time() - t_ar
+            if ev is not None:
+                ev[1].record()
         # (loss1 - loss2) / (2 eps) with torch's own tensor ops in the loss dtype on the loss
         # tensors' device, as the reference evaluates it per pair (:544), then `.item()` ->
         # python float; ONE sync for the run.
         projected = ((table[:, 0] - table[:, 1]) / (2 * zo_eps)).float().cpu().numpy()
         self.loss_table = table.float().cpu().numpy()
+        allreduce = None
+        if t_ar is not None:
+            allreduce = {"bytes": int(table.numel() * table.element_size()), "host_wall_ms": 1e3 * t_ar,
+                         "stream_ms": float(ev[0].elapsed_time(ev[1])) if ev is not None else None}
 
         grad_sum = {}
         for li, name in enumerate(names):
@@ -521,7 +582,10 @@ class LayerSparsity:
             raise ValueError(f"unknown zeroth-order score_method {self.score_method!r}")
         self.stats = {"seconds": time.time() - t0, "layers": len(names), "units": n_units,
                       "forwards": n_forward, "world_size": world,
-                      "host_enqueue_seconds": t_enqueued}
+                      "host_enqueue_seconds": t_enqueued, "loss_table_allreduce": allreduce,
+                      "z_mode": ("philox" if self.z_source == "philox" else
+                                 "torch-" + getattr(self, "_torch_z_mode", "materialised")
+                                 if self.z_source == "torch" else "callable")}
         return importance
 
     def _couple_rng(self, seed, param):
@@ -529,7 +593,8 @@ class LayerSparsity:
             return
         torch.manual_seed(seed)
         if self.z_source != "philox":
-            self._draw_z(seed, param)     # leaves the generator where the reference's draw does
+            # leaves the generator where the reference's draw does
+            self._draw_z(seed, param, materialise=True)
 
     def _table_for(self, table, loss, device):
         if table is None:

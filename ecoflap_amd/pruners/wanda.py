@@ -592,7 +592,8 @@ class _StageOneMixin:
             lists, extra = self._hook_plan()
             if lists:
                 from .hooked_prefix import HookedPrefixLoss
-                loss_func = HookedPrefixLoss(self.model, loss_func, lists, extra)
+                loss_func = HookedPrefixLoss(self.model, loss_func, lists, extra,
+                                             eval_batch=int(getattr(self, "eval_batch", 1)))
         if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO") and mapping):
             # same losses, bit for bit, from the owning block onwards only

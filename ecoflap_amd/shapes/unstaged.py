@@ -1,0 +1,44 @@
+"""Make one of the build's shape modules look like the reference's own modules to the pruners:
+no `stage_plan()` attribute, `forward` unchanged (it still is the composition of the stage
+functions, captured before the attribute goes).  A reference user who swaps the import
+ hands the pruners exactly such a model — LAVIS's Blip2T5
+(LAVIS/lavis/models/blip2_models/blip2_t5.py:116-168) has block lists and a forward, nothing
+else — so this is what the tests and `bench.py --unstaged` drive the un-staged path
+(pruners/hooked_prefix.py) with."""
+import contextlib
+
+
+@contextlib.contextmanager
+def hidden_stage_plan(*classes):
+    saved = []
+    for cls in classes:
+        plan = cls.__dict__.get("stage_plan")
+        if plan is None:
+            continue
+        fwd = cls.__dict__.get("forward")
+
+        def forward(self, samples, _plan=plan):
+            state = samples
+            for _, _, fn in _plan(self):
+                state = fn(state)
+            return state
+
+        saved.append((cls, plan, fwd))
+        cls.forward = forward
+        del cls.stage_plan
+    try:
+        yield
+    finally:
+        for cls, plan, fwd in saved:
+            cls.stage_plan = plan
+            if fwd is not None:
+                cls.forward = fwd
+            else:
+                del cls.forward
+
+
+def hide_stage_plan(*classes):
+    """The same, for the rest of the process (child processes of the tests, bench.py --unstaged)."""
+    ctx = hidden_stage_plan(*classes)
+    ctx.__enter__()
+    return ctx

@@ -151,6 +151,44 @@ int ecoflap_zo_perturb_layers_z(const int64_t* table, int n_layers, int64_t tota
                                 int dtype, float zo_eps, void* stream,
                                 void* start_event, void* stop_event);
 
+/* ---- the reference's own draw, in registers ------------------------------------------------
+ * layer_single_base_pruner.py:482-485 draws z with torch.manual_seed(seed) followed by ONE
+ * torch.normal(0, 1, size, device = param's device, dtype = param's dtype).  On a GPU that is
+ * ATen's distribution_elementwise_grid_stride_kernel<float, 4> over rocRAND's Philox4x32-10
+ * (torch/include/ATen/native/cuda/DistributionTemplates.h:50-100): `threads` = 256 * grid
+ * threads, thread idx takes rocrand_normal4 number j of Philox(counter {j, 0, idx, 0}, key =
+ * seed) and writes it to elements idx + threads * (4j + 0..3).  The three entry points below
+ * regenerate exactly that stream inside K1 — the same integer stream, the same Box-Muller
+ * instruction sequence as the kernel in libtorch_hip.so (csrc/zo_perturb.hip restates it from
+ * the disassembly), the same single rounding to `dtype` — so z costs no HBM traffic and no
+ * library launch, and the outputs equal the `z` != NULL forms fed torch's own tensor bit for bit
+ * (tests/test_gpu_parity.py; probed at start-up by pruners/layer_sparsity.py, which falls back to
+ * the materialised draw when a torch / rocRAND upgrade changes the stream).
+ * threads: what ATen's calc_execution_policy gives for n on the device at hand:
+ * ecoflap_torch_normal_threads(n, multiProcessorCount, maxThreadsPerMultiProcessor). */
+int64_t ecoflap_torch_normal_threads(int64_t n, int multiprocessors, int max_threads_per_mp);
+
+/* z_out <- the tensor torch.manual_seed(seed); torch.normal(0, 1, [n], dtype) returns. */
+int ecoflap_zo_fill_normal_torch(void* z_out, int64_t n, int dtype, uint64_t seed,
+                                 int64_t threads, void* stream);
+
+/* ecoflap_zo_perturb with z = that draw (one reference K1 call, in place). */
+int ecoflap_zo_perturb_torch(void* w, int64_t n, int dtype, float scaling_factor, float zo_eps,
+                             uint64_t seed, int64_t threads, void* stream);
+
+/* ecoflap_zo_perturb_layers with z = that draw per unit.  table: DEVICE int64
+ * [n_layers][6 + 3*ECOFLAP_MAX_UNITS], row = {w_in, w_final, numel, n_units, first_item, threads,
+ * seeds[MAX_UNITS], w_plus[MAX_UNITS], w_minus[MAX_UNITS]}; a layer of numel elements drawn by
+ * `threads` threads is items_l = ceil(numel / (4*threads)) * ceil(threads / (16/s) / 64) work
+ * items (one wave each: the four 16-byte vectors per lane that one Philox call per element
+ * column feeds); first_item = sum of the earlier layers' items, total_items = the sum over all.
+ * w_final may equal w_in and a unit's w_plus may alias w_in (a lane reads its elements before it
+ * writes them), so this one entry point also serves the units form (one layer, in place) and the
+ * triple form (one unit).  Algorithmic bytes: (2*owned_units + 2) * s per element: no z bytes. */
+int ecoflap_zo_perturb_layers_torch(const int64_t* table, int n_layers, int64_t total_items,
+                                    int dtype, float zo_eps, void* stream,
+                                    void* start_event, void* stop_event);
+
 /* An empty kernel through the same instrumented launch: the floor of that event pair. */
 int ecoflap_null_launch_timed(void* stream, void* start_event, void* stop_event);
 

@@ -125,11 +125,13 @@ def test_loss_table_keeps_the_loss_dtype():
     assert sbf == want and sbf != s32
 
 
-def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatch):
+def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan():
     """A model WITHOUT stage_plan() (the reference's own modules swapped in):
     the hook adapter serves every block-list call before the owning block from its cache and the
     loss table, sparsity table and drifted weights equal the full-forward run bit for bit —
-    through LayerSparsity directly and through the registered pruner."""
+    through LayerSparsity directly and through the registered pruner; per evaluation
+    (eval_batch = 1) and with the chunk's evaluations in lock step (round 5: the blocks behind
+    the owner run ONCE on the evaluations concatenated, the owning Linear per slot)."""
     import numpy as np
     import torch
     from oracle_backend import OracleKernels, torch_cpu_normal
@@ -139,38 +141,30 @@ def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatc
     from ecoflap_amd.pruners.losses import loss_vision_language
     from ecoflap_amd.shapes import synthetic as S
     from ecoflap_amd.shapes.blip2_t5 import Blip2T5, blip2_toy
+    from ecoflap_amd.shapes.unstaged import hidden_stage_plan
 
-    plan = Blip2T5.stage_plan
-
-    def forward(self, samples):                      # the same forward ...
-        state = samples
-        for _, _, fn in plan(self):
-            state = fn(state)
-        return state
-
-    monkeypatch.setattr(Blip2T5, "forward", forward)
-    monkeypatch.delattr(Blip2T5, "stage_plan")       # ... on a model with no stage_plan attribute
-
-    def run(hooked):
+    def run(mode):
         torch.manual_seed(4)
         model = blip2_toy().eval()
         assert not hasattr(model, "stage_plan")
-        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+        batches = S.image_text_batches(16, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
         mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
                    for k, v in model.named_parameters()
                    if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
         loss = loss_vision_language
-        if hooked:
+        if mode != "full":
             loss = HookedPrefixLoss(model, loss_vision_language,
                                     ["visual_encoder.blocks", "t5_model.encoder.block",
-                                     "t5_model.decoder.block"], ["ln_vision", "Qformer", "t5_proj"])
+                                     "t5_model.decoder.block"], ["ln_vision", "Qformer", "t5_proj"],
+                                    eval_batch={"hooked": 1, "lock": 4, "lock_all": 6}[mode],
+                                    verify_batched="all" if mode == "lock_all" else "entries")
         np.random.seed(42)
-        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+        ls = LayerSparsity(model, batches, loss, 16, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
                            kernels=OracleKernels(), z_source=torch_cpu_normal)
         sp = ls.return_sparsity()
         # the forward patches are gone from the instances again (deepcopy / pickle see plain modules)
         assert not any("forward" in m.__dict__ for m in model.modules())
-        if hooked:
+        if mode != "full":
             # a batch object the cache has not seen (same id or not) is never served another
             # batch's record: the cache holds the object it was filled from
             assert all(loss._held[k] is b for k, b in ((id(b), b) for b in batches))
@@ -179,18 +173,10 @@ def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatc
                 a = loss(model, fresh, False)[0]
                 b = loss_vision_language(model, batches[0], False)[0]
             assert torch.equal(a, b)
+            loss.close()
         return ls.loss_table, sp, {k: v.clone() for k, v in model.state_dict().items()}, loss
 
-    full = run(False)
-    hooked = run(True)
-    assert np.array_equal(full[0], hooked[0])
-    assert full[1] == hooked[1]
-    for k in full[2]:
-        assert torch.equal(full[2][k], hooked[2][k]), k
-    st = hooked[3].stats
-    assert st["events_served"] > 0.3 * st["events_total"], st      # most block calls came from cache
-
-    def prune(prefix_cache):
+    def prune(prefix_cache, eval_batch=1):
         torch.manual_seed(4)
         model = blip2_toy().eval()
         batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
@@ -199,17 +185,117 @@ def test_hooked_prefix_adapter_equals_full_forward_without_stage_plan(monkeypatc
                    t5_pruning_method="none", vit_pruning_method="none", num_samples=8,
                    max_sparsity_per_layer=0.6, num_data_first_stage=8,
                    sparsity_ratio_granularity="block", score_method="MEZO-GradOnly_sum",
-                   kernels=OracleKernels(), z_source=torch_cpu_normal)
+                   kernels=OracleKernels(), z_source=torch_cpu_normal, eval_batch=eval_batch)
         pruner = load_pruner("blipt5_wanda_pruner", model, batches, cfg=cfg)
         pruner.prefix_cache = prefix_cache
         model, table = pruner.prune()
-        return table, {k: v.clone() for k, v in model.state_dict().items()}
+        return table, {k: v.clone() for k, v in model.state_dict().items()}, pruner.stage_stats
 
-    t_full, w_full = prune(False)
-    t_hook, w_hook = prune(True)
-    assert t_full == t_hook
-    for k in w_full:
-        assert torch.equal(w_full[k], w_hook[k]), k
+    with hidden_stage_plan(Blip2T5):
+        full = run("full")
+        for mode in ("hooked", "lock", "lock_all"):
+            got = run(mode)
+            assert np.array_equal(full[0], got[0]), mode
+            assert full[1] == got[1], mode
+            for k in full[2]:
+                assert torch.equal(full[2][k], got[2][k]), (mode, k)
+            st = got[3].stats
+            assert st["events_served"] > 0.3 * st["events_total"], st  # most block calls came from cache
+            if mode != "hooked":
+                # every chunk but the first layer's (each batch's first forward runs alone: it
+                # records the batch) went through the lock-step path, the owning block ran once
+                # per chunk with the perturbed Linear per slot, nothing fell back for the run
+                assert st["lockstep_evals"] >= 2 * len(full[0]) - 2 * 8 and st["owner_batched_evals"] > 0, st
+                assert "lockstep_disabled_at" not in st and st["lockstep_checks"] >= 6, st
+                assert st.get("events_shared", 0) + st.get("events_per_evaluation", 0) > 0
+        t_full, w_full, _ = prune(False)
+        for eb in (1, 4):
+            t_hook, w_hook, stats = prune(True, eval_batch=eb)
+            assert t_full == t_hook
+            for k in w_full:
+                assert torch.equal(w_full[k], w_hook[k]), k
+            sf = stats["stage1"]["suffix_forward"]
+            assert (sf.get("lockstep_evals", 0) > 0) == (eb > 1), sf
+    assert hasattr(Blip2T5, "stage_plan")
+
+
+def test_lock_step_evaluation_falls_back_where_it_cannot_share():
+    """Lock step on models that resist it: (a) glue between the blocks that is NOT plumbing (each
+    block's input is made by the model's own code) — every block becomes a segment of its own,
+    losses unchanged; (b) a block argument that differs per evaluation without being
+    batch-leading — the event runs per evaluation; (c) an owner that is called twice in a
+    forward — the chunk runs per evaluation; (d) a call sequence that changes under lock step —
+    the adapter gives up for good, losses still those of the plain forward."""
+    import warnings
+    import numpy as np
+    import torch
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Net(torch.nn.Module):
+        def __init__(self, glue, twice=False, odd=False):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList(
+                [torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Tanh()) for _ in range(4)])
+            self.glue, self.twice, self.odd = glue, twice, odd
+
+        def forward(self, batch):
+            x = batch["x"]
+            for i, blk in enumerate(self.blocks):
+                if self.glue == "scale":
+                    x = x * 1.25                                   # a new tensor per call: not plumbing
+                x = blk(x)
+                if self.twice and i == 1:
+                    x = blk(x)
+                if self.odd and i == 2 and batch.get("skip"):
+                    break
+            return {"loss": x.pow(2).mean()}
+
+    def loss(m, b, c):
+        return m(b)["loss"], b["x"].shape[0]
+
+    def run(net_kw, eval_batch, batches):
+        torch.manual_seed(0)
+        model = Net(**net_kw).eval()
+        name = "blocks.1.0.weight"
+        param = dict(model.named_parameters())[name]
+        home = param.data
+        g = torch.Generator().manual_seed(1)
+        thetas = [(home + 1e-2 * torch.randn(home.shape, generator=g)) for _ in range(2 * len(batches))]
+        hooked = HookedPrefixLoss(model, loss, ["blocks"], eval_batch=eval_batch)
+        hooked.begin_layer(name)
+        hooked.begin_layer_weights(name, home)
+        with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            items = [(b, thetas[2 * i], thetas[2 * i + 1]) for i, b in enumerate(batches)]
+            got = []
+            for rep in range(3):       # (the first call meets batches it has no record of)
+                got = hooked.multi(model, items, False)
+            want = []
+            for b, tp, tm in items:
+                pair = []
+                for th in (tp, tm):
+                    param.data = th
+                    pair.append(loss(model, b, False)[0])
+                param.data = home
+                want.append(pair)
+        hooked.end_layer_weights(None)
+        assert param.data.data_ptr() == home.data_ptr()
+        for (l1, l2, n), (w1, w2), (b, _, _) in zip(got, want, items):
+            assert torch.equal(l1, w1) and torch.equal(l2, w2) and n == b["x"].shape[0]
+        hooked.close()
+        return hooked, w
+
+    torch.manual_seed(3)
+    batches = [{"x": torch.randn(3, 6)} for _ in range(2)]
+    h, _ = run(dict(glue=None), 4, batches)
+    assert h.stats["lockstep_evals"] == 8 and 2 in h.wired and 3 in h.wired
+    h, _ = run(dict(glue="scale"), 4, batches)                     # (a)
+    assert h.stats["lockstep_evals"] == 8 and not h.wired
+    h, _ = run(dict(glue=None, twice=True), 4, batches)            # (c)
+    assert h.stats.get("lockstep_evals", 0) == 0
+    odd = [{"x": torch.randn(3, 6), "skip": False}, {"x": torch.randn(3, 6), "skip": True}]
+    h, w = run(dict(glue=None, odd=True), 4, odd)                  # (d)
+    assert h.disabled and any("not fixed" in str(x.message) for x in w)
 
 
 def test_hooked_prefix_adapter_falls_back_when_the_call_sequence_changes():
