@@ -271,15 +271,19 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
                 t.us = ms * 1e3f;
                 timed.push_back(t);
             }
-            std::sort(timed.begin(), timed.end(), [](const Timed& a, const Timed& b) { return a.us < b.us; });
+            // NO timing enters the choice (two processes of one job — data-parallel ranks, a run
+            // resumed from its stage-1 checkpoint — must pin the same solution, and a single-shot
+            // timing ranks differently from process to process): the survivors are verified in
+            // ASCENDING SOLUTION INDEX and the first one that measures batch invariant and
+            // repeatable is pinned.  The timings above go into the report only.
+            std::sort(timed.begin(), timed.end(), [](const Timed& a, const Timed& b) { return a.index < b.index; });
             if (debug_on())
                 fprintf(stderr, "[gemm_pinned]   %zu of %d distinct solutions are name-clean and support both sizes\n",
                         timed.size(), plan.tried);
-            // stage 2: every survivor (fastest first, at most 8) is MEASURED: batch invariant and
-            // repeatable?  Among those that are, the choice must not hang on a timing — two
-            // processes of one job (data-parallel ranks) have to pin the same solution.
-            std::vector<Timed> good;
-            for (size_t c = 0; ok && c < timed.size() && c < 8; ++c) {
+            // stage 2: MEASURED — batch invariant (the probe problem alone == its first and its last
+            // slot of the 16-slot problem) and repeatable (two runs of the large problem)?
+            const Timed* pick = nullptr;
+            for (size_t c = 0; ok && c < timed.size() && c < 64 && !pick; ++c) {
                 const Timed& t = timed[c];
                 if (run(big, t.big, x, w, yb, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
                 if (run(big, t.big, x, w, yb2, ws, ws_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;
@@ -295,14 +299,12 @@ extern "C" int ecoflap_linear_pinned_plan(int64_t m_probe, int64_t N, int64_t K,
                 }
                 if (debug_on())
                     fprintf(stderr, "[gemm_pinned]   %s %7.1f us  %d %s\n", same ? "PASS" : "fail", t.us, t.index, t.name.c_str());
-                if (same) good.push_back(t);
+                if (same) {
+                    ++plan.passed;
+                    pick = &t;
+                }
             }
-            plan.passed = (int)good.size();
-            if (!good.empty()) {
-                // the LOWEST INDEX among the survivors: no timing enters the choice
-                const Timed* pick = &good[0];
-                for (const Timed& t : good)
-                    if (t.index < pick->index) pick = &t;
+            if (pick) {
                 plan.index = pick->index;
                 plan.name = pick->name;
                 plan.best_us = pick->us;

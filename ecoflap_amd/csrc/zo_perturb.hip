@@ -573,8 +573,9 @@ static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, 
     const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
     // logf(u) (ocml, u is never subnormal here: u >= 2^-32)
     const float r = __builtin_amdgcn_logf(u);                       // v_log_f32: log2
-    const float yl = r * 0.693147182464599609375f;                  // 0x3f317217
-    float t = __builtin_fmaf(r, 0.693147182464599609375f, -yl);
+    const float ln2_hi = __uint_as_float(0x3f317217u);              // ocml's split of ln 2: hi + lo
+    const float yl = r * ln2_hi;
+    float t = __builtin_fmaf(r, ln2_hi, -yl);
     t = __builtin_fmaf(__uint_as_float(0x3377d1cfu), r, t);
     const float ln = yl + t;
     const float x2 = -2.0f * ln;
@@ -587,7 +588,7 @@ static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, 
     float s = (0.0f >= rm) ? sm : s0;
     s = (0.0f < rp) ? sp : s;
     const float v = __builtin_fmaf((float)y, __uint_as_float(0x30c90fdbu), __uint_as_float(0x30c90fdbu));
-    const float a = v * 0.15915494f;                                // revolutions for v_sin / v_cos
+    const float a = v * __uint_as_float(0x3e22f983u);               // 1/(2 pi): revolutions for v_sin / v_cos
     // rocRAND's product, then ATen's transform fma(std = 1, x, mean = 0) = x + 0 (a -0 becomes
     // +0).  The product is an exact zero or a normal number (|sin|, |cos| >= 1e-9 unless 0,
     // s >= 3e-4 unless 0), so ONE fma with a +0 addend rounds to the same bits as the multiply

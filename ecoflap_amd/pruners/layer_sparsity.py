@@ -283,16 +283,48 @@ class LayerSparsity:
             return None
         return self.checkpoint_path if world == 1 else f"{self.checkpoint_path}.rank{rank}of{world}"
 
-    def _save_stage1_checkpoint(self, path, done, names, units, table):
+    def _run_fingerprint(self, names, params, batches):
+        """What a stage-1 checkpoint must share with the run that picks it up, beyond layer names
+        and seeds (those depend on --seed, the architecture and the sample count alone): the
+        perturbation size, how z is drawn, the sample / noise budget, the dtypes, the STARTING
+        weights of every scored layer (sum |W| per layer, one reduce launch each: another
+        --vit/t5_pruned_checkpoint or another init changes it) and the first calibration batch
+        (float64 sums of its tensors).  A checkpoint of a run that differs in any of these holds
+        another table: it is refused, not merged."""
+        import hashlib
+        import json
+        zsrc = self.z_source if isinstance(self.z_source, str) else "callable"
+        head = {"zo_eps": float(self.noise_eps), "z_source": zsrc, "num_samples": int(self.num_samples),
+                "num_noise": int(self.num_noise), "n_batches": len(batches),
+                "dtypes": sorted({str(p.dtype) for p in params}), "score_method": str(self.score_method)}
+        h = hashlib.sha256(json.dumps(head, sort_keys=True).encode())
+        if params:
+            sums = self._weight_sums(params, _hip.RED_ABSW)
+            h.update(np.asarray(sums, dtype=np.float64).tobytes())
+        first = batches[0] if batches else None
+        tensors = []
+        if isinstance(first, dict):
+            tensors = [first[k] for k in sorted(first, key=str) if torch.is_tensor(first[k])]
+        elif isinstance(first, (list, tuple)):
+            tensors = [v for v in first if torch.is_tensor(v)]
+        for t in tensors:
+            h.update(str(tuple(t.shape)).encode())
+            h.update(np.float64(t.double().sum().item()).tobytes())
+        return h.hexdigest(), head
+
+    def _save_stage1_checkpoint(self, path, done, names, units, table, complete=False):
         """Layers [0, done) are finished: their rows of the loss table (this rank's entries) and
-        what identifies the run (layer names, seeds).  One stream sync; written atomically."""
+        what identifies the run (layer names, seeds, `_run_fingerprint`).  One stream sync; written
+        atomically.  complete: the pass is over — a later run with the same identity takes the
+        whole table from the file and replays only the K1 drift."""
         import os
         host = table.detach().float().cpu().numpy() if table is not None else np.zeros(self._table_shape,
                                                                                        np.float32)
         tmp = path + ".tmp.npz"
         np.savez(tmp, done=np.array([done]), names=np.array(names), seeds=np.array([u[3] for u in units],
                  dtype=np.int64), table=host,
-                 table_dtype=np.array(str(table.dtype) if table is not None else "torch.float32"))
+                 table_dtype=np.array(str(table.dtype) if table is not None else "torch.float32"),
+                 fingerprint=np.array(self._fingerprint[0]), complete=np.array([int(bool(complete))]))
         os.replace(tmp, path)
         self.stats_checkpoints = getattr(self, "stats_checkpoints", 0) + 1
 
@@ -309,6 +341,11 @@ class LayerSparsity:
             if not same:
                 warnings.warn(f"stage-1 checkpoint {path} belongs to another run (layers / seeds "
                               "differ): ignored")
+                return 0, None
+            if "fingerprint" not in ck.files or str(ck["fingerprint"]) != self._fingerprint[0]:
+                warnings.warn(f"stage-1 checkpoint {path} was written by a run with other starting "
+                              "weights, calibration data, eps, z source or sample budget "
+                              f"(this run: {self._fingerprint[1]}): ignored")
                 return 0, None
             dtype = getattr(torch, str(ck["table_dtype"]).split(".")[-1])
             table = torch.from_numpy(ck["table"].copy()).to(device=device, dtype=dtype)
@@ -357,6 +394,8 @@ class LayerSparsity:
                     start = li
         max_units = getattr(self.kernels, "MAX_UNITS", 32)
         ck_file = self._checkpoint_file(rank, world)
+        if ck_file:
+            self._fingerprint = self._run_fingerprint(names, params, batches)
         resume_done, resumed = self._load_stage1_checkpoint(ck_file, names, units, device)
         if resumed is not None:
             table = resumed
@@ -517,6 +556,10 @@ class LayerSparsity:
             param.data = home
             del spare
 
+        if ck_file and len(names) > resume_done:
+            # the pass is over: mark the file complete (a rerun of the same command replays the
+            # drift from it; a modified command is refused by the fingerprint)
+            self._save_stage1_checkpoint(ck_file, len(names), names, units, table, complete=True)
         if getattr(self, "_torch_z_mode", None) == "registers" and units and params:
             # leave torch's generators where the reference's last K1 call leaves them (:482-485)
             self._draw_z(units[-1][3], params[units[-1][0]], materialise=True)

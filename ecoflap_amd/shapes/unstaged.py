@@ -37,8 +37,12 @@ def hidden_stage_plan(*classes):
                 del cls.forward
 
 
+_KEEP = []
+
+
 def hide_stage_plan(*classes):
     """The same, for the rest of the process (child processes of the tests, bench.py --unstaged)."""
     ctx = hidden_stage_plan(*classes)
     ctx.__enter__()
+    _KEEP.append(ctx)         # (a collected generator would run its `finally` and undo the hiding)
     return ctx

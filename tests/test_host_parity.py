@@ -456,6 +456,34 @@ def test_stage1_resumes_from_its_checkpoint_bit_for_bit(golden_dir, tmp_path, k1
     sd = model.state_dict()
     for k in names:
         assert np.array_equal(to_bits(sd[k]).ravel(), g[key + f"_final::{k}"].ravel()), k
+    # the finished pass marked its file complete: the same command again takes the whole table
+    # from it (no forward at all) and ends with the same table and weights
+    assert int(np.load(ck)["complete"][0]) == 1 and int(np.load(ck)["done"][0]) == len(names)
+    model2, ls2, calls2 = fresh()
+    sp2 = ls2.return_sparsity()
+    assert ls2.resumed_layers == len(names) and calls2[0] == 0 and sp2 == sp
+    for k in names:
+        assert torch.equal(model2.state_dict()[k], sd[k]), k
+    # ... but a run that differs in what the table depends on is refused, loudly (round 4's file
+    # knew layer names and seeds only): another eps, other starting weights, another first batch
+    for change in ("eps", "weights", "batch"):
+        model, ls, calls = fresh()
+        if change == "eps":
+            ls.noise_eps = 2e-3
+        elif change == "weights":
+            p0 = dict(model.named_parameters())[names[3]]
+            p0.data = p0.data * 1.5
+        else:
+            b0 = ls.data_loader[0]
+            k0 = next(k for k in b0 if torch.is_tensor(b0[k]) and b0[k].is_floating_point())
+            ls.data_loader = [dict(b0, **{k0: b0[k0] + 1})] + list(ls.data_loader[1:])
+        np.random.seed(int(g[key + "_cfg"][0]))
+        with pytest.warns(UserWarning, match="other starting weights"):
+            ls.return_sparsity()
+        assert ls.resumed_layers == 0 and calls[0] == 8 * len(names), change
+        os.remove(ck)
+        model, ls, calls = fresh()          # put the reference run's complete file back
+        ls.return_sparsity()
     # a checkpoint of another run (other seeds) is ignored, loudly
     model, ls, calls = fresh()
     np.random.seed(7)

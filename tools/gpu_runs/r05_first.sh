@@ -15,5 +15,4 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --unstaged --no-cpu-b
 echo "bench unstaged rc=$?"
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --z-source philox --no-cpu-baseline --no-parity-leg > $O/bench_philox.json 2> $O/bench_philox.err
 echo "bench philox rc=$?"
-tail -5 $O/pytest_new.log $O/pytest_dp.log
-tail -3 $O/*.err
+for f in $O/pytest_new.log $O/pytest_dp.log $O/*.err; do echo "== $f"; tail -n 4 $f; done
