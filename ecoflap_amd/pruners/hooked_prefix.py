@@ -204,6 +204,10 @@ class HookedPrefixLoss:
         self.verify_batched = verify_batched
         self.invariant = {}                   # (family, width, event) -> shared result == alone, bit for bit
         self._owner_ok = {}                   # (family, matrix) -> per-slot owner == per-evaluation owner
+        self._owner_block_ok = {}             # (family, owner event, width) -> checked on every slot
+        # inside a wired run of blocks the parked forwards get the un-sliced batched output back
+        # (they only hand it on to the next, served, block); False: every event sliced per evaluation
+        self.lazy_slices = os.environ.get("ECOFLAP_LOCKSTEP_LAZY", "1") != "0"
         self._verified = set()                # (family, owner event) whose lock-step losses were checked
         self._pair_name = self._pair_home = self._pair_param = None
         self._workers = []                    # lock-step threads, kept from chunk to chunk
@@ -483,7 +487,21 @@ class HookedPrefixLoss:
         losses = None
         if not self.disabled and self.eval_batch > 1:
             try:
-                losses = self._lockstep(model, evals, cuda_enabled)
+                try:
+                    losses = self._lockstep(model, evals, cuda_enabled)
+                except _SequenceChanged:
+                    raise
+                except Exception as ex:
+                    if not self.lazy_slices:
+                        raise
+                    # glue that looks at a value it only seemed to pass on (a shape test between
+                    # two blocks): hand every event out sliced per evaluation from here on
+                    import warnings
+                    warnings.warn(f"HookedPrefixLoss: lock step with shared intermediate values failed "
+                                  f"({type(ex).__name__}: {ex}); slicing every event per evaluation")
+                    self.lazy_slices = False
+                    self.stats["lazy_slices_disabled"] = f"{type(ex).__name__}: {ex}"[:200]
+                    losses = self._lockstep(model, evals, cuda_enabled)
             except _SequenceChanged:
                 self._give_up()
                 losses = None
@@ -655,6 +673,10 @@ class HookedPrefixLoss:
         return [c.result[0].detach().clone() for c in ctxs]
 
     # -- the coordinator's side: one segment for all parked evaluations ---------------------------
+    # Arguments and outputs of an event travel in one of two forms: "cat" — ONE set of leaves whose
+    # batch-leading tensors hold the k evaluations concatenated along dim 0 (everything else is
+    # shared) — or "per": k sets of leaves.  A wired segment stays in cat form from event to
+    # event: no slice, no re-concatenation, no per-evaluation Python between two blocks.
     def _run_segment(self, e0, ctxs, thetas, owner_ev, fam, B):
         k = len(ctxs)
         flat = [_flatten((c.pending[2], c.pending[3])) for c in ctxs]
@@ -664,48 +686,75 @@ class HookedPrefixLoss:
         state = ctxs[0].pending[4]
         if self.autocast_at.get(e0, state) != state or any(c.pending[4] != state for c in ctxs):
             raise _SequenceChanged()
-        leaves = [f[0] for f in flat]
+        per = [f[0] for f in flat]                # the heads' arguments come per evaluation
+        cat = self._cat(per, B, (fam, e0))
         n = len(self.sequence)
         e = e0
         first_of = {}
         for i, c in enumerate(ctxs):
             first_of.setdefault(c.key, i)
+        lazy = self.lazy_slices
         while True:
             mod = self.sequence[e]
+            if cat is None and per is not None and e != e0:
+                cat = self._cat(per, B, (fam, e))     # (behind an event that ran per evaluation)
             with torch.no_grad(), _autocast_as(self.autocast_at.get(e, state)):
                 if e == owner_ev:
-                    outs = self._owner_event(e, mod, spec, leaves, thetas, fam, B)
+                    out_cat, out_per = self._owner_event(e, mod, spec, cat, per, thetas, fam, B, k)
                 else:
-                    outs = self._shared_event(e, mod, spec, leaves, fam, B)
+                    out_cat, out_per = self._shared_event(e, mod, spec, cat, per, fam, B, k)
+            nxt = e + 1
+            w = self.wired.get(nxt) if nxt < n else None
+            out_cat_leaves = _flatten(out_cat)[0] if out_cat is not None else None
+            need_per = (out_cat is None or w is None or not lazy or e < ctxs[0].limit)
+            if need_per and out_per is None:
+                out_per = self._split(out_cat, k, B)
+            # what the parked forwards get back for this event: inside a wired run the model only
+            # hands the value on to the next (served) block, so every evaluation gets the SAME
+            # un-sliced object; the last event of the run, which real glue consumes, is sliced
             for i, c in enumerate(ctxs):
-                c.ready[e] = outs[i]
+                c.ready[e] = out_per[i] if need_per else out_cat
             if e < ctxs[0].limit:
                 # an event before the owner that was not on record yet (the scored matrix moved
                 # on): computed with the finished layers' weights, it is what every later
                 # evaluation of these batches will be served
                 for key, i in first_of.items():
                     cached = ctxs[i].cached
-                    keep = _map(outs[i], lambda t: t.detach().clone())
+                    keep = _map(out_per[i], lambda t: t.detach().clone())
                     if e < len(cached):
                         cached[e] = keep
                     elif e == len(cached):
                         cached.append(keep)
                     else:
                         raise _SequenceChanged()
-            nxt = e + 1
-            w = self.wired.get(nxt)
-            if nxt >= n or w is None:
+            if w is None:
                 return
-            out_leaves = [_flatten(o)[0] for o in outs]
-            new_leaves = []
-            for i in range(k):
-                row = []
-                for kind, ref in w[1]:
-                    row.append(out_leaves[i][ref] if kind == "o" else leaves[i][ref] if kind == "a" else ref)
-                new_leaves.append(row)
-                a = _unflatten(w[0], row)[0]
-                ctxs[i].expect[nxt] = a[0] if a and torch.is_tensor(a[0]) else None
-            leaves, spec, e = new_leaves, w[0], nxt
+            # the next event's arguments by the recorded plumbing, in the form(s) at hand
+            new_cat = new_per = None
+            if out_cat is not None and cat is not None:
+                new_cat = [out_cat_leaves[ref] if kind == "o" else cat[ref] if kind == "a" else ref
+                           for kind, ref in w[1]]
+            if need_per or new_cat is None:
+                if per is None:
+                    per = self._uncat(cat, k, B)
+                out_per_leaves = [_flatten(o)[0] for o in out_per]
+                new_per = [[out_per_leaves[i][ref] if kind == "o" else per[i][ref] if kind == "a" else ref
+                            for kind, ref in w[1]] for i in range(k)]
+            if need_per:
+                for i, c in enumerate(ctxs):
+                    a_ = _unflatten(w[0], new_per[i])[0]
+                    c.expect[nxt] = a_[0] if a_ and torch.is_tensor(a_[0]) else None
+            else:
+                a_ = _unflatten(w[0], new_cat)[0]
+                exp = a_[0] if a_ and torch.is_tensor(a_[0]) else None
+                for c in ctxs:
+                    c.expect[nxt] = exp
+            cat, per, spec, e = new_cat, new_per, w[0], nxt
+
+    @staticmethod
+    def _uncat(cat, k, B):
+        return [[t[i * B:(i + 1) * B] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == k * B) else t
+                 for t in cat] for i in range(k)]
 
     def _call(self, mod, spec, leaves):
         a, kw = _unflatten(spec, leaves)
@@ -759,64 +808,96 @@ class HookedPrefixLoss:
                                           for t in leaves]))
         return rows
 
-    def _bitwise_same(self, a, b):
+    def _slots_same(self, alone, outs):
+        """every slot of a shared result == that evaluation's own result, bit for bit (one fused
+        compare launch per slot OR-ing into one flag, ONE read-back)"""
         from .prefix_cache import _differ_flag
-        fa = [t for t in _flatten(a)[0] if torch.is_tensor(t)]
-        fb = [t for t in _flatten(b)[0] if torch.is_tensor(t)]
-        if len(fa) != len(fb) or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(fa, fb)):
-            return False
+        flag = None
         t0 = time.time()
-        same = not bool(_differ_flag([x.contiguous() for x in fa], [y.contiguous() for y in fb]).item())
+        for a, o in zip(alone, outs):
+            fa = [t for t in _flatten(a)[0] if torch.is_tensor(t)]
+            fb = [t for t in _flatten(o)[0] if torch.is_tensor(t)]
+            if len(fa) != len(fb) or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(fa, fb)):
+                return False
+            flag = _differ_flag([x.contiguous() for x in fa], [y.contiguous() for y in fb], flag)
+        same = flag is None or not bool(flag.item())
         self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t0
         return same
 
-    def _shared_event(self, e, mod, spec, leaves, fam, B):
-        k = len(leaves)
+    PAD_SLOTS = 2      # see prefix_cache.py: the library's fp32 GEMMs treat the LAST rows of a problem differently
+
+    def _shared_call(self, mod, spec, cat, k, B, pad):
+        """-> the event's output in cat form (k slots), computed at width k + pad"""
+        if cat is None:
+            return None
+        try:
+            if not pad:
+                return self._call(mod, spec, cat)
+            wide = [torch.cat([t, t[(k - 1) * B:].repeat((pad,) + (1,) * (t.dim() - 1))], 0)
+                    if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == k * B) else t for t in cat]
+            out = self._call(mod, spec, wide)
+            leaves, ospec = _flatten(out)
+            return _unflatten(ospec, [t[:k * B] if (torch.is_tensor(t) and t.dim() > 0
+                                                    and t.shape[0] == (k + pad) * B) else t for t in leaves])
+        except Exception as ex:                   # a module that cannot take the concatenated batch
+            self.stats["shared_call_error"] = f"{self.paths[mod]}: {type(ex).__name__}: {ex}"[:300]
+            return None
+
+    def _shared_event(self, e, mod, spec, cat, per, fam, B, k):
+        """One event for all k evaluations -> (output in cat form or None, per-evaluation outputs
+        or None).  ONCE on the concatenated arguments when that gives every slot the bits the
+        evaluation gets alone — measured on first use per (batch-shape family, width, event) on
+        ALL slots (a GEMM library may treat the rows of one slot differently: hipBLASLt's fp32
+        kernels do so with the last rows of a problem) — at width k or, failing that, at width
+        k + PAD_SLOTS with the extra slots carrying a copy of the last evaluation and never read;
+        otherwise k calls."""
         inv = self.invariant.get((fam, k, e))
-        if inv is not False:
-            cat = self._cat(leaves, B, (fam, e))
-            out = None
-            if cat is not None:
-                try:
-                    out = self._split(self._call(mod, spec, cat), k, B)
-                except Exception:                 # a module that cannot take the concatenated batch
-                    out = None
-            if out is not None and inv is None:
-                # probe, once per (batch-shape family, width, event): one slot alone, bit for bit
-                pick = self.stats.get("invariance_probes", 0) % k
-                alone = self._call(mod, spec, leaves[pick])
-                self.stats["invariance_probes"] = self.stats.get("invariance_probes", 0) + 1
-                inv = self._bitwise_same(alone, out[pick])
-            elif out is None:
-                inv = False
-            self.invariant[(fam, k, e)] = bool(inv)
+        if inv is None:
+            if per is None:
+                per = self._uncat(cat, k, B)
+            alone = [self._call(mod, spec, per[i]) for i in range(k)]
+            self.stats["invariance_probes"] = self.stats.get("invariance_probes", 0) + 1
+            inv, keep = False, None
+            for pad in (0, self.PAD_SLOTS):
+                out = self._shared_call(mod, spec, cat, k, B, pad)
+                if out is not None and self._slots_same(alone, self._split(out, k, B)):
+                    inv, keep = ("pad", pad), out
+                    break
+            self.invariant[(fam, k, e)] = inv
             if not inv:
                 self.stats.setdefault("events_not_batch_invariant", []).append(self.paths[mod])
-            else:
+            elif inv[1]:
+                self.stats.setdefault("events_shared_with_padding", []).append(self.paths[mod])
+            return keep, alone
+        if inv:
+            out = self._shared_call(mod, spec, cat, k, B, inv[1])
+            if out is not None:
                 self.stats["events_shared"] = self.stats.get("events_shared", 0) + 1
-                return out
+                return out, None
         self.stats["events_per_evaluation"] = self.stats.get("events_per_evaluation", 0) + 1
-        return [self._call(mod, spec, leaves[i]) for i in range(k)]
+        if per is None:
+            per = self._uncat(cat, k, B)
+        return None, [self._call(mod, spec, per[i]) for i in range(k)]
 
-    def _owner_event(self, e, mod, spec, leaves, thetas, fam, B):
+    def _owner_event(self, e, mod, spec, cat, per, thetas, fam, B, k):
         """The owning block of all k evaluations in ONE pass at batch k*B, the perturbed Linear
         applied per slot with its own theta (the very call an evaluation makes alone: same M, N,
         K, same kernel, same bits); checked against the per-evaluation call on first use of every
-        matrix.  Falls back to k calls with theta re-pointed."""
+        matrix.  Falls back to k calls with theta re-pointed.  -> (cat-form output or None,
+        per-evaluation outputs or None)."""
         import torch.nn.functional as F
-        k = len(leaves)
         name = self._pair_name
         param, home = self._pair_param, self._pair_home
         lin = None
-        if name.endswith(".weight") and self._owner_ok.get((fam, name), True):
+        if (name.endswith(".weight") and self._owner_ok.get((fam, name), True)
+                and self._owner_block_ok.get((fam, e, k), True)):
             try:
                 lin = self.model.get_submodule(name[:-len(".weight")])
             except AttributeError:
                 lin = None
             if not isinstance(lin, torch.nn.Linear):
                 lin = None
-        cat = self._cat(leaves, B, (fam, e)) if lin is not None else None
-        if cat is not None:
+        if cat is not None and lin is not None:
             if getattr(lin, "_ecoflap_pinned", False):
                 from ..shapes.fused import linear as _pinned, linear_or_torch as _linear
             else:
@@ -825,7 +906,7 @@ class HookedPrefixLoss:
             def per_slot(x):
                 if x.shape[0] != k * B:           # the Linear's input must carry the k slots in front
                     raise _NotBatchLeading()
-                if _pinned is not None and lin.bias is not None and lin.__dict__.get("_defer_bias"):
+                if _pinned is not None and lin.bias is not None and lin.__dict__.get("_defer_now"):
                     ys = [_pinned(x[i * B:(i + 1) * B], thetas[i], None, library_bias=lin.bias) for i in range(k)]
                     if all(y is not None for y in ys):
                         lin._bias_pending = True
@@ -840,7 +921,7 @@ class HookedPrefixLoss:
             lin.forward = per_slot
             out = None
             try:
-                out = self._split(self._call(mod, spec, cat), k, B)
+                out = self._call(mod, spec, cat)
             except _NotBatchLeading:
                 out = None
             finally:
@@ -849,25 +930,40 @@ class HookedPrefixLoss:
                 else:
                     del lin.forward
             if out is not None and (fam, name) not in self._owner_ok:
-                pick = self.stats.get("owner_checks", 0) % k
-                param.data = thetas[pick]
+                # first use of this MATRIX's per-slot form: against the per-evaluation call — on
+                # every slot for the first matrix of a block (the block's other ops run at k*B
+                # too: their slots are checked once per block and width), one rotating slot after
+                if (fam, e, k) in self._owner_block_ok:
+                    picks = [self.stats.get("owner_checks", 0) % k]
+                else:
+                    picks = list(range(k))
+                if per is None:
+                    per = self._uncat(cat, k, B)
+                alone = []
                 try:
-                    alone = self._call(mod, spec, leaves[pick])
+                    for i in picks:
+                        param.data = thetas[i]
+                        alone.append(self._call(mod, spec, per[i]))
                 finally:
                     param.data = home
                 self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
-                self._owner_ok[(fam, name)] = self._bitwise_same(alone, out[pick])
+                slots = self._split(out, k, B)
+                self._owner_ok[(fam, name)] = self._slots_same(alone, [slots[i] for i in picks])
+                if len(picks) == k:
+                    self._owner_block_ok[(fam, e, k)] = self._owner_ok[(fam, name)]
             if out is None:
                 self._owner_ok[(fam, name)] = False
             if self._owner_ok.get((fam, name), False):
                 self.stats["owner_batched_evals"] = self.stats.get("owner_batched_evals", 0) + k
-                return out
+                return out, None
             self.stats.setdefault("owner_not_batchable", []).append(name)
+        if per is None:
+            per = self._uncat(cat, k, B)
         outs = []
         try:
             for i in range(k):
                 param.data = thetas[i]
-                outs.append(self._call(mod, spec, leaves[i]))
+                outs.append(self._call(mod, spec, per[i]))
         finally:
             param.data = home
-        return outs
+        return None, outs

@@ -931,7 +931,7 @@ class PrefixCachedLoss:
             # shape where the shape modules use it (shapes/fused.py) — the very call an evaluation
             # makes alone —, with the bias left to the consuming op exactly when the module's own
             # forward would leave it there (`_defer_bias`): same kernel, same roundings, same bits
-            if mod.bias is not None and mod.__dict__.get("_defer_bias"):
+            if mod.bias is not None and mod.__dict__.get("_defer_now"):
                 ys = [_pinned(x[i * B:(i + 1) * B], thetas[i], None, library_bias=mod.bias) for i in range(k)]
                 if all(y is not None for y in ys):
                     mod._bias_pending = True

@@ -100,8 +100,9 @@ class Block(nn.Module):
         # (a Linear pinned by fused.pin_linears may return its output WITHOUT the bias; the op
         # that consumes the output adds it: `take_pending_bias` says whether this call did)
         h = fused.add_layernorm(x, None, self.norm1)
-        a = self.attn(fused.trace("00_ln1", self.norm1(x) if h is None else h[1]),
-                      rel_pos_bias=rel_pos_bias)
+        with fused.deferring_bias(self.attn.proj):      # this call only: see fused.deferring_bias
+            a = self.attn(fused.trace("00_ln1", self.norm1(x) if h is None else h[1]),
+                          rel_pos_bias=rel_pos_bias)
         pb = fused.take_pending_bias(self.attn.proj)
         h = fused.add_layernorm(x, a, self.norm2, residual_bias=pb)
         if h is None:
@@ -114,12 +115,14 @@ class Block(nn.Module):
         fused.trace("03_proj", a)            # (without the proj bias when it was deferred)
         fused.trace("04_x1", x)
         fused.trace("05_ln2", h2)
-        m = self.mlp.fc1(h2)                 # Mlp.forward, op by op
+        with fused.deferring_bias(self.mlp.fc1):
+            m = self.mlp.fc1(h2)             # Mlp.forward, op by op
         b1 = fused.take_pending_bias(self.mlp.fc1)
         fused.trace("06_fc1", m)
         m = fused.bias_gelu(m, b1) if b1 is not None else self.mlp.act(m)
         fused.trace("07_gelu", m)
-        m = self.mlp.fc2(m)
+        with fused.deferring_bias(self.mlp.fc2):
+            m = self.mlp.fc2(m)
         b2 = fused.take_pending_bias(self.mlp.fc2)
         fused.trace("08_fc2", m)
         out = fused.bias_add_residual(x, m, b2) if b2 is not None else x + m

@@ -451,11 +451,12 @@ def linear_or_torch(x, weight, bias):
 
 
 def _pinned_forward(self, x):
-    # a Linear whose parent block adds the bias in the op that consumes the output anyway
-    # (`_defer_bias`, set by pin_linears): the pinned solutions have no bias epilogue on gfx950,
+    # a Linear whose consumer asked, FOR THIS CALL (`deferring_bias`: the EVA block's forward), to
+    # add the bias itself in the op that consumes the output anyway; any other caller — `blk.mlp(x)`,
+    # a forward hook, a feature reader — gets the full Linear.  Why at all: the pinned solutions have no bias epilogue on gfx950,
     # and a bias prefill + beta = 1 costs a write and a read of the output (measured: -10 % on
     # the bench).  The flag the consumer reads says whether THIS call left the bias out.
-    if self.bias is not None and self.__dict__.get("_defer_bias"):
+    if self.bias is not None and self.__dict__.get("_defer_now"):
         y = linear(x, self.weight, None, library_bias=self.bias)
         if y is not None:
             self._bias_pending = True
@@ -464,6 +465,26 @@ def _pinned_forward(self, x):
     # (`_call_bias`: a bias that is not the module's own parameter, handed over for this call by
     # the parent — EVA's qkv Linear has bias=False and its q / v biases live in the Attention)
     return linear_or_torch(x, self.weight, self.bias if self.bias is not None else self.__dict__.get("_call_bias"))
+
+
+class deferring_bias:
+    """`with deferring_bias(lin): y = lin(x)` (or a call that reaches `lin`): the caller takes over
+    `lin`'s bias for the calls inside — it MUST read `take_pending_bias(lin)` afterwards and add
+    what that returns.  The request lives exactly as long as the block; a Linear that is not one
+    of `pin_linears`' (CPU, fp32, autograd) ignores it and returns its biased output."""
+
+    def __init__(self, *mods):
+        self.mods = [m for m in mods if m.__dict__.get("_defer_bias")]
+
+    def __enter__(self):
+        for m in self.mods:
+            m.__dict__["_defer_now"] = True
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m.__dict__.pop("_defer_now", None)
+        return False
 
 
 def take_pending_bias(mod):
@@ -520,8 +541,8 @@ def pin_linears(model):
             mod.forward = types.MethodType(_pinned_forward, mod)
             mod._ecoflap_pinned = True
             n += 1
-        if isinstance(mod, Block):          # its forward adds these biases in the consuming op
-            for lin in (mod.attn.proj, mod.mlp.fc1, mod.mlp.fc2):
+        if isinstance(mod, Block):          # its forward MAY add these biases in the consuming op
+            for lin in (mod.attn.proj, mod.mlp.fc1, mod.mlp.fc2):   # (eligible; asked for per call)
                 if lin.bias is not None:
                     lin._defer_bias = True
     return n

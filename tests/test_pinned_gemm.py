@@ -199,6 +199,23 @@ def test_pinned_block_defers_its_biases_and_tracks_the_plain_block(monkeypatch):
     assert not any(m.__dict__.get("_bias_pending") for m in pinned.modules())      # every bias was taken
     err = (y0 - y1).abs().max().item()
     assert err <= 2e-2 * y0.abs().max().item(), err
+    # the deferral is the BLOCK's request, per call (round 5): anyone else calling these Linears —
+    # `blk.mlp(x)`, `blk.attn(x)`, a hook on the Linear's output — gets the bias, and no request
+    # or pending flag outlives a call
+    for m in (pinned.mlp.fc1, pinned.mlp.fc2, pinned.attn.proj):
+        m.bias.data.fill_(3.0)
+    for m in (plain.mlp.fc1, plain.mlp.fc2, plain.attn.proj):
+        m.bias.data.fill_(3.0)
+    seen = []
+    hook = pinned.mlp.fc2.register_forward_hook(lambda mod, i, o: seen.append(o.float().mean().item()))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for fn in (lambda b: b.mlp(x), lambda b: b.attn(x), lambda b: b.mlp.fc1(x)):
+            a0, a1 = fn(plain).float(), fn(pinned).float()
+            assert (a0 - a1).abs().max().item() <= 2e-2 * a0.abs().max().item()       # 3.0 apart if dropped
+        hook.remove()
+        ref_mean = plain.mlp(x).float().mean().item()
+    assert seen and abs(seen[0] - ref_mean) < 0.1
+    assert not any(m.__dict__.get("_bias_pending") or m.__dict__.get("_defer_now") for m in pinned.modules())
 
 
 def test_f32_mfma_gemm_is_exact_to_rounding_batch_invariant_and_repeatable(monkeypatch):
