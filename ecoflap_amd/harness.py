@@ -67,6 +67,10 @@ def build_parser():
                    help="loss evaluations of a layer per pass of the batch-invariant suffix (1: one "
                         "suffix per evaluation)")
     p.add_argument("--lanes", type=int, default=2, help="concurrent evaluation lanes (weight replicas)")
+    p.add_argument("--unstaged", action="store_true",
+                   help="hide the shape module's stage_plan(): the pruners then see what a reference "
+                        "user's own model looks like (block lists and a forward, INTEGRATION.md §A) and "
+                        "score it through pruners/hooked_prefix.py — same table, same pruned weights")
     p.add_argument("--stage1_checkpoint", type=str, default=None,
                    help="zeroth-order stage 1: file that receives the loss table of the finished "
                         "layers every 32 layers; a rerun of the same command resumes behind the last "
@@ -78,6 +82,12 @@ def build_parser():
 def build_model_and_loader(args, device):
     from .shapes import synthetic as S
     bs = args.prunining_dataset_batch_size
+    if getattr(args, "unstaged", False):
+        from .shapes.blip2_t5 import Blip2T5
+        from .shapes.eva_clip import EVACLIP
+        from .shapes.t5 import T5 as _T5
+        from .shapes.unstaged import hide_stage_plan
+        hide_stage_plan(Blip2T5, _T5, EVACLIP)
     if args.shape == "blip2":
         from .shapes.blip2_t5 import blip2_flant5xl, blip2_toy
         with torch.device(device):

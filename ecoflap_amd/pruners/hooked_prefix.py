@@ -131,7 +131,7 @@ class _Abort(BaseException):
 class _Ctx:
     """One forward in flight: which batch, what may be served, where it is in the sequence."""
     __slots__ = ("owner", "key", "n_valid", "limit", "cached", "counter", "ready", "expect", "pending",
-                 "lock", "seen", "record", "abort", "wake", "result", "error", "done")
+                 "lock", "seen", "record", "abort", "wake", "result", "error", "done", "slot")
 
     def __init__(self, owner, key, n_valid, limit, cached, lock):
         self.owner, self.key, self.n_valid, self.limit, self.cached = owner, key, n_valid, limit, cached
@@ -140,6 +140,7 @@ class _Ctx:
         self.lock = lock              # lock-step worker (parks at heads) or a plain sequential forward
         self.seen, self.record = [], None
         self.abort, self.wake, self.result, self.error, self.done = False, None, None, None, False
+        self.slot = 0
 
 
 class _Worker(threading.Thread):
@@ -171,7 +172,7 @@ class HookedPrefixLoss:
     requires_static_weights = False       # no graphs: theta is re-pointed / applied per slot
 
     def __init__(self, model, loss_func, block_lists, extra_modules=(), max_batches=256, eval_batch=1,
-                 verify_batched="entries"):
+                 verify_batched="entries", use_graphs=True):
         self.model = model
         # batches whose recorded activations are kept (least recently used goes first).
         # `LayerSparsity` takes the calibration prefix ONCE and re-uses those batch objects for
@@ -210,7 +211,16 @@ class HookedPrefixLoss:
         self.lazy_slices = os.environ.get("ECOFLAP_LOCKSTEP_LAZY", "1") != "0"
         self._verified = set()                # (family, owner event) whose lock-step losses were checked
         self._pair_name = self._pair_home = self._pair_param = None
+        # the shared (batched) calls of the cacheable modules behind the owner are replayed from HIP
+        # graphs when a module lets itself be captured (static shapes, no host sync); one that does
+        # not stays eager.  The model's own glue and the owning block are never captured.
+        self.use_graphs = bool(use_graphs) and os.environ.get("ECOFLAP_LOCKSTEP_GRAPHS", "1") != "0"
+        self._graphs = {}                     # (family, width, event, pad) -> captured call or False
+        self._graph_pool = None
         self._workers = []                    # lock-step threads, kept from chunk to chunk
+        self._params = None                   # name -> Parameter (built once: 1000+ entries)
+        self._keep_patched = False            # inside a LayerSparsity pass
+        self._patch_state = None
         self._lens = {}                       # id(samples) -> batch length, for `multi`'s result
         self._value_shared = set()            # (family, event, leaf) tensors equal across evaluations
         self._assumed = None                  # device flag: such a tensor differed after all
@@ -243,6 +253,8 @@ class HookedPrefixLoss:
     def close(self):
         """End the lock-step worker threads (they are daemons: not calling this leaks nothing
         past the interpreter's exit)."""
+        self._keep_patched = False
+        self._uninstall()
         for w in self._workers:
             w.stop = True
             w.wake.set()
@@ -269,7 +281,10 @@ class HookedPrefixLoss:
 
     def begin_layer_weights(self, name, home):
         self._pair_name, self._pair_home = name, home
-        self._pair_param = dict(self.model.named_parameters())[name]
+        self._keep_patched = True
+        if self._params is None:
+            self._params = dict(self.model.named_parameters())
+        self._pair_param = self._params[name]
 
     def end_layer_weights(self, final):
         self._pair_name = self._pair_home = self._pair_param = None
@@ -277,9 +292,16 @@ class HookedPrefixLoss:
     def join(self):
         pass
 
+    def abort_run(self):
+        """`LayerSparsity` calls this when a pass dies: the instances get their forwards back."""
+        self._keep_patched = False
+        self._uninstall()
+
     def finish_run(self):
         """Called by `LayerSparsity` before it reads the loss table: the assumptions made without
         a host sync must have held."""
+        self._keep_patched = False
+        self._uninstall()
         if self._assumed is not None and bool(self._assumed.item()):
             raise RuntimeError("HookedPrefixLoss: a tensor assumed equal across the evaluations of a "
                                "chunk differed; rerun with eval_batch=1")
@@ -319,25 +341,43 @@ class HookedPrefixLoss:
                 warnings.warn(f"HookedPrefixLoss: more than {self.max_batches} calibration batches in "
                               "flight; the oldest records are dropped (their prefixes re-run)")
 
-    @contextlib.contextmanager
-    def _patched(self):
-        """Instance-level forwards on the cacheable modules for the duration of a call; the
-        instances are left as they were found (deepcopy / pickle see plain modules)."""
+    def _install(self):
+        """Instance-level forwards on the cacheable modules (written straight into the instance
+        dict: nn.Module.__setattr__ costs 4 us a piece, 100 modules, every chunk)."""
+        if self._patch_state is not None:
+            return
         originals, had_own = {}, {}
         for mod in self.paths:
             had_own[mod] = "forward" in mod.__dict__
             originals[mod] = mod.forward
-            mod.forward = self._make_patch(mod, originals[mod])
+            mod.__dict__["forward"] = self._make_patch(mod, originals[mod])
+        self._patch_state = (originals, had_own)
         self._real = originals
+
+    def _uninstall(self):
+        """The instances are left as they were found (deepcopy / pickle see plain modules)."""
+        if self._patch_state is None:
+            return
+        originals, had_own = self._patch_state
+        for mod, fwd in originals.items():
+            if had_own[mod]:
+                mod.__dict__["forward"] = fwd
+            else:
+                mod.__dict__.pop("forward", None)   # back to the class's forward
+        self._patch_state = None
+        self._real = None
+
+    @contextlib.contextmanager
+    def _patched(self):
+        """Patches for the duration of a call; inside a `LayerSparsity` pass (between
+        `begin_layer_weights` and `finish_run`) they stay on from chunk to chunk."""
+        fresh = self._patch_state is None
+        self._install()
         try:
             yield
         finally:
-            for mod, fwd in originals.items():
-                if had_own[mod]:
-                    mod.forward = fwd
-                else:
-                    del mod.forward       # back to the class's forward: nothing left on the instance
-            self._real = None
+            if fresh and not self._keep_patched:
+                self._uninstall()
 
     def _make_patch(self, mod, real):
         def patched(*args, **kwargs):
@@ -477,6 +517,18 @@ class HookedPrefixLoss:
         self.blen[ctx.key] = out[1]
         return out
 
+    def _worker_profile(self, i):
+        """ECOFLAP_LOCKSTEP_PROFILE=<file>: cProfile of worker 0's forwards (diagnosis only)."""
+        path = os.environ.get("ECOFLAP_LOCKSTEP_PROFILE")
+        if not path or i != 0:
+            return None
+        if getattr(self, "_prof", None) is None:
+            import atexit
+            import cProfile
+            self._prof = cProfile.Profile()
+            atexit.register(lambda: self._prof.dump_stats(path))
+        return self._prof
+
     # ---- k evaluations in lock step ----------------------------------------------------------------
     def multi(self, model, items, cuda_enabled):
         """items: [(samples, theta_plus, theta_minus)] for up to pairs_in_flight() units ->
@@ -570,6 +622,11 @@ class HookedPrefixLoss:
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))
             self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t1
             self.finish_run()
+            if not same and every and len(sel) == k and not os.environ.get("ECOFLAP_VERIFY_BATCHED"):
+                # every chunk is being checked (small tensors: the probes cannot be trusted): the
+                # chunk takes its per-evaluation losses, the next chunk is checked again
+                self.stats["lockstep_corrected_chunks"] = self.stats.get("lockstep_corrected_chunks", 0) + 1
+                return want
             if not same:
                 import warnings
                 self.stats["lockstep_disabled_at"] = self.paths[self.owner]
@@ -615,7 +672,14 @@ class HookedPrefixLoss:
                         torch.cuda.set_device(device)
                     with torch.set_grad_enabled(grad), (torch.cuda.stream(stream) if stream is not None
                                                         else contextlib.nullcontext()):
-                        ctx.result = self.loss_func(model, evals[i][0], cuda_enabled)
+                        prof = self._worker_profile(i)
+                        if prof is not None:
+                            prof.enable()
+                        try:
+                            ctx.result = self.loss_func(model, evals[i][0], cuda_enabled)
+                        finally:
+                            if prof is not None:
+                                prof.disable()
                 except _Abort:
                     pass
                 except BaseException as ex:       # noqa: BLE001 (re-raised by the coordinator)
@@ -628,6 +692,7 @@ class HookedPrefixLoss:
             return body
 
         for i, ctx in enumerate(ctxs):
+            ctx.slot = i
             ctx.wake = self._workers[i].wake
             self._workers[i].job = make_body(i)
 
@@ -819,6 +884,13 @@ class HookedPrefixLoss:
             fb = [t for t in _flatten(o)[0] if torch.is_tensor(t)]
             if len(fa) != len(fb) or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(fa, fb)):
                 return False
+            if sum(t.numel() for t in fa) < 65536 and self.verify_batched != "all":
+                # too few values for one comparison to rule out a lucky agreement (toy shapes: two
+                # GEMM kernels that add 32 products in different orders round to the same fp16
+                # value for most inputs — measured: one evaluation in 704 did not): from here on
+                # every chunk is also evaluated per evaluation and compared
+                self.verify_batched = "all"
+                self.stats["verify_all_small_tensors"] = True
             flag = _differ_flag([x.contiguous() for x in fa], [y.contiguous() for y in fb], flag)
         same = flag is None or not bool(flag.item())
         self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t0
@@ -826,16 +898,61 @@ class HookedPrefixLoss:
 
     PAD_SLOTS = 2      # see prefix_cache.py: the library's fp32 GEMMs treat the LAST rows of a problem differently
 
-    def _shared_call(self, mod, spec, cat, k, B, pad):
+    def _graphed_call(self, key, mod, spec, leaves):
+        """`mod` on `leaves` through a HIP graph captured on first use (None: not capturable —
+        the caller runs it eagerly).  The graph's inputs are static buffers; a leaf that IS the
+        static output of the graph that ran just before (a wired run of blocks) is used in place,
+        anything else is copied in (one fused copy launch)."""
+        g = self._graphs.get(key)
+        if g is False or not self.use_graphs:
+            return None
+        if not all(t.is_cuda for t in leaves if torch.is_tensor(t)):
+            return None
+        sig = tuple((tuple(t.shape), t.dtype) if torch.is_tensor(t) else ("c", t) for t in leaves)
+        if g is not None and g["sig"] != sig:
+            g = None
+        if g is None:
+            from .base_pruner import capture_graph
+            static_in = [t if (torch.is_tensor(t) and getattr(t, "_ecoflap_static", False))
+                         else (t.clone() if torch.is_tensor(t) else t) for t in leaves]
+            graph = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            try:
+                with capture_graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    out = self._call(mod, spec, static_in)
+            except Exception as ex:               # the module does something a capture cannot hold
+                self._graphs[key] = False
+                self.stats.setdefault("not_capturable", []).append(
+                    f"{self.paths[mod]}: {type(ex).__name__}: {ex}"[:200])
+                torch.cuda.synchronize()
+                return None
+            for t in _flatten(out)[0]:
+                if torch.is_tensor(t):
+                    t._ecoflap_static = True      # (may be consumed in place by the next graph)
+            g = self._graphs[key] = {"graph": graph, "in": static_in, "out": out, "sig": sig}
+            self.stats["graph_captures"] = self.stats.get("graph_captures", 0) + 1
+        pairs = [(d, s_) for d, s_ in zip(g["in"], leaves) if torch.is_tensor(d) and d is not s_]
+        if pairs:
+            from .prefix_cache import _flush_copies
+            _flush_copies(pairs)
+        g["graph"].replay()
+        self.stats["graph_replays"] = self.stats.get("graph_replays", 0) + 1
+        return g["out"]
+
+    def _shared_call(self, mod, spec, cat, k, B, pad, key=None):
         """-> the event's output in cat form (k slots), computed at width k + pad"""
         if cat is None:
             return None
         try:
             if not pad:
-                return self._call(mod, spec, cat)
+                out = self._graphed_call(key, mod, spec, cat) if key is not None else None
+                return out if out is not None else self._call(mod, spec, cat)
             wide = [torch.cat([t, t[(k - 1) * B:].repeat((pad,) + (1,) * (t.dim() - 1))], 0)
                     if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == k * B) else t for t in cat]
-            out = self._call(mod, spec, wide)
+            out = self._graphed_call(key, mod, spec, wide) if key is not None else None
+            if out is None:
+                out = self._call(mod, spec, wide)
             leaves, ospec = _flatten(out)
             return _unflatten(ospec, [t[:k * B] if (torch.is_tensor(t) and t.dim() > 0
                                                     and t.shape[0] == (k + pad) * B) else t for t in leaves])
@@ -870,7 +987,7 @@ class HookedPrefixLoss:
                 self.stats.setdefault("events_shared_with_padding", []).append(self.paths[mod])
             return keep, alone
         if inv:
-            out = self._shared_call(mod, spec, cat, k, B, inv[1])
+            out = self._shared_call(mod, spec, cat, k, B, inv[1], key=(fam, k, e, inv[1]))
             if out is not None:
                 self.stats["events_shared"] = self.stats.get("events_shared", 0) + 1
                 return out, None

@@ -353,6 +353,15 @@ class LayerSparsity:
 
     # ------------------------------------------------------------------ zeroth order
     def compute_importance_scores_mezo(self, layer_to_group_mapping):
+        try:
+            return self._compute_importance_scores_mezo(layer_to_group_mapping)
+        except BaseException:
+            abort = getattr(self.loss_func, "abort_run", None)
+            if abort is not None:
+                abort()
+            raise
+
+    def _compute_importance_scores_mezo(self, layer_to_group_mapping):
         t0 = time.time()
         model = self.model
         model.eval()

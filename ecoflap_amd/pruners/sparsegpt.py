@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import hip as _hip
 from ..registry import registry
+from .phase_timer import PhaseTimer
 from .wanda import BLIPT5LayerWandaPruner, T5LayerWandaPruner, VITLayerWandaPruner
 
 
@@ -80,8 +81,9 @@ class SparseGPT:
         xs = [x for x, _, _ in self._pending]
         b = sum(n for _, n, _ in self._pending)
         self._pending = []
-        x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
-        self.kernels.hessian_accum(self.H, x, self.nsamples, b)
+        with PhaseTimer.span("sparsegpt.hessian (cat + MFMA SYRK)"):
+            x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+            self.kernels.hessian_accum(self.H, x, self.nsamples, b)
         self.nsamples += b
 
     @staticmethod
@@ -116,28 +118,37 @@ class SparseGPT:
             W[:, dead] = 0
             del H
         else:
-            dead = torch.diag(H) == 0
-            H[dead, dead] = 1
-            W[:, dead] = 0
-            self._clamp_inf(H)
-            damp = percdamp * torch.mean(torch.diag(H))
-            H = self._damped_cholesky(H, damp, upper=False)
-            H = torch.cholesky_inverse(H)
-            self._clamp_inf(H)
-            damp = percdamp * torch.mean(torch.diag(H).abs())
-            Hinv = self._damped_cholesky(H, damp, upper=True).contiguous()
+            with PhaseTimer.span("sparsegpt.factor (clamp, 2 damped Cholesky, inverse: torch.linalg)"):
+                dead = torch.diag(H) == 0
+                H[dead, dead] = 1
+                W[:, dead] = 0
+                with PhaseTimer.span("sparsegpt.factor.clamp_inf (isinf scans + host syncs)"):
+                    self._clamp_inf(H)
+                damp = percdamp * torch.mean(torch.diag(H))
+                with PhaseTimer.span("sparsegpt.factor.cholesky_lower"):
+                    H = self._damped_cholesky(H, damp, upper=False)
+                with PhaseTimer.span("sparsegpt.factor.cholesky_inverse"):
+                    H = torch.cholesky_inverse(H)
+                with PhaseTimer.span("sparsegpt.factor.clamp_inf (isinf scans + host syncs)"):
+                    self._clamp_inf(H)
+                damp = percdamp * torch.mean(torch.diag(H).abs())
+                with PhaseTimer.span("sparsegpt.factor.cholesky_upper"):
+                    Hinv = self._damped_cholesky(H, damp, upper=True).contiguous()
         self.factor = (dead, Hinv)
-        for i1 in range(0, self.columns, blocksize):
-            i2 = min(i1 + blocksize, self.columns)
-            count = i2 - i1
-            err = torch.empty((self.rows, count), dtype=torch.float32, device=W.device)
-            if prune_n != 0:                                      # n:m, mask grown in the sweep (:190, :196-198)
-                self.kernels.sparsegpt_block_nm(W, Hinv, i1, count, prune_n, prune_m, err)
-            else:
-                k = int(self.rows * count * sparsity)             # int(tmp.numel() * sparsity) (:187)
-                self.kernels.sparsegpt_block(W, Hinv, i1, count, k, err)
-            if i2 < self.columns:
-                W[:, i2:] -= err.matmul(Hinv[i1:i2, i2:])         # (:216)
+        with PhaseTimer.span("sparsegpt.sweep (threshold + OBS kernels + trailing GEMMs)"):
+            for i1 in range(0, self.columns, blocksize):
+                i2 = min(i1 + blocksize, self.columns)
+                count = i2 - i1
+                err = torch.empty((self.rows, count), dtype=torch.float32, device=W.device)
+                with PhaseTimer.span("sparsegpt.sweep.block_kernels"):
+                    if prune_n != 0:                              # n:m, mask grown in the sweep (:190, :196-198)
+                        self.kernels.sparsegpt_block_nm(W, Hinv, i1, count, prune_n, prune_m, err)
+                    else:
+                        k = int(self.rows * count * sparsity)     # int(tmp.numel() * sparsity) (:187)
+                        self.kernels.sparsegpt_block(W, Hinv, i1, count, k, err)
+                if i2 < self.columns:
+                    with PhaseTimer.span("sparsegpt.sweep.trailing_gemm"):
+                        W[:, i2:] -= err.matmul(Hinv[i1:i2, i2:])     # (:216)
         self.layer.weight.data = W.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
 
     def free(self):

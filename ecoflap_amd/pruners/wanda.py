@@ -459,11 +459,13 @@ class _BlockwiseWanda:
                     immediate=bool(getattr(self.owner, "k6_immediate", False)))
                 for w_ in wrapped.values():
                     w_.sink = collector[0]
-            if graphed:
-                graph_pass(block, wrapped, keep=False)
-            else:
-                for j in range(n_batches):
-                    outs[j] = call(block, j)
+            from .phase_timer import PhaseTimer
+            with PhaseTimer.span("stage2.block_forward_with_hooks (incl. K6 / Hessian updates)"):
+                if graphed:
+                    graph_pass(block, wrapped, keep=False)
+                else:
+                    for j in range(n_batches):
+                        outs[j] = call(block, j)
             for h in handles:
                 h.remove()
             if sparsegpt:
@@ -486,13 +488,14 @@ class _BlockwiseWanda:
                 self._merge_hessians(wrapped)
             twins = {}
             if sparsegpt:      # Linears fed by the same tensor have bit-identical Hessians
-                names_ = list(subset)
-                for a_i, a in enumerate(names_):
-                    for b in names_[:a_i]:
-                        if (b not in twins and wrapped[b].H.shape == wrapped[a].H.shape
-                                and torch.equal(wrapped[b].H, wrapped[a].H)):
-                            twins[a] = b
-                            break
+                with PhaseTimer.span("sparsegpt.twin_detection (torch.equal of Hessians)"):
+                    names_ = list(subset)
+                    for a_i, a in enumerate(names_):
+                        for b in names_[:a_i]:
+                            if (b not in twins and wrapped[b].H.shape == wrapped[a].H.shape
+                                    and torch.equal(wrapped[b].H, wrapped[a].H)):
+                                twins[a] = b
+                                break
             block_items = []
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps) * count_factor
@@ -520,11 +523,12 @@ class _BlockwiseWanda:
             if sparsegpt:
                 for w_ in wrapped.values():
                     w_.free()
-            if graphed:
-                graph_pass(block, None, keep=True)
-            else:
-                for j in range(n_batches):
-                    outs[j] = call(block, j)
+            with PhaseTimer.span("stage2.block_forward_after_prune"):
+                if graphed:
+                    graph_pass(block, None, keep=True)
+                else:
+                    for j in range(n_batches):
+                        outs[j] = call(block, j)
             inps, outs = outs, inps
         if torch.cuda.is_available():
             torch.cuda.empty_cache()

@@ -15,26 +15,26 @@ def hidden_stage_plan(*classes):
         plan = cls.__dict__.get("stage_plan")
         if plan is None:
             continue
-        fwd = cls.__dict__.get("forward")
 
-        def forward(self, samples, _plan=plan):
+        def composed(self, samples, _plan=plan):
             state = samples
             for _, _, fn in _plan(self):
                 state = fn(state)
             return state
 
-        saved.append((cls, plan, fwd))
-        cls.forward = forward
+        # the entry points that are the composition of the stages (`forward`; EVACLIP: `predict`)
+        entries = {name: cls.__dict__[name] for name in ("forward", "predict") if name in cls.__dict__}
+        saved.append((cls, plan, entries))
+        for name in entries:
+            setattr(cls, name, composed)
         del cls.stage_plan
     try:
         yield
     finally:
-        for cls, plan, fwd in saved:
+        for cls, plan, entries in saved:
             cls.stage_plan = plan
-            if fwd is not None:
-                cls.forward = fwd
-            else:
-                del cls.forward
+            for name, fn in entries.items():
+                setattr(cls, name, fn)
 
 
 _KEEP = []

@@ -79,8 +79,11 @@ def test_unstaged_stage1_hip_equals_full_forward_on_the_oracle(kern):
             st = got[3]
             assert st["events_served"] > 0.3 * st["events_total"], st
             if mode != "hooked":
+                # (toy tensors are too small for the invariance probes to be trusted: every chunk
+                # is then also evaluated per evaluation, `verify_all_small_tensors`, and the rare
+                # chunk whose shared pass rounds differently takes those losses)
                 assert st["lockstep_evals"] >= 2 * len(ref[1]) - 2 * 8 and st["owner_batched_evals"] > 0, st
-                assert "lockstep_disabled_at" not in st, st
+                assert "lockstep_disabled_at" not in st and st.get("verify_all_small_tensors"), st
 
 
 def test_unstaged_whole_pruner_hip_equals_oracle(kern):

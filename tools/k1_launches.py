@@ -27,7 +27,7 @@ BLOCKS = [("t5_block", [2048 * 2048] * 4 + [5120 * 2048] * 3, torch.bfloat16),
           ("vit_block", [4224 * 1408, 1408 * 1408, 6144 * 1408, 6144 * 1408], torch.float16)]
 
 
-def block_form(kern, U, reps):
+def block_form(kern, U, reps, z=None):
     """One launch per transformer block: every matrix of the block with its U units (the
     default form of the stage-1 loop).  Two buffer sets per block shape, > 1 GiB each."""
     plan = []
@@ -46,12 +46,13 @@ def block_form(kern, U, reps):
             for k, (ws, fin, scr) in enumerate(sets):
                 layers = [(w, f, [1000 * rep + 100 * k + 16 * i + u for u in range(U)],
                            [s[2 * u] for u in range(U)], [s[2 * u + 1] for u in range(U)])
+                          + ((z,) if z else ())
                           for i, (w, f, s) in enumerate(zip(ws, fin, scr))]
                 kern.zo_perturb_layers(layers, 1e-3)
                 launches.append({"shape": name, "numel": sum(numels), "dtype": str(dt),
                                  "algorithmic_bytes": (2 * U + 2) * 2 * sum(numels)})
     torch.cuda.synchronize()
-    print(json.dumps({"units": U, "form": "block", "launches": launches}))
+    print(json.dumps({"units": U, "form": "torch_block" if z else "block", "launches": launches}))
 
 
 def main():
@@ -62,11 +63,14 @@ def main():
     ap.add_argument("--form", choices=["units", "block"], default="units",
                     help="block: one zo_perturb_layers launch per transformer block (all of its "
                          "matrices), as the stage-1 loop issues it by default")
+    ap.add_argument("--z", choices=["philox", "torch"], default="philox",
+                    help="torch: the reference's draw regenerated in registers (zo_torch_layers_kernel, the "
+                         "default mode of the loop since round 5); block form only")
     args = ap.parse_args()
     kern = hip.HipKernels()
     U = args.units
     if args.form == "block":
-        return block_form(kern, U, args.reps)
+        return block_form(kern, U, args.reps, hip.TORCH_Z if args.z == "torch" else None)
     plan = []
     for name, n, dt in SHAPES:
         if args.only and args.only != name:

@@ -15,9 +15,15 @@ args = ["--shape", "blip2", "--pruning_method", "blipt5_sparsegpt_pruner", "--sc
         "MEZO-GradOnly_sum", "--sparsity_ratio_granularity", "block", "--max_sparsity_per_layer", "0.7",
         "--prunining_dataset_batch_size", "1", "--num_data", "128", "--num_data_first_stage", "32",
         "--t5_prune_spec", "24-0.4-1.0-1.0", "--vit_prune_spec", "39-0.4-1.0-1.0"] + sys.argv[1:]
+phases = "--phases" in args
+if phases:            # device-time breakdown of stage 2 (pruners/phase_timer.py)
+    args.remove("--phases")
+    from ecoflap_amd.pruners.phase_timer import PhaseTimer
+    PhaseTimer.enable()
 t0 = time.time()
 model, table = harness.main(args)
 torch.cuda.synchronize()
+phase_report = PhaseTimer.report() if phases else None
 blocks = {k: v for k, v in model.state_dict().items() if v.dim() == 2 and ".block" in k
           and "relative_attention_bias" not in k}
 zeros = sum(int((v == 0).sum()) for v in blocks.values())
@@ -25,6 +31,7 @@ total = sum(v.numel() for v in blocks.values())
 print(json.dumps({"wall_seconds": time.time() - t0, "pruned_fraction": zeros / total,
                   "stage_stats": getattr(harness.main, "last_stage_stats", None),
                   "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
+                  "stage2_phases": phase_report,
                   # which weight shapes ran a pinned hipBLASLt solution (shapes/fused.py)
                   "pinned_gemm": __import__("ecoflap_amd.shapes.fused", fromlist=["x"]).gemm_report()},
                  default=str))

@@ -24,14 +24,15 @@ def main():
     doc = json.load(open(launches_json))
     launches = doc["launches"]
     form = doc.get("form", "units")
-    kernel = {"units": "zo_perturb_units_kernel", "block": "zo_perturb_layers_kernel"}[form]
+    kernel = {"units": "zo_perturb_units_kernel", "block": "zo_perturb_layers_kernel",
+              "torch_block": "zo_torch_layers_kernel"}[form]
     f = per_kernel(fetch_csv, "FETCH_SIZE", kernel)
     w = per_kernel(write_csv, "WRITE_SIZE", kernel)
     n = min(len(f), len(w), len(launches))
     by_shape = {}
     for i in range(n):
         L = launches[i]
-        d = by_shape.setdefault(L["shape"], {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0,
+        d = by_shape.setdefault((form + ":" if form == "torch_block" else "") + L["shape"], {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0,
                                              "algorithmic_bytes": L["algorithmic_bytes"]})
         d["launches"] += 1
         d["fetch_kib"] += f[i]
