@@ -2124,6 +2124,101 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     }
 }
 
+// The exact finish for a matrix the sampled passes could not settle (bracket miss ~1e-6 per
+// matrix, a threshold bin crowded by massive ties, a non-finite threshold), ON THE DEVICE: one
+// conditional launch, one workgroup per matrix, which leaves at once when `fallback` is 0 — the
+// usual case costs the launch of 4 idle workgroups — and otherwise runs the whole three-histogram
+// selection and the apply pass by itself (LDS histograms, no other workgroup to wait for: no
+// grid barrier, nothing that could deadlock with another resident instance).  Slow (one CU
+// streams the matrix four times: ~1 ms for 8.6 M elements) and rare; what the apply2 pass has
+// already zeroed lay below the threshold's bin and stays below it as a zero, so the order
+// statistic is unchanged.  Until round 5 this decision sat on the host: a flag read-back and a
+// stream round trip per call (105 us from the stream for 64 us of kernels).
+template <int DT, int PASS>
+static __device__ __forceinline__ void fallback_hist_pass(const void* __restrict__ w, const float* sq,
+                                                          int64_t nvec, uint32_t vpr32, uint32_t* h,
+                                                          uint32_t prefix) {
+    constexpr int N = Vec<DT>::N;
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr uint32_t DMASK = PASS == 2 ? 1023u : 2047u;
+    constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) h[i] = 0;
+    __syncthreads();
+    uint32_t cv = threadIdx.x % vpr32;
+    const uint32_t step32 = WM_THREADS % vpr32;
+    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
+        const int64_t c0 = (int64_t)cv * N;
+        cv += step32;
+        if (cv >= vpr32) cv -= vpr32;
+        float f[N];
+        Vec<DT>::unpack(ld16(w, v), f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * sq[c0 + e]);
+            if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & DMASK], 1u);
+        }
+    }
+    __syncthreads();
+}
+
+template <int DT>
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_fallback_kernel(const BracketGroup bg) {
+    const MatGroup& g = bg.m;
+    const int it = blockIdx.x;                   // one workgroup per matrix
+    BracketState* bs = bg.bs[it];
+    if (bs->fallback == 0u) return;              // settled by the sampled passes
+    constexpr int N = Vec<DT>::N;
+    void* w = g.w[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    uint8_t* mask_out = g.mask[it];
+    __shared__ uint32_t h[2048];
+    __shared__ uint32_t wave4[WM_WAVES];
+    __shared__ uint32_t out2[2];
+    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    const float* sq = stage_sqrt(bg.sr[it], cols, sq_lds);
+    const int64_t vpr = cols / N, nvec = rows * vpr;
+    const uint32_t vpr32 = (uint32_t)vpr;
+    uint32_t prefix = 0, remaining = g.rank0[it];
+    fallback_hist_pass<DT, 0>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0] << 21; remaining = out2[1];
+    __syncthreads();
+    fallback_hist_pass<DT, 1>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0] << 10; remaining = out2[1];
+    __syncthreads();
+    fallback_hist_pass<DT, 2>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0];
+    __syncthreads();
+    const float thres = __uint_as_float(prefix);     // sorted[k]
+    uint32_t cv = threadIdx.x % vpr32;
+    const uint32_t step32 = WM_THREADS % vpr32;
+    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
+        const int64_t c0 = (int64_t)cv * N;
+        cv += step32;
+        if (cv >= vpr32) cv -= vpr32;
+        float f[N];
+        Vec<DT>::unpack(ld16(w, v), f);
+        uint32_t lo = 0, hi = 0;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            // W_metric <= thres (W:556): false for NaN metrics, as in torch
+            const bool prune = (__builtin_fabsf(f[e]) * sq[c0 + e]) <= thres;
+            if (prune) { f[e] = 0.0f; any = true; }
+            if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
+            else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
+        }
+        if (any) st16(w, v, Vec<DT>::pack(f));
+        if (mask_out) {
+            uint8_t* m = mask_out + v * N;
+            *(uint32_t*)m = lo;
+            if (N == 8) *(uint32_t*)(m + 4) = hi;
+        }
+    }
+}
+
 static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
 
 extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
@@ -2195,12 +2290,13 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     BracketState* bst[WMAX];
     for (int i = 0; i < n_items; ++i) { bst[i] = (BracketState*)p; p += sizeof(BracketState); }
     // The sampled-bracket path (matrix-mode items big enough to sample one vector per stride; it
-    // stages sqrt(scaler_row) itself and clears its own state) is OPT-IN, ECOFLAP_WANDA_SAMPLED=1
-    // (read at every call): its three kernels take 64 us on a ViT-g block against the four of the
-    // three-histogram path's 71, but the flag it hands to the host costs a stream round trip —
-    // 105 us per call measured from the stream (tools/wanda_launches.py), so the asynchronous
-    // three-histogram path is the default.
-    const bool force_legacy = getenv("ECOFLAP_WANDA_SAMPLED") == nullptr;
+    // stages sqrt(scaler_row) itself and clears its own state): 2 reads + 1 write of W instead of
+    // 4 + 1.  DEFAULT since round 5 — the matrices it cannot settle are finished by ONE conditional
+    // launch on the device (`wanda_matrix_fallback_kernel`), no flag crosses to the host and the
+    // call stays asynchronous.  ECOFLAP_WANDA_SAMPLED=0 (read at every call) selects the
+    // three-histogram path for every matrix.
+    const char* sampled_env = getenv("ECOFLAP_WANDA_SAMPLED");
+    const bool force_legacy = sampled_env != nullptr && sampled_env[0] == '0';
     bool sampled_item[WMAX];
     for (int i = 0; i < n_items; ++i) {
         const ecoflap_wanda_item& a = items[i];
@@ -2394,63 +2490,12 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
 #undef MATRIX_GO
         ECO_CHECK_LAUNCH();
         // every count above is exact; a matrix the pass could not settle (bracket miss, a crowded
-        // threshold bin, a non-finite threshold) carries a flag and nothing wrongly decided: the
-        // three-histogram path finishes it.  One stream sync per block call.
-        // (into PINNED memory, one strided copy: four 4-byte copies into pageable memory took
-        // longer than the three kernels)
-        static thread_local uint32_t* flags = nullptr;
-        if (!flags && hipHostMalloc((void**)&flags, WMAX * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
-            return ECOFLAP_EWORKSPACE;
-        {
-            bool strided = true;
-            for (int q = 1; q < g.n; ++q) strided = strided && members[q] == members[q - 1] + 1;
-            hipError_t e = hipSuccess;
-            if (strided && g.n > 1) {
-                e = hipMemcpy2DAsync(flags, sizeof(uint32_t), &bst[members[0]]->fallback, sizeof(BracketState),
-                                     sizeof(uint32_t), (size_t)g.n, hipMemcpyDeviceToHost, s);
-            } else {
-                for (int q = 0; q < g.n && e == hipSuccess; ++q)
-                    e = hipMemcpyAsync(&flags[q], &bst[members[q]]->fallback, sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, s);
-            }
-            if (e != hipSuccess) return (int)e;
-        }
-        {
-            // the host waits here for the flags: a spinning event query (the wake-up out of
-            // hipStreamSynchronize's sleep was 50-90 us of idle GPU on some boxes, as long as the
-            // three launches themselves)
-            static thread_local hipEvent_t ev = nullptr;
-            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-            hipError_t e = ev ? hipEventRecord(ev, s) : hipErrorUnknown;
-            if (e == hipSuccess) {
-                while ((e = hipEventQuery(ev)) == hipErrorNotReady) {}
-            } else {
-                e = hipStreamSynchronize(s);
-            }
-            if (e != hipSuccess) return (int)e;
-        }
-        MatGroup lg;
-        lg.n = 0;
-        lg.start[0] = 0;
-        for (int q = 0; q < g.n; ++q) {
-            if (!flags[q]) continue;
-            const int z = lg.n++;
-            lg.w[z] = g.w[q]; lg.sq[z] = g.sq[q]; lg.rows[z] = g.rows[q]; lg.cols[z] = g.cols[q];
-            lg.rank0[z] = g.rank0[q]; lg.st[z] = g.st[q]; lg.mask[z] = g.mask[q];
-            lg.start[z + 1] = lg.start[z] + (g.start[q + 1] - g.start[q]);
-        }
-        if (lg.n) {
-            bool want[WMAX];
-            for (int z = 0; z < n_items; ++z) want[z] = false;
-            for (int q = 0; q < g.n; ++q) if (flags[q]) want[members[q]] = true;
-            const int rc = launch_sqrt(want);
-            if (rc) return rc;
-            const dim3 lgrid((unsigned)lg.start[lg.n]);
-#define MATRIX_GO(DT_) MATRIX_LEGACY(DT_, lg, lgrid)
-            DT_SWITCH(a.dtype, MATRIX_GO);
-#undef MATRIX_GO
-            ECO_CHECK_LAUNCH();
-        }
+        // threshold bin, a non-finite threshold) carries a flag and nothing wrongly decided: one
+        // workgroup per matrix looks at its flag and, if set, finishes the matrix exactly by itself
+#define FALLBACK_GO(DT_) hipLaunchKernelGGL((wanda_matrix_fallback_kernel<DT_>), dim3((unsigned)g.n), blk, 0, s, bg)
+        DT_SWITCH(a.dtype, FALLBACK_GO);
+#undef FALLBACK_GO
+        ECO_CHECK_LAUNCH();
 #undef MATRIX_LEGACY
     }
     return 0;

@@ -303,8 +303,10 @@ class HookedPrefixLoss:
         self._keep_patched = False
         self._uninstall()
         if self._assumed is not None and bool(self._assumed.item()):
-            raise RuntimeError("HookedPrefixLoss: a tensor assumed equal across the evaluations of a "
-                               "chunk differed; rerun with eval_batch=1")
+            raise RuntimeError("HookedPrefixLoss: a check that was queued without a host sync failed (a "
+                               "tensor assumed equal across the evaluations of a chunk differed, or the "
+                               f"per-slot form of a matrix — last queued: {getattr(self, '_assumed_what', None)} "
+                               "— did not equal its per-evaluation call); rerun with eval_batch=1")
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _limit(self):
@@ -896,6 +898,23 @@ class HookedPrefixLoss:
         self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t0
         return same
 
+    def _queue_same(self, alone, outs, what):
+        """`_slots_same` without the read-back: the compare launches OR into the flag that
+        `finish_run` (and the guard) read; a difference found there is an error."""
+        from .prefix_cache import _differ_flag
+        for a, o in zip(alone, outs):
+            fa = [t for t in _flatten(a)[0] if torch.is_tensor(t)]
+            fb = [t for t in _flatten(o)[0] if torch.is_tensor(t)]
+            if len(fa) != len(fb) or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(fa, fb)):
+                raise RuntimeError(f"HookedPrefixLoss: per-slot owner of {what} returns another structure")
+            if fa and fa[0].device.type != "cuda":
+                if not all(torch.equal(x, y) for x, y in zip(fa, fb)):
+                    raise RuntimeError(f"HookedPrefixLoss: per-slot owner of {what} differs from the "
+                                       "per-evaluation call; rerun with eval_batch=1")
+                continue
+            self._assumed = _differ_flag([x.contiguous() for x in fa], [y.contiguous() for y in fb], self._assumed)
+            self._assumed_what = what
+
     PAD_SLOTS = 2      # see prefix_cache.py: the library's fp32 GEMMs treat the LAST rows of a problem differently
 
     def _graphed_call(self, key, mod, spec, leaves):
@@ -1047,13 +1066,15 @@ class HookedPrefixLoss:
                 else:
                     del lin.forward
             if out is not None and (fam, name) not in self._owner_ok:
-                # first use of this MATRIX's per-slot form: against the per-evaluation call — on
-                # every slot for the first matrix of a block (the block's other ops run at k*B
-                # too: their slots are checked once per block and width), one rotating slot after
-                if (fam, e, k) in self._owner_block_ok:
-                    picks = [self.stats.get("owner_checks", 0) % k]
-                else:
-                    picks = list(range(k))
+                # first use of this MATRIX's per-slot form: against the per-evaluation call.  The
+                # first matrix of a block is checked on EVERY slot, with a host sync and a graceful
+                # fallback (the block's other ops run at k*B too: this is what tells whether the
+                # block is batch invariant at that width).  Once a block has passed, its other
+                # matrices can only differ in the patched Linear — the same GEMM call an evaluation
+                # makes alone — so their check (one rotating slot) is queued without a sync and
+                # read at the guard / at the end of the run: a violation is an error there.
+                first_of_block = (fam, e, k) not in self._owner_block_ok
+                picks = list(range(k)) if first_of_block else [self.stats.get("owner_checks", 0) % k]
                 if per is None:
                     per = self._uncat(cat, k, B)
                 alone = []
@@ -1065,9 +1086,12 @@ class HookedPrefixLoss:
                     param.data = home
                 self.stats["owner_checks"] = self.stats.get("owner_checks", 0) + 1
                 slots = self._split(out, k, B)
-                self._owner_ok[(fam, name)] = self._slots_same(alone, [slots[i] for i in picks])
-                if len(picks) == k:
-                    self._owner_block_ok[(fam, e, k)] = self._owner_ok[(fam, name)]
+                if first_of_block:
+                    ok = self._slots_same(alone, [slots[i] for i in picks])
+                    self._owner_ok[(fam, name)] = self._owner_block_ok[(fam, e, k)] = ok
+                else:
+                    self._queue_same(alone, [slots[i] for i in picks], name)
+                    self._owner_ok[(fam, name)] = True
             if out is None:
                 self._owner_ok[(fam, name)] = False
             if self._owner_ok.get((fam, name), False):

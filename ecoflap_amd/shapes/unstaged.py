@@ -17,8 +17,12 @@ def hidden_stage_plan(*classes):
             continue
 
         def composed(self, samples, _plan=plan):
+            held = self.__dict__.get("_unstaged_fns")
+            if held is None or held[0] != id(self):   # (the stage functions close over `self`: built
+                held = self.__dict__["_unstaged_fns"] = (id(self), [fn for _, _, fn in _plan(self)])
+            fns = held[1]                             #  once per model; a deep copy builds its own)
             state = samples
-            for _, _, fn in _plan(self):
+            for fn in fns:
                 state = fn(state)
             return state
 
