@@ -773,7 +773,8 @@ class HookedPrefixLoss:
             nxt = e + 1
             w = self.wired.get(nxt) if nxt < n else None
             out_cat_leaves = _flatten(out_cat)[0] if out_cat is not None else None
-            need_per = (out_cat is None or w is None or not lazy or e < ctxs[0].limit)
+            need_per = (out_cat is None or w is None or not lazy
+                        or (e < ctxs[0].limit and not self.stats.get("verify_all_small_tensors")))
             if need_per and out_per is None:
                 out_per = self._split(out_cat, k, B)
             # what the parked forwards get back for this event: inside a wired run the model only
@@ -781,10 +782,13 @@ class HookedPrefixLoss:
             # un-sliced object; the last event of the run, which real glue consumes, is sliced
             for i, c in enumerate(ctxs):
                 c.ready[e] = out_per[i] if need_per else out_cat
-            if e < ctxs[0].limit:
+            if e < ctxs[0].limit and not self.stats.get("verify_all_small_tensors"):
                 # an event before the owner that was not on record yet (the scored matrix moved
                 # on): computed with the finished layers' weights, it is what every later
-                # evaluation of these batches will be served
+                # evaluation of these batches will be served.  (Not when the tensors are too small
+                # for the invariance probes to be trusted: a shared pass that rounds differently
+                # would then sit in the record and feed the checking evaluations too; the record
+                # is left to those per-evaluation forwards.)
                 for key, i in first_of.items():
                     cached = ctxs[i].cached
                     keep = _map(out_per[i], lambda t: t.detach().clone())
@@ -1073,7 +1077,10 @@ class HookedPrefixLoss:
                 # matrices can only differ in the patched Linear — the same GEMM call an evaluation
                 # makes alone — so their check (one rotating slot) is queued without a sync and
                 # read at the guard / at the end of the run: a violation is an error there.
-                first_of_block = (fam, e, k) not in self._owner_block_ok
+                # (tensors too small for a comparison to be trusted, `verify_all_small_tensors`:
+                # every matrix is checked on every slot, with a sync and the graceful fallback)
+                first_of_block = ((fam, e, k) not in self._owner_block_ok
+                                  or bool(self.stats.get("verify_all_small_tensors")))
                 picks = list(range(k)) if first_of_block else [self.stats.get("owner_checks", 0) % k]
                 if per is None:
                     per = self._uncat(cat, k, B)
@@ -1088,7 +1095,8 @@ class HookedPrefixLoss:
                 slots = self._split(out, k, B)
                 if first_of_block:
                     ok = self._slots_same(alone, [slots[i] for i in picks])
-                    self._owner_ok[(fam, name)] = self._owner_block_ok[(fam, e, k)] = ok
+                    self._owner_ok[(fam, name)] = ok
+                    self._owner_block_ok[(fam, e, k)] = ok and self._owner_block_ok.get((fam, e, k), True)
                 else:
                     self._queue_same(alone, [slots[i] for i in picks], name)
                     self._owner_ok[(fam, name)] = True
