@@ -890,7 +890,7 @@ class HookedPrefixLoss:
             fb = [t for t in _flatten(o)[0] if torch.is_tensor(t)]
             if len(fa) != len(fb) or any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(fa, fb)):
                 return False
-            if sum(t.numel() for t in fa) < 65536 and self.verify_batched != "all":
+            if sum(t.numel() for t in fa) < 65536 and not self.stats.get("verify_all_small_tensors"):
                 # too few values for one comparison to rule out a lucky agreement (toy shapes: two
                 # GEMM kernels that add 32 products in different orders round to the same fp16
                 # value for most inputs — measured: one evaluation in 704 did not): from here on

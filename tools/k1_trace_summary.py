@@ -36,7 +36,8 @@ def main():
         rd = csv.DictReader(f)
         fields = rd.fieldnames
         for r in rd:
-            if "zo_perturb_units_kernel" in r["Kernel_Name"] or "zo_perturb_layers_kernel" in r["Kernel_Name"]:
+            if ("zo_perturb_units_kernel" in r["Kernel_Name"] or "zo_perturb_layers_kernel" in r["Kernel_Name"]
+                    or "zo_torch_layers_kernel" in r["Kernel_Name"]):
                 rows.append(r)
             else:
                 others.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
