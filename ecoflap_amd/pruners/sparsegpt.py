@@ -103,6 +103,102 @@ class SparseGPT:
             H[diag, diag] += damp                                 # not positive definite yet
         raise RuntimeError("Hessian could not be made positive definite")
 
+    # ---- the factorisations of a block's Linears, side by side ---------------------------------
+    _side_streams = []
+
+    @classmethod
+    def factor_all(cls, items, percdamp=.01):
+        """`factor` (dead columns, Hinv) for every SparseGPT in `items` — the three torch.linalg
+        calls of `fasterprune` (:84-110) — with the Linears of a transformer block running SIDE BY
+        SIDE on their own HIP streams.  Why: rocSOLVER's potrf is latency-bound at these sizes
+        (measured: 4.0 ms at 1408, 6.0 ms at 2048, 20 ms at 6144 = 0.2-3.8 TFLOP/s of fp32; the
+        three calls of one ViT-g block's four Hessians one after the other: 78 ms, of a FlanT5
+        decoder block's seven: 112 ms — `profiles/r05_sparsegpt/`), the Hessians of a block are
+        independent, and the library's small kernels leave the chip almost empty.  Same calls on
+        the same inputs as the one-by-one form -> the same bits.  The host-side decisions of the
+        reference's loop (`if isinf(H).sum() > 0`, `info == 0 and not isnan(L).any()`) are read
+        back ONCE per step for the whole block instead of once per Linear; a Hessian that needs
+        damping (rare) takes the reference's own loop afterwards, alone."""
+        items = [it for it in items if it.factor is None]
+        if not items:
+            return
+        for it in items:
+            it.flush()
+        if not (items[0].H.is_cuda and len(items) > 1):
+            for it in items:
+                it._factor_alone(percdamp)
+            return
+        main = torch.cuda.current_stream()
+        while len(cls._side_streams) < len(items):
+            cls._side_streams.append(torch.cuda.Stream())
+        streams = cls._side_streams[:len(items)]
+
+        def each(fn):
+            for it, st in zip(items, streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    fn(it)
+            for st in streams:
+                main.wait_stream(st)
+
+        def clamp_flagged(attr):
+            # `_clamp_inf`'s two tests for every item, one read-back
+            flags = torch.stack([torch.isinf(getattr(it, attr)).any() for it in items]).cpu().tolist()
+            for it, bad in zip(items, flags):
+                if bad:
+                    cls._clamp_inf(getattr(it, attr))
+
+        def step1(it):
+            H = it.H
+            it._dead = torch.diag(H) == 0
+            H[it._dead, it._dead] = 1
+        each(step1)
+        clamp_flagged("H")
+
+        def chol(attr, out, upper, damp_abs):
+            def go(it):
+                M = getattr(it, attr)
+                d = torch.diag(M)
+                it._damp = percdamp * torch.mean(d.abs() if damp_abs else d)
+                L, info = torch.linalg.cholesky_ex(M, upper=upper)
+                it._bad = (info != 0) | torch.isnan(L).any()
+                setattr(it, out, L)
+            each(go)
+            bad = torch.stack([it._bad.reshape(()) for it in items]).cpu().tolist()
+            for it, b in zip(items, bad):
+                if b:       # not positive definite yet: the reference's damping loop (:98-103, :130-135)
+                    M = getattr(it, attr)
+                    diag = torch.arange(M.shape[0], device=M.device)
+                    M[diag, diag] += it._damp
+                    setattr(it, out, cls._damped_cholesky(M, it._damp, upper=upper))
+        chol("H", "_L", False, False)
+
+        def inverse(it):
+            it._Hi = torch.cholesky_inverse(it._L)
+            it._L = None
+        each(inverse)
+        clamp_flagged("_Hi")
+        chol("_Hi", "_U", True, True)
+        for it in items:
+            it.factor = (it._dead, it._U.contiguous())
+            for t in it.factor:          # made on a side stream, read by the sweep on this one
+                t.record_stream(main)
+            it.H = None
+            it._Hi = it._U = it._dead = it._bad = it._damp = None
+
+    def _factor_alone(self, percdamp):
+        H = self.H
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        self._clamp_inf(H)
+        damp = percdamp * torch.mean(torch.diag(H))
+        H = self._damped_cholesky(H, damp, upper=False)
+        H = torch.cholesky_inverse(H)
+        self._clamp_inf(H)
+        damp = percdamp * torch.mean(torch.diag(H).abs())
+        self.factor = (dead, self._damped_cholesky(H, damp, upper=True).contiguous())
+        self.H = None
+
     def fasterprune(self, sparsity, prune_n=0, prune_m=0, blocksize=128, percdamp=.01,
                     same_hessian_as=None):
         """`same_hessian_as`: a SparseGPT of this block that saw the very same inputs (q/k/v,
@@ -112,11 +208,14 @@ class SparseGPT:
         self.flush()
         W = self.layer.weight.data.clone().float()
         H = self.H
-        del self.H
+        self.H = None
         if same_hessian_as is not None and same_hessian_as.factor is not None:
             dead, Hinv = same_hessian_as.factor
             W[:, dead] = 0
             del H
+        elif self.factor is not None:               # factored with its block (`factor_all`)
+            dead, Hinv = self.factor
+            W[:, dead] = 0
         else:
             with PhaseTimer.span("sparsegpt.factor (clamp, 2 damped Cholesky, inverse: torch.linalg)"):
                 dead = torch.diag(H) == 0

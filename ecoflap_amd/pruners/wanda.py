@@ -384,12 +384,16 @@ class _BlockwiseWanda:
         # equally shaped calibration samples on the GPU: each block forward (with its K6 hooks
         # in the first pass) is captured once as a HIP graph and replayed per sample — the loop
         # is launch-bound (the reference's batch 1: ~40 kernels of a few microseconds per block)
-        graphed = (torch.is_tensor(inps[0]) and inps[0].is_cuda
-                   and n_batches >= int(getattr(self.owner, "graph_min_batches", 24))   # two captures per block cost ~5 ms
-                   and bool(getattr(self.owner, "use_graphs", True))
-                   and bool(getattr(self.kernels, "graph_safe", False))
-                   and getattr(self.owner, "local_method", "wanda") != "sparsegpt"
-                   and _uniform_calibration(inps, caches, n_batches))
+        graphed_plain = (torch.is_tensor(inps[0]) and inps[0].is_cuda
+                         and n_batches >= int(getattr(self.owner, "graph_min_batches", 24))   # two captures per block cost ~5 ms
+                         and bool(getattr(self.owner, "use_graphs", True))
+                         and bool(getattr(self.kernels, "graph_safe", False))
+                         and _uniform_calibration(inps, caches, n_batches))
+        # SparseGPT's hooks keep their inputs by reference until 8 samples are in (one MFMA call):
+        # a replayed graph would overwrite them, so its hooked pass stays eager; the pass behind
+        # the pruning has no hooks and replays like Wanda's (round 5: 3.9 s of 128-sample eager
+        # block forwards at batch 1 in the BLIP-2 run)
+        graphed = graphed_plain and getattr(self.owner, "local_method", "wanda") != "sparsegpt"
 
         def graph_pass(block, wrapped, keep):
             """All n_batches samples through `block`: sample 0 eagerly (warm-up), one capture,
@@ -496,6 +500,10 @@ class _BlockwiseWanda:
                                     and torch.equal(wrapped[b].H, wrapped[a].H)):
                                 twins[a] = b
                                 break
+            if sparsegpt and getattr(self.owner, "sparsegpt_factor_side_by_side", True):
+                # the block's independent factorisations on side-by-side streams (pruners/sparsegpt.py)
+                with PhaseTimer.span("sparsegpt.factor (all Linears of a block side by side: torch.linalg)"):
+                    SparseGPT.factor_all([wrapped[n] for n in subset if n not in twins], percdamp=0.01)
             block_items = []
             for name in subset:
                 assert wrapped[name].nsamples == sum(x.shape[0] for x in inps) * count_factor
@@ -524,7 +532,7 @@ class _BlockwiseWanda:
                 for w_ in wrapped.values():
                     w_.free()
             with PhaseTimer.span("stage2.block_forward_after_prune"):
-                if graphed:
+                if graphed_plain:
                     graph_pass(block, None, keep=True)
                 else:
                     for j in range(n_batches):

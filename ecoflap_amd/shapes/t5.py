@@ -413,3 +413,12 @@ class T5(nn.Module):
         for _, _, fn in self.stage_plan():
             state = fn(state)
         return state
+
+    def reference_forward(self, samples):
+        """The composition of the stages as ONE call of the HF-shaped model under one autocast
+        region (LAVIS/lavis/models/t5_models/t5.py:60-90); see Blip2T5.reference_forward."""
+        st = self._inputs(samples)
+        with self.maybe_autocast(dtype=torch.bfloat16):
+            res = self.t5_model(inputs_embeds=st["inputs_embeds"], attention_mask=st["attention_mask"],
+                                labels=st["labels"], decoder_attention_mask=st["decoder_attention_mask"])
+        return {"loss": res.loss, "logits": res.logits}

@@ -26,11 +26,14 @@ def hidden_stage_plan(*classes):
                 state = fn(state)
             return state
 
-        # the entry points that are the composition of the stages (`forward`; EVACLIP: `predict`)
+        # the entry points that are the composition of the stages (`forward`; EVACLIP: `predict`):
+        # replaced by the class's reference-style forward where it has one (the same ops written
+        # as the reference writes its forward), by the composition otherwise
         entries = {name: cls.__dict__[name] for name in ("forward", "predict") if name in cls.__dict__}
         saved.append((cls, plan, entries))
         for name in entries:
-            setattr(cls, name, composed)
+            ref = cls.__dict__.get("reference_" + name)
+            setattr(cls, name, ref if ref is not None else composed)
         del cls.stage_plan
     try:
         yield

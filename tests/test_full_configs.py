@@ -27,12 +27,20 @@ def test_config3_blip2_zeroth_order_full_size():
     with the reference's draw regenerated in registers, 16 evaluations per pass sharing the whole
     suffix behind the owning block, two lanes).  ONE full-size run in the suite (round 5: the
     suite has to stay inside the driver's step limit); the other forms are opt-in below."""
-    import run_config
-    a = run_config.run("3")
+    # in a FRESH process: which GEMM a weight shape gets is decided per process when the shape
+    # first comes up (shapes/fused.py probes it at that row count), so the canonical hash is that
+    # of a run that starts from nothing — what `python3 tools/run_config.py 3` is; inside this
+    # pytest process, after other tests' GEMMs, the same run ends with another (self-consistent)
+    # table (measured: 1d7ac97a... after tests/test_unstaged_gpu.py)
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config.py"), "3"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = json.loads(r.stdout.strip().splitlines()[-1])
     assert a["stage_stats"]["stage1"]["z_mode"] == "torch-registers"
     assert a["table_sha256"].startswith(CONFIG3_TABLE_SHA256_PREFIX), a["table_sha256"]
     _check_config3(a)
-    test_config3_blip2_zeroth_order_full_size.result = a
 
 
 def _check_config3(a):
@@ -59,7 +67,7 @@ def test_config3_full_size_all_loop_forms_agree():
     the model with its stage_plan() hidden (un-staged lock-step path): identical table and pruned
     weights.  (`profiles/r05_config3_staged.json` / `r05_config3_unstaged.json` are such runs.)"""
     import run_config
-    a = getattr(test_config3_blip2_zeroth_order_full_size, "result", None) or run_config.run("3")
+    a = run_config.run("3")
     torch.cuda.empty_cache()
     b = run_config.run("3", ["--k1_form", "units", "--eval_batch", "1"])
     assert b["stage_stats"]["stage1"]["suffix_forward"].get("batched_evals", 0) == 0

@@ -493,3 +493,31 @@ def test_pinned_linear_plumbing_on_the_cpu():
         twin.mlp.fc1.weight.mul_(2.0)
         assert torch.equal(blk(x, None), want) and not torch.equal(twin(x, None), want)
     assert set(blk.state_dict()) == set(Block(32, 4, 64).state_dict())
+
+
+def test_reference_style_forward_equals_the_staged_composition():
+    """`Blip2T5.reference_forward` / `T5.reference_forward` — the forward written the way LAVIS
+    writes it (one autocast region per tower, blip2_t5.py:116-168) and installed when the stage
+    plan is hidden (shapes/unstaged.py) — gives the staged composition's loss and logits bit for
+    bit, in fp32 and under (CPU) autocast at fp16 / bf16 weights."""
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import Blip2T5, blip2_toy
+    from ecoflap_amd.shapes.t5 import T5, t5_config
+    from ecoflap_amd.shapes.unstaged import hidden_stage_plan
+    batches = S.image_text_batches(4, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+    for fp32 in (True, False):
+        torch.manual_seed(0)
+        m = blip2_toy(fp32=fp32).eval()
+        m.cpu_autocast = not fp32
+        with torch.no_grad():
+            a, r = m(batches[0]), m.reference_forward(batches[0])
+            assert torch.equal(a["loss"], r["loss"]) and torch.equal(a["logits"], r["logits"])
+            with hidden_stage_plan(Blip2T5):
+                assert not hasattr(m, "stage_plan")
+                assert torch.equal(m(batches[1])["loss"], m.reference_forward(batches[1])["loss"])
+            assert torch.equal(m(batches[1])["loss"], m.reference_forward(batches[1])["loss"])
+    t = T5(t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, vocab_size=96), dtype=None,
+           init_std=0.2).eval()
+    tb = S.text_batches(4, 2, vocab=96, seed=3)
+    with torch.no_grad():
+        assert torch.equal(t(tb[0])["loss"], t.reference_forward(tb[0])["loss"])

@@ -128,3 +128,41 @@ def test_sparsegpt_pruner_n_m_end_to_end(golden_dir):
     g, model = run_sparsegpt_nm_e2e(golden_dir, OracleKernels())
     for k, v in model.state_dict().items():
         assert np.array_equal(to_bits(v).ravel(), g[f"vit_final::{k}"].ravel()), k
+
+
+@pytest.mark.gpu
+def test_block_factorisations_side_by_side_equal_one_by_one():
+    """`SparseGPT.factor_all` (round 5: the Linears of a block factored on side-by-side streams,
+    the reference's host-side tests read back once per step for the block) == `fasterprune`'s own
+    one-by-one factorisation, bit for bit: dead columns, Hinv and the pruned weights; including a
+    Hessian with dead columns and one that needs the damping loop."""
+    import torch.nn as nn
+    from ecoflap_amd import hip
+    from ecoflap_amd.pruners.sparsegpt import SparseGPT
+    kern = hip.HipKernels()
+
+    def build():
+        torch.manual_seed(11)
+        out = []
+        for cols, rows, kind in ((1408, 64, "plain"), (2048, 48, "dead"), (768, 32, "rank_deficient"),
+                                 (1408, 64, "plain2")):
+            lin = nn.Linear(cols, rows, bias=False).cuda()
+            w = SparseGPT(lin, kernels=kern)
+            n_tok = 64 if kind == "rank_deficient" else 4 * cols
+            x = torch.randn(n_tok, cols, device="cuda")
+            if kind == "dead":
+                x[:, 5:9] = 0
+            w.use_mfma_hessian = False
+            w.add_batch(x.unsqueeze(0), None)
+            out.append(w)
+        return out
+
+    one_by_one, together = build(), build()
+    for w in one_by_one:
+        w.fasterprune(0.5)
+    SparseGPT.factor_all(together)
+    assert all(w.factor is not None and w.H is None for w in together)
+    for a, b in zip(one_by_one, together):
+        assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1])
+        b.fasterprune(0.5)
+        assert torch.equal(a.layer.weight.data, b.layer.weight.data)

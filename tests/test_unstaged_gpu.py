@@ -119,3 +119,22 @@ def test_unstaged_whole_pruner_hip_equals_oracle(kern):
         zeros = sum(int((v == 0).sum()) for k, v in w_ref.items() if ".block" in k and v.dim() == 2)
         total = sum(v.numel() for k, v in w_ref.items() if ".block" in k and v.dim() == 2)
         assert 0.45 < zeros / total < 0.55
+
+
+def test_reference_style_forward_equals_the_staged_composition_on_the_gpu():
+    """The forward installed when the stage plan is hidden (`Blip2T5.reference_forward`: LAVIS's
+    structure, one autocast region per tower) == the staged composition, loss and logits bit for
+    bit, at production dtypes on the GPU (toy widths and a true-width slice)."""
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.blip2_t5 import blip2_toy, blip2_width_slice
+    for build, img, vocab in ((lambda: blip2_toy(fp32=False), 28, 96), (blip2_width_slice, 224, 32128)):
+        torch.manual_seed(3)
+        with torch.device("cuda"):
+            m = build().eval()
+        b = S.image_text_batches(4, 2, img_size=img, vocab=vocab, in_len=5, out_len=4, seed=6, device="cuda")
+        with torch.no_grad():
+            for batch in b:
+                a, r = m(batch), m.reference_forward(batch)
+                assert torch.equal(a["loss"], r["loss"]) and torch.equal(a["logits"], r["logits"])
+        del m
+        torch.cuda.empty_cache()

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05_eighth
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_sparsegpt_parity.py tests/test_gpu_parity.py -x -q -m gpu -k "sparsegpt or factoris" > $O/pytest_sgpt.log 2>&1
+echo "rc=$?" >> $O/pytest_sgpt.log
+timeout 1200 python tools/run_sparsegpt.py --phases > $O/sparsegpt_phases.json 2> $O/sparsegpt_phases.err
+timeout 1200 python tools/run_sparsegpt.py > $O/sparsegpt.json 2> $O/sparsegpt.err
+tail -n 4 $O/pytest_sgpt.log
+python - <<'PY'
+import json
+for f in ("sparsegpt_phases.json", "sparsegpt.json"):
+    s = json.loads(open("gpurun_out/r05_eighth/" + f).read().strip().splitlines()[-1])
+    print(f, "wall %.1f" % s["wall_seconds"], s["stage_stats"].get("stage2"), "stage1 %.1f" % s["stage_stats"]["stage1"]["seconds"], "pruned", round(s["pruned_fraction"], 4))
+    for k, v in sorted((s.get("stage2_phases") or {}).items(), key=lambda kv: -kv[1]["seconds"]):
+        print("   %-78s %6d spans %7.2f s" % (k, v["spans"], v["seconds"]))
+PY
