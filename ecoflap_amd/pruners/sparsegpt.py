@@ -104,21 +104,24 @@ class SparseGPT:
         raise RuntimeError("Hessian could not be made positive definite")
 
     # ---- the factorisations of a block's Linears, side by side ---------------------------------
-    _side_streams = []
+    _pool = None
+    _pool_streams = {}
 
     @classmethod
     def factor_all(cls, items, percdamp=.01):
         """`factor` (dead columns, Hinv) for every SparseGPT in `items` — the three torch.linalg
         calls of `fasterprune` (:84-110) — with the Linears of a transformer block running SIDE BY
-        SIDE on their own HIP streams.  Why: rocSOLVER's potrf is latency-bound at these sizes
-        (measured: 4.0 ms at 1408, 6.0 ms at 2048, 20 ms at 6144 = 0.2-3.8 TFLOP/s of fp32; the
-        three calls of one ViT-g block's four Hessians one after the other: 78 ms, of a FlanT5
-        decoder block's seven: 112 ms — `profiles/r05_sparsegpt/`), the Hessians of a block are
-        independent, and the library's small kernels leave the chip almost empty.  Same calls on
-        the same inputs as the one-by-one form -> the same bits.  The host-side decisions of the
-        reference's loop (`if isinf(H).sum() > 0`, `info == 0 and not isnan(L).any()`) are read
-        back ONCE per step for the whole block instead of once per Linear; a Hessian that needs
-        damping (rare) takes the reference's own loop afterwards, alone."""
+        SIDE: one host thread and one HIP stream each.  Why: rocSOLVER's potrf is latency-bound at
+        these sizes (measured: 4.0 ms at 1408, 6.0 ms at 2048, 20 ms at 6144 = 0.2-3.8 TFLOP/s of
+        fp32; the three calls of one ViT-g block's four Hessians one after the other: 78 ms, of a
+        FlanT5 decoder block's seven: 112 ms — `profiles/r05_sparsegpt/cholesky_bench.log`), the
+        Hessians of a block are independent, and the library's small kernels leave the chip almost
+        empty.  A THREAD per Linear, not just a stream: torch keeps one solver / BLAS handle per
+        host thread, and a handle's device workspace must not serve two streams at once (tried
+        first with streams alone: factors came out corrupted whenever two calls overlapped).  Each
+        thread runs exactly `_factor_alone` — the reference's sequence with its own host-side
+        tests, which now wait on that thread's stream only — so the results are the one-by-one
+        results bit for bit (`tests/test_sparsegpt_parity.py`)."""
         items = [it for it in items if it.factor is None]
         if not items:
             return
@@ -128,63 +131,35 @@ class SparseGPT:
             for it in items:
                 it._factor_alone(percdamp)
             return
+        import concurrent.futures as cf
+        import threading
+        if cls._pool is None:
+            cls._pool = cf.ThreadPoolExecutor(max_workers=8, thread_name_prefix="sparsegpt-factor")
         main = torch.cuda.current_stream()
-        while len(cls._side_streams) < len(items):
-            cls._side_streams.append(torch.cuda.Stream())
-        streams = cls._side_streams[:len(items)]
+        device = torch.cuda.current_device()
+        done_streams = []
 
-        def each(fn):
-            for it, st in zip(items, streams):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    fn(it)
-            for st in streams:
-                main.wait_stream(st)
+        def work(it):
+            torch.cuda.set_device(device)
+            tid = threading.get_ident()
+            st = cls._pool_streams.get((tid, device))
+            if st is None:
+                st = cls._pool_streams[(tid, device)] = torch.cuda.Stream()
+            st.wait_stream(main)
+            with torch.cuda.stream(st), torch.no_grad():
+                it._factor_alone(percdamp)
+                st.synchronize()
+            done_streams.append(st)
 
-        def clamp_flagged(attr):
-            # `_clamp_inf`'s two tests for every item, one read-back
-            flags = torch.stack([torch.isinf(getattr(it, attr)).any() for it in items]).cpu().tolist()
-            for it, bad in zip(items, flags):
-                if bad:
-                    cls._clamp_inf(getattr(it, attr))
-
-        def step1(it):
-            H = it.H
-            it._dead = torch.diag(H) == 0
-            H[it._dead, it._dead] = 1
-        each(step1)
-        clamp_flagged("H")
-
-        def chol(attr, out, upper, damp_abs):
-            def go(it):
-                M = getattr(it, attr)
-                d = torch.diag(M)
-                it._damp = percdamp * torch.mean(d.abs() if damp_abs else d)
-                L, info = torch.linalg.cholesky_ex(M, upper=upper)
-                it._bad = (info != 0) | torch.isnan(L).any()
-                setattr(it, out, L)
-            each(go)
-            bad = torch.stack([it._bad.reshape(()) for it in items]).cpu().tolist()
-            for it, b in zip(items, bad):
-                if b:       # not positive definite yet: the reference's damping loop (:98-103, :130-135)
-                    M = getattr(it, attr)
-                    diag = torch.arange(M.shape[0], device=M.device)
-                    M[diag, diag] += it._damp
-                    setattr(it, out, cls._damped_cholesky(M, it._damp, upper=upper))
-        chol("H", "_L", False, False)
-
-        def inverse(it):
-            it._Hi = torch.cholesky_inverse(it._L)
-            it._L = None
-        each(inverse)
-        clamp_flagged("_Hi")
-        chol("_Hi", "_U", True, True)
+        # (largest first: the block's 5120 / 6144 Hessian is the critical path)
+        order = sorted(items, key=lambda it: -it.columns)
+        for f in [cls._pool.submit(work, it) for it in order]:
+            f.result()
+        for st in done_streams:
+            main.wait_stream(st)
         for it in items:
-            it.factor = (it._dead, it._U.contiguous())
             for t in it.factor:          # made on a side stream, read by the sweep on this one
                 t.record_stream(main)
-            it.H = None
-            it._Hi = it._U = it._dead = it._bad = it._damp = None
 
     def _factor_alone(self, percdamp):
         H = self.H

@@ -5,8 +5,8 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_sparsegpt_parity.py tests/test_gpu_parity.py -x -q -m gpu -k "sparsegpt or factoris" > $O/pytest_sgpt.log 2>&1
 echo "rc=$?" >> $O/pytest_sgpt.log
-timeout 1200 python tools/run_sparsegpt.py --phases > $O/sparsegpt_phases.json 2> $O/sparsegpt_phases.err
-timeout 1200 python tools/run_sparsegpt.py > $O/sparsegpt.json 2> $O/sparsegpt.err
+timeout 600 python tools/run_sparsegpt.py --phases > $O/sparsegpt_phases.json 2> $O/sparsegpt_phases.err
+timeout 600 python tools/run_sparsegpt.py > $O/sparsegpt.json 2> $O/sparsegpt.err
 tail -n 4 $O/pytest_sgpt.log
 python - <<'PY'
 import json
