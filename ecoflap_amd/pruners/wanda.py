@@ -440,6 +440,79 @@ class _BlockwiseWanda:
             torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
             del graph
 
+        def graph_pass_hessian(block, wrapped):
+            """SparseGPT's hooked pass as graph replays (round 5: 4.3 s of eager block forwards at
+            batch 1 in the BLIP-2 run).  The reference's hook reduces each input into H at once
+            (sparsegpt_pruner.py:71-82); this build's keeps `samples_per_call` inputs and makes ONE
+            MFMA call over them, which a replayed graph would break (it overwrites the tensors
+            the hooks kept by reference).  So: sample 0 runs eagerly with the ordinary hooks; the
+            capture's hooks only note WHICH static tensors the Linears read; after every replay
+            one fused copy moves those into slot s of a ring [S, tokens, cols] per Linear, and
+            every S samples each Linear's ring — already the concatenated layout, no torch.cat —
+            goes through `hessian_accum`.  Same inputs in the same order through the same kernel:
+            the Hessians are those of the eager pass bit for bit.  -> False when a Linear is not on
+            the MFMA path (fp32 activations): the caller runs the pass eagerly."""
+            from ..shapes import fused
+            from .sparsegpt import SparseGPT
+            outs[0] = call(block, 0)
+            S_ = int(SparseGPT.samples_per_call)
+            first = {}
+            for name, w_ in wrapped.items():
+                if len(w_._pending) != 1 or w_.nsamples != 0:
+                    return False
+                first[name] = w_._pending[0]
+            rings, static, slot = {}, {}, 1
+            for name, (x0, b0, _) in first.items():
+                rings[name] = torch.empty((S_,) + tuple(x0.shape), dtype=x0.dtype, device=x0.device)
+                rings[name][0].copy_(x0)
+                wrapped[name]._pending = []
+
+            def flush():
+                nonlocal slot
+                for name, w_ in wrapped.items():
+                    r = rings[name]
+                    b_tot = first[name][1] * slot
+                    w_.kernels.hessian_accum(w_.H, r[:slot].reshape(slot * r.shape[1], r.shape[2]),
+                                             w_.nsamples, b_tot)
+                    w_.nsamples += b_tot
+                slot = 0
+
+            def recorder(name):
+                def add_batch(inp, out):
+                    x = inp.reshape((-1, inp.shape[-1]))
+                    static[name] = x if x.is_contiguous() else x.contiguous()
+                return add_batch
+
+            static_x = inps[0].clone()
+            static_kw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in caches[0].items()}
+            for name, w_ in wrapped.items():
+                w_.add_batch = recorder(name)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
+                    with autocast():
+                        block(static_x, **static_kw)
+            finally:
+                for w_ in wrapped.values():
+                    del w_.add_batch
+            assert set(static) == set(wrapped) and all(
+                static[n].shape == rings[n].shape[1:] and static[n].dtype == rings[n].dtype for n in static)
+            for j in range(1, n_batches):
+                static_x.copy_(inps[j], non_blocking=True)
+                for k, v in caches[j].items():
+                    if torch.is_tensor(v):
+                        static_kw[k].copy_(v, non_blocking=True)
+                graph.replay()
+                fused.multi_copy([(rings[n][slot], static[n]) for n in static])
+                slot += 1
+                if slot == S_:
+                    flush()
+            if slot:
+                flush()
+            torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
+            del graph
+            return True
+
         for i in range(len(blocks)):
             block = blocks[i]
             subset = find_layers(block)
@@ -467,8 +540,11 @@ class _BlockwiseWanda:
             with PhaseTimer.span("stage2.block_forward_with_hooks (incl. K6 / Hessian updates)"):
                 if graphed:
                     graph_pass(block, wrapped, keep=False)
-                else:
-                    for j in range(n_batches):
+                elif not (sparsegpt and graphed_plain and getattr(self.owner, "sparsegpt_graph_hooks", True)
+                          and graph_pass_hessian(block, wrapped)):
+                    # (a refused graph pass has run sample 0 already: its hooks have fired)
+                    done0 = sparsegpt and any(w_.nsamples or w_._pending for w_ in wrapped.values())
+                    for j in range(1 if done0 else 0, n_batches):
                         outs[j] = call(block, j)
             for h in handles:
                 h.remove()

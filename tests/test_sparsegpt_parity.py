@@ -166,3 +166,32 @@ def test_block_factorisations_side_by_side_equal_one_by_one():
         assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1])
         b.fasterprune(0.5)
         assert torch.equal(a.layer.weight.data, b.layer.weight.data)
+
+
+@pytest.mark.gpu
+def test_sparsegpt_hooked_pass_from_graph_replays_equals_eager():
+    """Stage 2 of `blipt5_sparsegpt_pruner` with its block passes replayed from HIP graphs (round
+    5: the hooked pass through a ring of the Linears' inputs, one MFMA Hessian call per 8 samples;
+    the pass behind the pruning as for Wanda) == the eager passes: every pruned weight bit for
+    bit, production dtypes."""
+    from ecoflap_amd import hip
+
+    def run(graphs):
+        torch.manual_seed(4)
+        model = blip2_toy(fp32=False).eval().to("cuda")
+        batches = S.image_text_batches(20, 1, img_size=28, vocab=96, in_len=5, out_len=4, seed=6, device="cuda")
+        cfg = dict(t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
+                   t5_pruning_method="none", vit_pruning_method="none", num_samples=20,
+                   kernels=hip.HipKernels(), use_graphs=graphs)
+        pruner = load_pruner("blipt5_sparsegpt_pruner", model, batches, cfg=cfg)
+        pruner.graph_min_batches = 4
+        model, _ = pruner.prune()
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    eager, graphed = run(False), run(True)
+    for k in eager:
+        assert torch.equal(eager[k], graphed[k]), k
+    blocks = [k for k, v in eager.items() if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
+    zeros = sum(int((eager[k] == 0).sum()) for k in blocks) / sum(eager[k].numel() for k in blocks)
+    assert 0.45 < zeros < 0.55
