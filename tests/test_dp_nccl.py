@@ -56,6 +56,10 @@ def test_bench_self_launch_two_ranks_on_one_gpu_over_gloo():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] is None
     assert line["process_group"] == {"backend": "gloo", "world_size": 2, "all_reduce_of_ones": 2}
+    # stage 1's one exchange, timed: the [units, 2] loss table
+    ar = line["breakdown"]["allreduce"]
+    units = line["steps"] * (line["config"]["pairs_total"] // line["config"]["batch_size"])
+    assert line["breakdown"]["allreduce_ms"] > 0 and ar["bytes"] == 4 * 2 * units, ar
     assert line["scaling"] == "weak" and line["config"]["pairs_total"] == 2 * line["config"]["pairs_per_gpu"]
     # strong scaling: ONE calibration set split over the ranks
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--toy",
