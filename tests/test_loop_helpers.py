@@ -1,6 +1,8 @@
 """Host-side helpers of the zeroth-order loop and the stage-2 block loop that only run on the
 GPU path in production (graph families, slot layout of batched evaluations, calibration
 uniformity): their pure-tensor logic, on CPU."""
+import numpy as np
+import pytest
 import torch
 
 from ecoflap_amd.pruners import prefix_cache as PC
@@ -521,3 +523,115 @@ def test_reference_style_forward_equals_the_staged_composition():
     tb = S.text_batches(4, 2, vocab=96, seed=3)
     with torch.no_grad():
         assert torch.equal(t(tb[0])["loss"], t.reference_forward(tb[0])["loss"])
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_unstaged_path_on_a_huggingface_t5(use_cache):
+    """The modules a reference user actually brings: `transformers`' own T5ForConditionalGeneration
+    behind a LAVIS-shaped wrapper (`model(samples)["loss"]`, prunable prefix `t5_model`,
+    LAVIS/lavis/models/t5_models/t5.py:60-90) — nothing of this build in the model.  Hooked per
+    evaluation and in lock step == plain full forwards: loss table and sparsity table bit for bit.
+    With `use_cache=False` the decoder's block calls are plumbing like the encoder's (tuple
+    outputs: hidden states, position bias, cross-attention bias) and join the wired segments; with
+    the library's default the decoder hands every block a KV-cache OBJECT, which the adapter
+    cannot concatenate and does not try to: those calls run per evaluation, results unchanged."""
+    transformers = pytest.importorskip("transformers")
+    import warnings
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd.pruners import LayerSparsity
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+    cfg = transformers.T5Config(vocab_size=96, d_model=32, d_kv=8, d_ff=64, num_layers=3, num_decoder_layers=3,
+                                num_heads=4, feed_forward_proj="gated-gelu", dropout_rate=0.0,
+                                tie_word_embeddings=False, decoder_start_token_id=0, pad_token_id=0)
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.t5_model = transformers.T5ForConditionalGeneration(cfg)
+
+        def forward(self, samples):
+            ids = samples["text_input"]
+            out = self.t5_model(input_ids=ids, attention_mask=(ids != 0).long(), labels=samples["text_output"],
+                                return_dict=True, use_cache=use_cache)
+            return {"loss": out.loss}
+
+    def loss_fn(m, b, c):
+        return m(b)["loss"], len(b["text_input"])
+
+    def run(mode):
+        torch.manual_seed(0)
+        model = Wrapper().eval()
+        g = torch.Generator().manual_seed(1)
+        batches = [{"text_input": torch.randint(1, 96, (2, 7), generator=g),
+                    "text_output": torch.randint(1, 96, (2, 5), generator=g)} for _ in range(4)]
+        mapping = {k: ".".join(k.split(".")[:4]) for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block." in k and "relative_attention_bias" not in k}
+        loss = loss_fn
+        if mode != "full":
+            loss = HookedPrefixLoss(model, loss_fn, ["t5_model.encoder.block", "t5_model.decoder.block"],
+                                    eval_batch=1 if mode == "hooked" else 4)
+        np.random.seed(3)
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=OracleKernels(), z_source=torch_cpu_normal)
+        sp = ls.return_sparsity()
+        if mode != "full":
+            loss.close()
+        return ls.loss_table, sp, loss
+
+    full = run("full")
+    for mode in ("hooked", "lock"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")          # nothing gives up, nothing is switched off
+            got = run(mode)
+        assert np.array_equal(full[0], got[0]) and full[1] == got[1], mode
+        h = got[2]
+        assert len(h.sequence) == 6 and not h.disabled
+        # encoder blocks 1, 2 always follow their predecessor by plumbing; decoder blocks 4, 5 do
+        # when no cache object travels with them
+        assert sorted(h.wired) == ([1, 2, 4, 5] if not use_cache else [1, 2]), sorted(h.wired)
+        if mode == "lock":
+            assert h.stats["lockstep_evals"] > 0 and h.stats.get("owner_batched_evals", 0) > 0
+
+
+@pytest.mark.parametrize("name", ["t5_wanda_pruner", "vit_wanda_pruner"])
+def test_unstaged_single_tower_pruners_equal_their_staged_runs(name):
+    """`t5_wanda_pruner` (loss_language, `t5_model.{en,de}coder.block`) and `vit_wanda_pruner`
+    (loss_vision through `predict()`, `visual.blocks`) on their shape modules with the stage plan
+    hidden: the hook adapter finds the block lists, lock step included, and table and pruned
+    weights equal the staged run's bit for bit."""
+    from oracle_backend import OracleKernels, torch_cpu_normal
+    from ecoflap_amd import load_pruner
+    from ecoflap_amd.shapes import synthetic as S
+    from ecoflap_amd.shapes.eva_clip import EVACLIP, vit_toy
+    from ecoflap_amd.shapes.t5 import T5, t5_config
+    from ecoflap_amd.shapes.unstaged import hidden_stage_plan
+
+    def run(eval_batch):
+        torch.manual_seed(2)
+        if name == "t5_wanda_pruner":
+            model = T5(t5_config(d_model=32, d_kv=8, num_heads=4, d_ff=64, num_layers=2, vocab_size=96),
+                       dtype=None, init_std=0.2).eval()
+            batches = S.text_batches(8, 2, vocab=96, seed=5)
+            cfg = dict(prune_spec="2-0.5-1.0-1.0", score_method="MEZO-GradOnly_avg")
+        else:
+            model = vit_toy().eval()
+            batches = S.image_label_batches(8, 2, img_size=32, num_classes=5, seed=5)
+            cfg = dict(prune_spec="3-0.5-1.0-1.0", score_method="MEZO-GradOnly_sum")
+        np.random.seed(9)
+        cfg.update(num_samples=8, num_data_first_stage=8, sparsity_ratio_granularity="block",
+                   max_sparsity_per_layer=0.6, kernels=OracleKernels(), z_source=torch_cpu_normal,
+                   eval_batch=eval_batch)
+        pruner = load_pruner(name, model, batches, cfg=cfg)
+        model, table = pruner.prune()
+        return table, {k: v.clone() for k, v in model.state_dict().items()}, pruner.stage_stats
+
+    staged = run(1)
+    assert len(set(staged[0].values())) > 1
+    with hidden_stage_plan(T5, EVACLIP):
+        for eb in (1, 4):
+            got = run(eb)
+            assert got[0] == staged[0], eb
+            for k in staged[1]:
+                assert torch.equal(got[1][k], staged[1][k]), (eb, k)
+            sf = got[2]["stage1"]["suffix_forward"]
+            assert sf["events_served"] > 0 and (sf.get("lockstep_evals", 0) > 0) == (eb > 1), sf
