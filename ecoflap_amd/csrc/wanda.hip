@@ -1452,6 +1452,28 @@ static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
 // K7 matrix mode: global (k+1)-th smallest over rows*cols by 3 histogram passes
 // (11 + 11 + 10 bits), then zero metric <= threshold.
 // =====================================================================================
+// Phase clock for the matrix-mode kernels, compiled in only by tools/diag/k7_clock.sh
+// (-DECO_K7_CLOCK, its own .so): workgroup 0 stamps the 100 MHz wall clock at its phase boundaries,
+// every workgroup folds its entry / exit into a min / max.
+#ifdef ECO_K7_CLOCK
+__device__ unsigned long long eco_k7_clk[8][16];
+#define K7_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) eco_k7_clk[k][i] = wall_clock64(); } while (0)
+#define K7_ENTER(k) do { if (threadIdx.x == 0) atomicMin(&eco_k7_clk[k][14], wall_clock64()); } while (0)
+#define K7_EXIT(k) do { if (threadIdx.x == 0) atomicMax(&eco_k7_clk[k][15], wall_clock64()); } while (0)
+extern "C" int ecoflap_debug_k7_clock_reset(void) {
+    unsigned long long z[8][16];
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 16; ++i) z[k][i] = i == 14 ? ~0ull : 0ull;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_clk), z, sizeof(z));
+}
+extern "C" int ecoflap_debug_k7_clock_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eco_k7_clk), sizeof(unsigned long long) * 8 * 16);
+}
+#else
+#define K7_STAMP(k, i) do { } while (0)
+#define K7_ENTER(k) do { } while (0)
+#define K7_EXIT(k) do { } while (0)
+#endif
+
 struct MatrixSelState {
     uint32_t hist[3][2048];
     uint32_t resolved[3][2];      // (prefix, remaining rank) after pass 1, 2, 3
@@ -1803,6 +1825,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
     __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
     __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
     const int it = blockIdx.x;
+    K7_ENTER(0); K7_STAMP(0, 0);
     const void* __restrict__ w = g.w[it];
     const float* __restrict__ sr = g.scaler_row[it];
     BracketState* bs = g.bs[it];
@@ -1829,7 +1852,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
             for (int e = 0; e < 4; ++e) sc[j][4 * q + e] = __uint_as_float(s4[e]);
         }
     }
+    K7_STAMP(0, 1);
     __syncthreads();
+    K7_STAMP(0, 2);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int i = threadIdx.x + WM_THREADS * j;
@@ -1844,7 +1869,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
             else atomicAdd(&h1[top], 1u);                       // (-0 / NaN patterns: rare)
         }
     }
+    K7_STAMP(0, 3);
     __syncthreads();
+    K7_STAMP(0, 4);
     {
         uint32_t c = 0;
 #pragma unroll
@@ -1860,8 +1887,10 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
     const bool open_lo = mid - dev < 1.0, open_hi = mid + dev > (double)S;
     const uint32_t r_lo = open_lo ? 1u : (uint32_t)(mid - dev);
     const uint32_t r_hi = open_hi ? (uint32_t)S : (uint32_t)(mid + dev);
+    K7_STAMP(0, 5);
     find_rank_wm(h1, r_lo, waves, o_lo);
     find_rank_wm(h1, r_hi, waves, o_hi);
+    K7_STAMP(0, 6);
     const uint32_t b_lo = o_lo[0], b_hi = o_hi[0];
     for (int i = threadIdx.x; i < S; i += WM_THREADS) {
         const uint32_t b = sb[i];
@@ -1869,8 +1898,10 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
         if ((b >> 21) == b_hi) atomicAdd(&h2b[(b >> 10) & 2047u], 1u);
     }
     __syncthreads();
+    K7_STAMP(0, 7);
     find_rank_wm(h2a, o_lo[1], waves, s_lo);
     find_rank_wm(h2b, o_hi[1], waves, s_hi);
+    K7_STAMP(0, 8);
     if (threadIdx.x == 0) {
         const uint32_t lo = open_lo ? 0u : ((b_lo << 21) | (s_lo[0] << 10));
         const uint64_t hi64 = open_hi ? 0x100000000ull
@@ -1882,6 +1913,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const S
         bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift;
         bs->valid = hi > lo ? 1u : 0u;
     }
+    K7_EXIT(0);
 }
 
 struct BracketGroup {
@@ -1903,11 +1935,13 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const 
     __shared__ uint32_t h[WS_BINS];
     __shared__ uint32_t red[WM_WAVES];
     __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    K7_ENTER(1); K7_STAMP(1, 0);
     if (!bs->valid) return;
     const uint32_t lo = bs->lo, width = bs->hi - bs->lo, shift = bs->shift;
     for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS) h[i] = 0;
     sq = stage_sqrt(bg.sr[it], cols, sq_lds);
     __syncthreads();
+    K7_STAMP(1, 1);
     uint32_t below = 0;
     const int64_t vpr = cols / N;
     const int64_t nvec = rows * vpr;
@@ -1941,6 +1975,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const 
             }
         }
     }
+    K7_STAMP(1, 2);
     // count below the bracket: wave sum, then one atomic per workgroup
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
@@ -1954,6 +1989,8 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const 
     }
     for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS)
         if (h[i]) atomicAdd(&bs->hist[i], h[i]);
+    K7_STAMP(1, 3);
+    K7_EXIT(1);
 }
 
 template <int DT>
@@ -1974,6 +2011,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     __shared__ uint32_t arr[WS_CAP];
     __shared__ uint32_t hsel[2048];
     __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    K7_ENTER(2); K7_STAMP(2, 0);
     if (!bs->valid) {
         if (lb == 0 && threadIdx.x == 0) bs->fallback = 1u;
         return;
@@ -1999,6 +2037,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
         return;
     }
     const uint32_t binlo = lo + (bin << shift), binw = (uint32_t)binhi64 - binlo;
+    K7_STAMP(2, 1);
     {
         const int64_t vpr = cols / N;
         const int64_t nvec = rows * vpr;
@@ -2073,13 +2112,19 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
         }
     }
     // ---- the last workgroup of this matrix settles the threshold's bin ----------------------
+    K7_STAMP(2, 2);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    K7_STAMP(2, 3);
     if (threadIdx.x == 0)
         is_last = (__hip_atomic_fetch_add(&bs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    == nb - 1u) ? 1u : 0u;
     __syncthreads();
+    K7_EXIT(2);
     if (!is_last) return;
+#ifdef ECO_K7_CLOCK
+    if (threadIdx.x == 0) atomicMin(&eco_k7_clk[3][14], wall_clock64());
+#endif
     const uint32_t n = __hip_atomic_load(&bs->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > (uint32_t)WS_CAP || n < rr) {          // too crowded (ties): the host finishes this matrix
         if (threadIdx.x == 0) bs->fallback = 2u;
@@ -2122,6 +2167,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
         if (prune) Vec<DT>::store1(w, (int64_t)idx, 0.0f);
         if (mask_out) mask_out[idx] = prune ? 1 : 0;
     }
+    K7_EXIT(3);
 }
 
 // The exact finish for a matrix the sampled passes could not settle (bracket miss ~1e-6 per
@@ -2166,6 +2212,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_fallback_kernel(const
     const MatGroup& g = bg.m;
     const int it = blockIdx.x;                   // one workgroup per matrix
     BracketState* bs = bg.bs[it];
+    K7_ENTER(4); K7_EXIT(4);
     if (bs->fallback == 0u) return;              // settled by the sampled passes
     constexpr int N = Vec<DT>::N;
     void* w = g.w[it];

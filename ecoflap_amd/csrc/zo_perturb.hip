@@ -573,15 +573,18 @@ static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, 
     const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
     // logf(u) (ocml, u is never subnormal here: u >= 2^-32)
     const float r = __builtin_amdgcn_logf(u);                       // v_log_f32: log2
-    const float ln2_hi = __uint_as_float(0x3f317217u);              // ocml's split of ln 2: hi + lo
-    const float yl = r * ln2_hi;
-    float t = __builtin_fmaf(r, ln2_hi, -yl);
-    t = __builtin_fmaf(__uint_as_float(0x3377d1cfu), r, t);
-    const float ln = yl + t;
-    const float x2 = -2.0f * ln;
+    // ocml's split of ln 2 (hi 0x3f317217 + lo 0x3377d1cf) with rocRAND's "-2 *" folded into both
+    // constants: scaling by -2 is exact at every step (no value here is subnormal), so
+    // x2 = -2 * (yl + fma(lo, r, fma(r, hi, -yl))) bit for bit, one multiply less per pair
+    const float m2ln2_hi = __uint_as_float(0xbfb17217u);
+    const float yl = r * m2ln2_hi;
+    float t = __builtin_fmaf(r, m2ln2_hi, -yl);
+    t = __builtin_fmaf(__uint_as_float(0xb3f7d1cfu), r, t);
+    const float x2 = yl + t;
     // sqrtf(x2), correctly rounded: v_sqrt_f32 and one step either way (x2 is 0 or >= 1e-7:
-    // ocml's rescaling of tiny arguments never triggers; for x2 = -0 every comparison below is
-    // false and s stays -0, which the final "+ 0" turns into torch's +0)
+    // ocml's rescaling of tiny arguments never triggers; u = 1 gives x2 = +0 here where the
+    // unfolded form has -0: every comparison below is false either way and the final "+ 0"
+    // produces torch's +0 from both)
     const float s0 = __builtin_amdgcn_sqrtf(x2);
     const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
     const float rm = __builtin_fmaf(-sm, s0, x2), rp = __builtin_fmaf(-sp, s0, x2);
