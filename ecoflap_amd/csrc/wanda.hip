@@ -494,8 +494,6 @@ struct SqrtGroup {
     int64_t cols[WMAX];
     uint32_t* zero[WMAX];         // matrix mode: the item's selection state, cleared here (no memset launch)
     int zero_words;
-    uint32_t* zero2[WMAX];        // ... and the head of its bracket state
-    int zero2_words;
 };
 __global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
     const int it = group_item(g, blockIdx.x);
@@ -504,8 +502,6 @@ __global__ __launch_bounds__(256) void sqrt_cols_kernel(const SqrtGroup g) {
     if (c < g.cols[it]) g.dst[it][c] = __builtin_sqrtf(g.src[it][c]);
     if (g.zero[it])
         for (int i = lb * 256 + threadIdx.x; i < g.zero_words; i += nb * 256) g.zero[it][i] = 0u;
-    if (g.zero2[it])
-        for (int i = lb * 256 + threadIdx.x; i < g.zero2_words; i += nb * 256) g.zero2[it][i] = 0u;
 }
 
 template <int DT>
@@ -1494,6 +1490,22 @@ struct MatrixSelState {
 #define WM_UNROLL 4
 #define WM_SQ_LDS 16384      // columns whose sqrt table is staged in LDS (64 KiB of the CU's 160)
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a release / acquire fence on
+// every address space, which the compiler implements as s_waitcnt vmcnt(0): in a kernel that has
+// its share of W in flight in registers, EVERY barrier of the prologue then waits for the whole
+// stream (measured: 12 us to the first barrier instead of 2).  Here: lgkmcnt(0) (LDS and scalar
+// loads; vmcnt 63 / expcnt 7 = do not wait) and s_barrier; the "memory" clobber keeps the compiler
+// from moving accesses across it.  Threads that exchange data through GLOBAL memory inside one
+// kernel must not use this.
+static __device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <bool LDS_ONLY>
+static __device__ __forceinline__ void wm_barrier() {
+    if (LDS_ONLY) lds_barrier();
+    else __syncthreads();
+}
+
 // sqrt(scaler_row) of the workgroup's matrix into LDS (every vector needs 2 x 16 bytes of it:
 // from global memory those were two dependent cache round trips per vector, most of a pass)
 static __device__ __forceinline__ const float* stage_sq(const float* __restrict__ sq, int64_t cols,
@@ -1510,11 +1522,40 @@ static __device__ __forceinline__ const float* stage_sqrt(const float* __restric
     __syncthreads();
     return lds;
 }
+// the same in two halves, so that the statistic's loads can be issued BEFORE a long run of other
+// loads (loads return in order: issued after them, these would wait for all of them) and consumed
+// after it: the first WM_SR_PRE * WM_THREADS columns travel through registers
+#define WM_SR_PRE 8
+struct SqrtPre { float v[WM_SR_PRE]; };
+static __device__ __forceinline__ SqrtPre stage_sqrt_issue(const float* __restrict__ sr, int64_t cols) {
+    SqrtPre p;
+#pragma unroll
+    for (int q = 0; q < WM_SR_PRE; ++q) {
+        // (index clamped, not predicated: a predicated load becomes a branch, and the compiler
+        // then sinks the wait and the sqrt into it — eight serial round trips)
+        const int64_t c = threadIdx.x + (int64_t)q * WM_THREADS;
+        p.v[q] = sr[c < cols ? c : cols - 1];
+    }
+    return p;
+}
+static __device__ __forceinline__ const float* stage_sqrt_finish(const SqrtPre& p, const float* __restrict__ sr,
+                                                                 int64_t cols, float* lds) {
+#pragma unroll
+    for (int q = 0; q < WM_SR_PRE; ++q) {
+        const int64_t c = threadIdx.x + (int64_t)q * WM_THREADS;
+        if (c < cols) lds[c] = __builtin_sqrtf(p.v[q]);
+    }
+    for (int64_t c = threadIdx.x + (int64_t)WM_SR_PRE * WM_THREADS; c < cols; c += WM_THREADS)
+        lds[c] = __builtin_sqrtf(sr[c]);
+    lds_barrier();
+    return lds;
+}
 static __device__ __forceinline__ u32x4 ld_sq4(const float* sq, int64_t i4) {
     return *(const u32x4*)(sq + 4 * i4);      // LDS or global, 16-byte aligned either way
 }
 
 // inclusive scan of one value per thread over the 1024-thread block; returns (inclusive, total)
+template <bool LDS_ONLY = false>
 static __device__ __forceinline__ uint32_t block_scan_wm(uint32_t v, uint32_t* lds_waves,
                                                          uint32_t& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1524,9 +1565,9 @@ static __device__ __forceinline__ uint32_t block_scan_wm(uint32_t v, uint32_t* l
         const uint32_t y = __shfl_up(x, off, 64);
         if (lane >= off) x += y;
     }
-    __syncthreads();  // protect lds_waves reuse
+    wm_barrier<LDS_ONLY>();  // protect lds_waves reuse
     if (lane == 63) lds_waves[wave] = x;
-    __syncthreads();
+    wm_barrier<LDS_ONLY>();
     uint32_t base = 0, t = 0;
 #pragma unroll
     for (int k = 0; k < WM_WAVES; ++k) {
@@ -1753,7 +1794,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
 }
 
 // =====================================================================================
-// K7 matrix mode, sampled bracket: 2 reads + 1 write of W instead of 4 + 1
+// K7 matrix mode, sampled bracket: 2 reads + 1 write of W instead of 4 + 1, in TWO dependent launches
 // =====================================================================================
 // The three histogram passes above read W three times to find ONE number.  Here a sample of
 // WS_SAMPLE_VECS vectors per matrix (pseudo-randomly placed, one per stride) brackets the (k+1)-th
@@ -1766,31 +1807,41 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
 // them.  Every count is exact, so the result is the reference's (W:555-558) bit for bit; when the
 // bracket misses (probability ~1e-6 per matrix), the bin is too crowded for the list (massive
 // ties) or the threshold is not finite, the pass flags the matrix WITHOUT having decided anything
-// wrongly (elements below the bin are pruned in the exact answer too) and the host runs the
-// three-histogram path on it.
+// wrongly (elements below the bin are pruned in the exact answer too) and one more workgroup per
+// matrix runs the three-histogram selection on it (wanda_matrix_fallback_kernel).
+//
+// Round 5, after a phase clock on the device (tools/diag/k7_clock.py: sample 14.9 us alone on 4
+// workgroups, 1.6 us to the next launch, bracket pass 19 us of which 11 streaming, apply pass 21 us
+// of which 4.2 before its first load, 5 us of threshold settling at the end): the sample no longer
+// has a launch of its own.  EVERY workgroup of the counting pass takes the sample of its matrix
+// itself (2048 vectors, L2 hits after the first workgroup; the result is a pure function of W and
+// the statistic, so all workgroups hold the same bracket and nobody waits for anybody — no flag,
+// no spin, nothing that could deadlock against another process's launch) while the WS_PRE vectors
+// per thread that are its share of the matrix are already on their way into registers; counts go
+// to a slot per workgroup (no zeroed state, no atomics meeting at the memory side) which the
+// apply pass sums in its prologue, again with its share of W already in flight.
 #define WS_SAMPLE_VECS 2048
 #define WS_BINS 512
-#define WS_CAP 8192
+#define WS_CAP 16384                    // list of the threshold bin's elements (LDS of the settling workgroup)
+// Matrices of more elements than this keep the three-histogram selection: the bracket holds up to
+// ~8.5 % of a matrix (5 sigma of the sample plus a sample bin either side) in 256-512 histogram
+// bins, so the threshold's bin of a larger matrix would outgrow the list and every such call
+// would end in the one-workgroup fallback.
+#define WS_MAX_NUMEL (48ll << 20)
+#define WS_PRE 4                        // vectors per thread in registers across the prologue (see below)
+#define WS_PART_WORDS (WS_BINS + 8)     // a workgroup's slot: histogram, count below the bracket
 
 struct BracketState {
-    // zeroed by the sqrt kernel
-    uint32_t count_below;
-    uint32_t list_count, ticket, fallback;
-    uint32_t hist[WS_BINS];
-    // written by the sample workgroup
-    uint32_t lo, hi, shift, valid;
+    uint32_t list_count, ticket, fallback, pad;     // cleared by the counting pass
+    uint32_t lo, hi, shift, valid;                  // written by the counting pass
     uint32_t list_idx[WS_CAP];
     uint32_t list_bits[WS_CAP];
 };
-#define WS_ZERO_WORDS (4 + WS_BINS)
 
-struct SampleGroup {
-    int n;
-    const void* w[WMAX];
-    const float* scaler_row[WMAX];     // the raw statistic: sqrt taken here (same value as the table)
-    int64_t rows[WMAX], cols[WMAX];
-    uint32_t rank0[WMAX];
+struct BracketGroup {
+    MatGroup m;
     BracketState* bs[WMAX];
+    const float* sr[WMAX];          // the raw statistic (sqrt taken while staging it into LDS)
 };
 
 // rank (1-based) -> (bin, rank inside the bin) over an LDS histogram of 2048 bins, WM_THREADS threads
@@ -1807,199 +1858,208 @@ static __device__ __forceinline__ void find_rank_wm(const uint32_t* h, uint32_t 
     }
     __syncthreads();
 }
-
-// One workgroup per matrix: WS_SAMPLE_VECS vectors (one per stride of the matrix, at a
-// pseudo-random place inside its stride: a regular stride can be a multiple of the row length
-// and then sees one column group only), their metrics (sqrt of the statistic taken here: the
-// same correctly rounded value as the table's), two levels of histogram in LDS (11 + 11 bits)
-// -> bracket [lo, hi) at 22-bit resolution.  Also clears the head of the bracket state.
+// the counting pass: sample -> bracket [lo, hi) (every workgroup, identically), then the exact
+// count below the bracket and the WS_BINS-bin histogram inside it over the workgroup's share of W.
+// The sample's two order statistics are taken at the resolution of ONE histogram — 4096 bins of
+// 1/16 octave (metric bits >> 19): the bracket's edges are bin edges, up to 4 % of the elements wider
+// on either side than the exact order statistics would make it, which costs the exact pass a few
+// more LDS atomics and saves the prologue a second histogram level (two more scans, five barriers:
+// 3.5 us of every workgroup's time by the phase clock).  Nothing about exactness depends on where
+// the edges lie.
+#define WS_SBINS 4096
+#define WS_SSUB 4                      // interleaved counters per sample bin (few dozen live bins)
 template <int DT>
-__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sample_kernel(const SampleGroup g) {
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sbracket_kernel(const BracketGroup bg,
+                                                                           uint32_t* __restrict__ part) {
+    const MatGroup& g = bg.m;
+    const int it = group_item(g, blockIdx.x);
+    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
+    const void* __restrict__ w = g.w[it];
+    const int64_t rows = g.rows[it], cols = g.cols[it];
+    BracketState* bs = bg.bs[it];
     constexpr int N = Vec<DT>::N;
     constexpr int S = WS_SAMPLE_VECS * N;
-    constexpr int VPT = WS_SAMPLE_VECS / WM_THREADS;          // vectors per thread
-    __shared__ uint32_t sb[WS_SAMPLE_VECS * 8];
-    // first level: 16 interleaved counters per bin (the top 11 bits of a metric take a few dozen
-    // values: same-address LDS atomics are served one by one); finite metrics have bit 31 clear
-    __shared__ uint32_t h1s[1024 * 16];
-    __shared__ uint32_t h1[2048], h2a[2048], h2b[2048];
-    __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], s_lo[2], s_hi[2];
-    const int it = blockIdx.x;
-    K7_ENTER(0); K7_STAMP(0, 0);
-    const void* __restrict__ w = g.w[it];
-    const float* __restrict__ sr = g.scaler_row[it];
-    BracketState* bs = g.bs[it];
-    const int64_t cols = g.cols[it];
-    const int64_t vpr = cols / N, nvec = g.rows[it] * vpr;
-    const int64_t step = nvec / WS_SAMPLE_VECS;
-    for (int i = threadIdx.x; i < WS_ZERO_WORDS; i += WM_THREADS) ((uint32_t*)bs)[i] = 0u;
-    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) { h1[i] = 0; h2a[i] = 0; h2b[i] = 0; }
-    for (int i = threadIdx.x; i < 1024 * 16; i += WM_THREADS) h1s[i] = 0;
-    // every load of the thread in flight before the first use
-    u32x4 wv[VPT];
-    float sc[VPT][N];
+    constexpr int VPT = WS_SAMPLE_VECS / WM_THREADS;          // sample vectors per thread
+    __shared__ uint32_t h[WS_BINS];
+    __shared__ uint32_t red[WM_WAVES];
+    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
+    __shared__ __attribute__((aligned(16))) uint32_t h1s[WS_SBINS * WS_SSUB];
+    __shared__ uint32_t waves[WM_WAVES], o_lo[2], o_hi[2], brk[4];
+    K7_ENTER(1); K7_STAMP(1, 0);
+    const int64_t vpr = cols / N, nvec = rows * vpr;
+    const uint32_t vpr32 = (uint32_t)vpr;
+    // ---- the prologue's global loads, issued before anything waits --------------------------
+    const SqrtPre srp = stage_sqrt_issue(bg.sr[it], cols);
+    // the sample: one vector per stride of the matrix, at a pseudo-random place inside its stride
+    // (a regular stride can be a multiple of the row length and then sees one column group only)
+    const uint32_t step = (uint32_t)(nvec / WS_SAMPLE_VECS);
+    u32x4 sv[VPT];
+    uint32_t sc0[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-        const int i = threadIdx.x + WM_THREADS * j;
-        const uint32_t jitter = (uint32_t)(((uint64_t)((uint32_t)i * 2654435761u) * (uint64_t)step) >> 32);
-        const int64_t v = (int64_t)i * step + jitter;
-        const int64_t c0 = (v % vpr) * N;
-        wv[j] = ld16(w, v);
-#pragma unroll
-        for (int q = 0; q < N / 4; ++q) {
-            const u32x4 s4 = *(const u32x4*)(sr + c0 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sc[j][4 * q + e] = __uint_as_float(s4[e]);
-        }
+        const uint32_t i = threadIdx.x + WM_THREADS * j;
+        const uint32_t jitter = (uint32_t)(((uint64_t)(i * 2654435761u) * (uint64_t)step) >> 32);
+        const uint32_t v = i * step + jitter;
+        sc0[j] = (v % vpr32) * N;
+        sv[j] = ld16(w, (int64_t)v);
     }
-    K7_STAMP(0, 1);
-    __syncthreads();
-    K7_STAMP(0, 2);
+    // A compute unit serves its waves' loads in the order they arrive: every wave's prologue loads
+    // are queued before any wave's W loads
+    lds_barrier();
+    // The first WS_PRE vectors per thread of the workgroup's share of W, in registers across the
+    // sample.  Not more: a wave cannot run ahead of its own loads by more than the memory pipeline
+    // holds — with the whole share (12 vectors) issued up front the waves sat in the ISSUE of those
+    // loads until most of the stream had arrived, and the sample waited with them.
+    const uint32_t nvec32 = (uint32_t)nvec, stride32 = nb * WM_THREADS;     // (numel < 2^32)
+    const uint32_t vfirst32 = lb * WM_THREADS + threadIdx.x;
+    u32x4 cur[WS_PRE];
+#pragma unroll
+    for (int j = 0; j < WS_PRE; ++j) {
+        const uint32_t v = vfirst32 + j * stride32;
+        cur[j] = ld16(w, (int64_t)(v < nvec32 ? v : nvec32 - 1u));  // (clamped: no branch around a load)
+    }
+    for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS) h[i] = 0;
+    for (int i = threadIdx.x; i < WS_SBINS * WS_SSUB; i += WM_THREADS) h1s[i] = 0;
+    const float* sq = stage_sqrt_finish(srp, bg.sr[it], cols, sq_lds);      // (ends with a barrier)
+    K7_STAMP(1, 1);
+    // ---- the sample's histogram -------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-        const int i = threadIdx.x + WM_THREADS * j;
         float f[N];
-        Vec<DT>::unpack(wv[j], f);
+        Vec<DT>::unpack(sv[j], f);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __builtin_sqrtf(sc[j][e]));
-            sb[i * N + e] = b;
-            const uint32_t top = b >> 21;
-            if (top < 1024u) atomicAdd(&h1s[top * 16 + (threadIdx.x & 15)], 1u);
-            else atomicAdd(&h1[top], 1u);                       // (-0 / NaN patterns: rare)
+            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * sq[sc0[j] + e]);
+            const uint32_t top = b >> 19;                       // (sign-bit patterns: the last bin)
+            atomicAdd(&h1s[(top < (uint32_t)WS_SBINS ? top : (uint32_t)WS_SBINS - 1u) * WS_SSUB + (threadIdx.x & (WS_SSUB - 1))], 1u);
         }
     }
-    K7_STAMP(0, 3);
-    __syncthreads();
-    K7_STAMP(0, 4);
-    {
-        uint32_t c = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c += h1s[threadIdx.x * 16 + q];
-        h1[threadIdx.x] = c;                                    // WM_THREADS == 1024 bins
-    }
-    __syncthreads();
-    // sample ranks 5 sigma either side of the expected one
-    const double numel = (double)g.rows[it] * (double)cols;
+    lds_barrier();
+    K7_STAMP(1, 2);
+    // sample ranks 5 sigma either side of the expected one; four bins per thread, one scan
+    const double numel = (double)rows * (double)cols;
     const double p = (double)g.rank0[it] / numel;
     const double mid = p * S;
     const double dev = 5.0 * __builtin_sqrt((double)S * p * (1.0 - p)) + 8.0;
     const bool open_lo = mid - dev < 1.0, open_hi = mid + dev > (double)S;
     const uint32_t r_lo = open_lo ? 1u : (uint32_t)(mid - dev);
     const uint32_t r_hi = open_hi ? (uint32_t)S : (uint32_t)(mid + dev);
-    K7_STAMP(0, 5);
-    find_rank_wm(h1, r_lo, waves, o_lo);
-    find_rank_wm(h1, r_hi, waves, o_hi);
-    K7_STAMP(0, 6);
-    const uint32_t b_lo = o_lo[0], b_hi = o_hi[0];
-    for (int i = threadIdx.x; i < S; i += WM_THREADS) {
-        const uint32_t b = sb[i];
-        if ((b >> 21) == b_lo) atomicAdd(&h2a[(b >> 10) & 2047u], 1u);
-        if ((b >> 21) == b_hi) atomicAdd(&h2b[(b >> 10) & 2047u], 1u);
+    {
+        uint32_t c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 x = *(const u32x4*)(h1s + (4 * threadIdx.x + k) * WS_SSUB);
+            c4[k] = x[0] + x[1] + x[2] + x[3];
+        }
+        const uint32_t csum = c4[0] + c4[1] + c4[2] + c4[3];
+        uint32_t total;
+        const uint32_t incl = block_scan_wm<true>(csum, waves, total);
+        const uint32_t excl = incl - csum;
+        if (excl < r_lo && r_lo <= incl) {
+            uint32_t e = excl; int d = 0; bool on = true;      // first bin whose running count reaches the rank
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                on = on && r_lo > e + c4[k];
+                if (on) { e += c4[k]; d = k + 1; }
+            }
+            o_lo[0] = 4 * threadIdx.x + (uint32_t)d;
+        }
+        if (excl < r_hi && r_hi <= incl) {
+            uint32_t e = excl; int d = 0; bool on = true;      // first bin whose running count reaches the rank
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                on = on && r_hi > e + c4[k];
+                if (on) { e += c4[k]; d = k + 1; }
+            }
+            o_hi[0] = 4 * threadIdx.x + (uint32_t)d;
+        }
     }
-    __syncthreads();
-    K7_STAMP(0, 7);
-    find_rank_wm(h2a, o_lo[1], waves, s_lo);
-    find_rank_wm(h2b, o_hi[1], waves, s_hi);
-    K7_STAMP(0, 8);
+    lds_barrier();
     if (threadIdx.x == 0) {
-        const uint32_t lo = open_lo ? 0u : ((b_lo << 21) | (s_lo[0] << 10));
-        const uint64_t hi64 = open_hi ? 0x100000000ull
-                                      : ((uint64_t)((b_hi << 21) | (s_hi[0] << 10)) + 1024ull);
+        const uint32_t lo = open_lo ? 0u : (o_lo[0] << 19);
+        const uint64_t hi64 = open_hi ? 0x100000000ull : ((uint64_t)(o_hi[0] + 1u) << 19);
         const uint32_t hi = hi64 > 0xffffffffull ? 0xffffffffu : (uint32_t)hi64;
         const uint32_t width = hi - lo;
         int shift = 0;
         while (shift < 31 && ((width - 1u) >> shift) >= (uint32_t)WS_BINS) ++shift;
-        bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift;
-        bs->valid = hi > lo ? 1u : 0u;
+        brk[0] = lo; brk[1] = hi; brk[2] = (uint32_t)shift; brk[3] = hi > lo ? 1u : 0u;
+        if (lb == 0) {
+            bs->list_count = 0u; bs->ticket = 0u; bs->fallback = 0u;
+            bs->lo = lo; bs->hi = hi; bs->shift = (uint32_t)shift; bs->valid = hi > lo ? 1u : 0u;
+        }
     }
-    K7_EXIT(0);
-}
-
-struct BracketGroup {
-    MatGroup m;
-    BracketState* bs[WMAX];
-    const float* sr[WMAX];          // the raw statistic (sqrt taken while staging it into LDS)
-};
-
-template <int DT>
-__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_bracket_kernel(const BracketGroup bg) {
-    const MatGroup& g = bg.m;
-    const int it = group_item(g, blockIdx.x);
-    const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
-    const void* __restrict__ w = g.w[it];
-    const float* sq = g.sq[it];
-    const int64_t rows = g.rows[it], cols = g.cols[it];
-    BracketState* bs = bg.bs[it];
-    constexpr int N = Vec<DT>::N;
-    __shared__ uint32_t h[WS_BINS];
-    __shared__ uint32_t red[WM_WAVES];
-    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
-    K7_ENTER(1); K7_STAMP(1, 0);
-    if (!bs->valid) return;
-    const uint32_t lo = bs->lo, width = bs->hi - bs->lo, shift = bs->shift;
-    for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS) h[i] = 0;
-    sq = stage_sqrt(bg.sr[it], cols, sq_lds);
-    __syncthreads();
-    K7_STAMP(1, 1);
+    lds_barrier();
+    K7_STAMP(1, 3);
+    const uint32_t lo = brk[0], width = brk[1] - brk[0], shift = brk[2];
+    // ---- the exact counts over the share of W: the next WS_PRE loads in flight while the ---------
+    // ---- current ones are counted                                                       ---------
     uint32_t below = 0;
-    const int64_t vpr = cols / N;
-    const int64_t nvec = rows * vpr;
-    const int64_t stride = (int64_t)nb * WM_THREADS;
-    const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
-    uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
-    for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
-        u32x4 wv[WM_UNROLL];
+    if (brk[3]) {
+        const uint32_t step32 = stride32 % vpr32;
+        uint32_t cv = vfirst32 % vpr32;
+        const uint32_t wg_first = lb * WM_THREADS;              // (uniform: the loop's trip count)
+        for (uint32_t base = 0; wg_first + base < nvec32; base += WS_PRE * stride32) {
+            u32x4 nxt[WS_PRE];
+            const bool more = wg_first + base + WS_PRE * stride32 < nvec32;
+            if (more) {
 #pragma unroll
-        for (int j = 0; j < WM_UNROLL; ++j)
-            if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
-#pragma unroll
-        for (int j = 0; j < WM_UNROLL; ++j) {
-            const int64_t v = v0 + j * stride;
-            const int64_t c0 = (int64_t)cv * N;
-            cv += step32;
-            if (cv >= vpr32) cv -= vpr32;
-            if (v >= nvec) continue;
-            float f[N];
-            Vec<DT>::unpack(wv[j], f);
-#pragma unroll
-            for (int q = 0; q < N / 4; ++q) {
-                const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
-                    const uint32_t rel = b - lo;
-                    below += b < lo ? 1u : 0u;
-                    if (b >= lo && rel < width) atomicAdd(&h[rel >> shift], 1u);
+                for (int j = 0; j < WS_PRE; ++j) {
+                    const uint32_t v = vfirst32 + base + (WS_PRE + j) * stride32;
+                    nxt[j] = ld16(w, (int64_t)(v < nvec32 ? v : nvec32 - 1u));
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < WS_PRE; ++j) {
+                const uint32_t c0 = cv * N;
+                cv += step32;
+                if (cv >= vpr32) cv -= vpr32;
+                if (vfirst32 + base + j * stride32 < nvec32) {
+                    float f[N];
+                    Vec<DT>::unpack(cur[j], f);
+#pragma unroll
+                    for (int q = 0; q < N / 4; ++q) {
+                        const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t b = __float_as_uint(__builtin_fabsf(f[4 * q + i]) * __uint_as_float(s4[i]));
+                            const uint32_t rel = b - lo;
+                            below += b < lo ? 1u : 0u;
+                            if (b >= lo && rel < width) atomicAdd(&h[rel >> shift], 1u);
+                        }
+                    }
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < WS_PRE; ++j) cur[j] = nxt[j];
             }
         }
     }
-    K7_STAMP(1, 2);
-    // count below the bracket: wave sum, then one atomic per workgroup
+    K7_STAMP(1, 4);
+    // the workgroup's slot: its histogram and its count below the bracket
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = below;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    lds_barrier();
+    uint32_t* slot = part + (size_t)blockIdx.x * WS_PART_WORDS;
+    if (threadIdx.x < WS_BINS) slot[threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x == WS_BINS) {
         uint32_t t = 0;
 #pragma unroll
         for (int k = 0; k < WM_WAVES; ++k) t += red[k];
-        if (t) atomicAdd(&bs->count_below, t);
+        slot[WS_BINS] = t;
     }
-    for (int i = threadIdx.x; i < WS_BINS; i += WM_THREADS)
-        if (h[i]) atomicAdd(&bs->hist[i], h[i]);
-    K7_STAMP(1, 3);
+    K7_STAMP(1, 5);
     K7_EXIT(1);
 }
 
 template <int DT>
-__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const BracketGroup bg) {
+__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const BracketGroup bg,
+                                                                         const uint32_t* __restrict__ part) {
     const MatGroup& g = bg.m;
     const int it = group_item(g, blockIdx.x);
     const unsigned lb = blockIdx.x - g.start[it], nb = g.start[it + 1] - g.start[it];
     void* w = g.w[it];
-    const float* sq = g.sq[it];
     const int64_t rows = g.rows[it], cols = g.cols[it];
     const uint32_t rank0 = g.rank0[it];
     BracketState* bs = bg.bs[it];
@@ -2007,9 +2067,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
-    __shared__ uint32_t is_last;
-    __shared__ uint32_t arr[WS_CAP];
-    __shared__ uint32_t hsel[2048];
+    __shared__ uint32_t is_last, below_s, ln, lbase;
+    __shared__ __attribute__((aligned(16))) uint32_t arr[WS_CAP];   // (first the slots' sums, 8 x 512)
+    __shared__ __attribute__((aligned(16))) uint32_t hsel[4096];
     __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
     K7_ENTER(2); K7_STAMP(2, 0);
     if (!bs->valid) {
@@ -2017,17 +2077,79 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
         return;
     }
     const uint32_t lo = bs->lo, hi = bs->hi, shift = bs->shift;
-    const uint32_t below = bs->count_below;
-    const uint32_t c = threadIdx.x < WS_BINS ? bs->hist[threadIdx.x] : 0u;
-    sq = stage_sqrt(bg.sr[it], cols, sq_lds);
+    // Loads return in order, so the prologue's own loads go FIRST and the workgroup's share of W
+    // right behind them: the prologue then runs while W streams in.
+    // The matrix's counts: the sum of its workgroups' slots (L2-resident, 2 KB each)
+    const uint32_t* pp = part + (size_t)g.start[it] * WS_PART_WORDS;
+    // eight groups of 128 threads, 4 bins per thread, one slot per group at a time: 12 slots per
+    // group in flight, one latency for up to 96 workgroups (more: further rounds, still ahead of
+    // the W loads); the groups' sums meet in LDS
+    constexpr int PXG = WM_THREADS / (WS_BINS / 4), PXN = 12;
+    const unsigned grp = threadIdx.x / (WS_BINS / 4), b4 = (threadIdx.x % (WS_BINS / 4)) * 4u;
+    u32x4 px[PXN];
+#pragma unroll
+    for (int u = 0; u < PXN; ++u) {
+        const unsigned q = grp + (unsigned)PXG * u;
+        const u32x4 x = *(const u32x4*)(pp + (size_t)(q < nb ? q : nb - 1u) * WS_PART_WORDS + b4);
+        px[u] = q < nb ? x : u32x4{0u, 0u, 0u, 0u};
+    }
+    // one wave: the slots' counts below the bracket
+    const bool tb_wave = threadIdx.x >= WS_BINS && threadIdx.x < WS_BINS + 64;
+    uint32_t tb0 = 0, tb1 = 0;
+    if (tb_wave) {
+        const unsigned q0 = threadIdx.x - WS_BINS, q1 = q0 + 64u;
+        const uint32_t x0 = pp[(size_t)(q0 < nb ? q0 : nb - 1u) * WS_PART_WORDS + WS_BINS];
+        const uint32_t x1 = pp[(size_t)(q1 < nb ? q1 : nb - 1u) * WS_PART_WORDS + WS_BINS];
+        tb0 = q0 < nb ? x0 : 0u;
+        tb1 = q1 < nb ? x1 : 0u;
+    }
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    if (nb > (unsigned)(PXG * PXN)) {          // (rare: one matrix on more than 96 workgroups)
+        for (unsigned q = grp + (unsigned)(PXG * PXN); q < nb; q += PXG)
+            acc += *(const u32x4*)(pp + (size_t)q * WS_PART_WORDS + b4);
+        if (tb_wave)
+            for (unsigned q = threadIdx.x - WS_BINS + 128u; q < nb; q += 64u) tb0 += pp[(size_t)q * WS_PART_WORDS + WS_BINS];
+    }
+    const SqrtPre srp = stage_sqrt_issue(bg.sr[it], cols);
+    if (threadIdx.x == 0) ln = 0u;
+    lds_barrier();          // (every wave's prologue loads are queued before any wave's W loads)
+    const int64_t vpr = cols / N;
+    const int64_t nvec = rows * vpr;
+    const uint32_t nvec32 = (uint32_t)nvec, stride32 = nb * WM_THREADS;
+    const uint32_t vfirst32 = lb * WM_THREADS + threadIdx.x;
+    const int64_t stride = (int64_t)stride32, vfirst = (int64_t)vfirst32;
+    u32x4 cur[WS_PRE];
+#pragma unroll
+    for (int j = 0; j < WS_PRE; ++j) {
+        const uint32_t v = vfirst32 + j * stride32;
+        cur[j] = ld16(w, (int64_t)(v < nvec32 ? v : nvec32 - 1u));  // (clamped: no branch around a load)
+    }
+    {
+#pragma unroll
+        for (int u = 0; u < PXN; ++u) acc += px[u];
+        *(u32x4*)(arr + grp * WS_BINS + b4) = acc;
+    }
+    if (tb_wave) {
+        uint32_t tb = tb0 + tb1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tb += __shfl_xor(tb, off, 64);
+        if (threadIdx.x == WS_BINS) below_s = tb;
+    }
+    const float* sq = stage_sqrt_finish(srp, bg.sr[it], cols, sq_lds);      // (ends with a barrier)
+    uint32_t c = 0;
+    if (threadIdx.x < WS_BINS) {
+#pragma unroll
+        for (int u = 0; u < PXG; ++u) c += arr[u * WS_BINS + threadIdx.x];
+    }
+    const uint32_t below = below_s;
     uint32_t total;
-    const uint32_t incl = block_scan_wm(c, wave4, total);
+    const uint32_t incl = block_scan_wm<true>(c, wave4, total);
     const bool miss = rank0 <= below || rank0 - below > total;
     const uint32_t r = rank0 - below;
     if (threadIdx.x == 0) { out2[0] = 0xffffffffu; out2[1] = 0; }
-    __syncthreads();
+    lds_barrier();
     if (!miss && incl - c < r && r <= incl) { out2[0] = threadIdx.x; out2[1] = r - (incl - c); }
-    __syncthreads();
+    lds_barrier();
     const uint32_t bin = out2[0], rr = out2[1];
     uint64_t binhi64 = (uint64_t)lo + ((uint64_t)(bin + 1u) << shift);
     if (binhi64 > (uint64_t)hi) binhi64 = hi;
@@ -2039,80 +2161,109 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     const uint32_t binlo = lo + (bin << shift), binw = (uint32_t)binhi64 - binlo;
     K7_STAMP(2, 1);
     {
-        const int64_t vpr = cols / N;
-        const int64_t nvec = rows * vpr;
-        const int64_t stride = (int64_t)nb * WM_THREADS;
-        const uint32_t vpr32 = (uint32_t)vpr, step32 = (uint32_t)(stride % vpr);
-        uint32_t cv = (uint32_t)(((int64_t)lb * WM_THREADS + threadIdx.x) % vpr);
-        for (int64_t v0 = (int64_t)lb * WM_THREADS + threadIdx.x; v0 < nvec; v0 += stride * WM_UNROLL) {
-            u32x4 wv[WM_UNROLL];
+        const uint32_t vpr32 = (uint32_t)vpr, step32 = stride32 % vpr32;
+        uint32_t cv = vfirst32 % vpr32;
+        auto apply_vec = [&](const u32x4& x, int64_t v, int64_t c0) {
+            float f[N];
+            Vec<DT>::unpack(x, f);
+            uint32_t lo4 = 0, hi4 = 0;
+            bool any = false, open_any = false;
 #pragma unroll
-            for (int j = 0; j < WM_UNROLL; ++j)
-                if (v0 + j * stride < nvec) wv[j] = ld16(w, v0 + j * stride);
+            for (int q = 0; q < N / 4; ++q) {
+                const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
 #pragma unroll
-            for (int j = 0; j < WM_UNROLL; ++j) {
-                const int64_t v = v0 + j * stride;
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * q + i;
+                    const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __uint_as_float(s4[i]));
+                    const bool prune = b < binlo;
+                    open_any |= (b - binlo) < binw;          // (b < binlo wraps to a huge value)
+                    if (prune) { f[e] = 0.0f; any = true; }
+                    if (mask_out) {
+                        if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
+                        else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
+                    }
+                }
+            }
+            if (!open_any) {
+                if (any) st16(w, v, Vec<DT>::pack(f));
+                if (mask_out) {
+                    uint8_t* m = mask_out + v * N;
+                    *(uint32_t*)m = lo4;
+                    if (N == 8) *(uint32_t*)(m + 4) = hi4;
+                }
+            } else {
+                // a vector with an element of the threshold's bin (a few hundred per matrix):
+                // element stores only, and never the open element's own bytes (the last
+                // workgroup may write them).  Metrics again from the untouched vector.
+                float f0[N];
+                Vec<DT>::unpack(x, f0);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const int64_t idx = v * N + e;
+                    const uint32_t b = __float_as_uint(__builtin_fabsf(f0[e]) * sq[c0 + e]);
+                    if ((b - binlo) < binw) {
+                        // the workgroup's own list first (LDS; `hsel` is free until the settling):
+                        // one atomic per WORKGROUP at the memory side instead of one per element —
+                        // ~1000 returning atomics on one address were most of this pass's time
+                        const uint32_t ls = atomicAdd(&ln, 1u);
+                        if (ls < 2048u) { hsel[2 * ls] = (uint32_t)idx; hsel[2 * ls + 1] = b; continue; }
+                        const uint32_t slot = atomicAdd(&bs->list_count, 1u);
+                        if (slot < (uint32_t)WS_CAP) {
+                            __hip_atomic_store(&bs->list_idx[slot], (uint32_t)idx, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&bs->list_bits[slot], b, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        const bool prune = b < binlo;
+                        if (prune) Vec<DT>::store1(w, idx, 0.0f);
+                        if (mask_out) mask_out[idx] = prune ? 1 : 0;
+                    }
+                }
+            }
+        };
+        // the next WS_PRE loads in flight while the current vectors are decided and stored
+        const uint32_t wg_first = lb * WM_THREADS;              // (uniform: the loop's trip count)
+        for (uint32_t base = 0; wg_first + base < nvec32; base += WS_PRE * stride32) {
+            u32x4 nxt[WS_PRE];
+            const bool more = wg_first + base + WS_PRE * stride32 < nvec32;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < WS_PRE; ++j) {
+                    const uint32_t v = vfirst32 + base + (WS_PRE + j) * stride32;
+                    nxt[j] = ld16(w, (int64_t)(v < nvec32 ? v : nvec32 - 1u));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WS_PRE; ++j) {
                 const int64_t c0 = (int64_t)cv * N;
                 cv += step32;
                 if (cv >= vpr32) cv -= vpr32;
-                if (v >= nvec) continue;
-                float f[N];
-                Vec<DT>::unpack(wv[j], f);
-                uint32_t lo4 = 0, hi4 = 0;
-                bool any = false, open_any = false;
+                const uint32_t v = vfirst32 + base + j * stride32;
+                if (v < nvec32) apply_vec(cur[j], (int64_t)v, c0);
+            }
+            if (more) {
 #pragma unroll
-                for (int q = 0; q < N / 4; ++q) {
-                    const u32x4 s4 = ld_sq4(sq, c0 / 4 + q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = 4 * q + i;
-                        const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * __uint_as_float(s4[i]));
-                        const bool prune = b < binlo;
-                        open_any |= (b - binlo) < binw;          // (b < binlo wraps to a huge value)
-                        if (prune) { f[e] = 0.0f; any = true; }
-                        if (mask_out) {
-                            if (e < 4) lo4 |= (prune ? 1u : 0u) << (8 * e);
-                            else hi4 |= (prune ? 1u : 0u) << (8 * (e - 4));
-                        }
-                    }
-                }
-                if (!open_any) {
-                    if (any) st16(w, v, Vec<DT>::pack(f));
-                    if (mask_out) {
-                        uint8_t* m = mask_out + v * N;
-                        *(uint32_t*)m = lo4;
-                        if (N == 8) *(uint32_t*)(m + 4) = hi4;
-                    }
-                } else {
-                    // a vector with an element of the threshold's bin (a few hundred per matrix):
-                    // element stores only, and never the open element's own bytes (the last
-                    // workgroup may write them).  Metrics again from the untouched vector.
-                    float f0[N];
-                    Vec<DT>::unpack(wv[j], f0);
-#pragma unroll
-                    for (int e = 0; e < N; ++e) {
-                        const int64_t idx = v * N + e;
-                        const uint32_t b = __float_as_uint(__builtin_fabsf(f0[e]) * sq[c0 + e]);
-                        if ((b - binlo) < binw) {
-                            const uint32_t slot = atomicAdd(&bs->list_count, 1u);
-                            if (slot < (uint32_t)WS_CAP) {
-                                __hip_atomic_store(&bs->list_idx[slot], (uint32_t)idx, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(&bs->list_bits[slot], b, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        } else {
-                            const bool prune = b < binlo;
-                            if (prune) Vec<DT>::store1(w, idx, 0.0f);
-                            if (mask_out) mask_out[idx] = prune ? 1 : 0;
-                        }
-                    }
-                }
+                for (int j = 0; j < WS_PRE; ++j) cur[j] = nxt[j];
+            }
+        }
+    }
+    // ---- the workgroup's list joins the matrix's -------------------------------------------------
+    K7_STAMP(2, 2);
+    __syncthreads();
+    {
+        const uint32_t nl = ln < 2048u ? ln : 2048u;
+        if (threadIdx.x == 0) lbase = nl ? atomicAdd(&bs->list_count, nl) : 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nl; i += WM_THREADS) {
+            const uint32_t slot = lbase + i;
+            if (slot < (uint32_t)WS_CAP) {
+                __hip_atomic_store(&bs->list_idx[slot], hsel[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&bs->list_bits[slot], hsel[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     // ---- the last workgroup of this matrix settles the threshold's bin ----------------------
-    K7_STAMP(2, 2);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     K7_STAMP(2, 3);
@@ -2126,41 +2277,45 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     if (threadIdx.x == 0) atomicMin(&eco_k7_clk[3][14], wall_clock64());
 #endif
     const uint32_t n = __hip_atomic_load(&bs->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n > (uint32_t)WS_CAP || n < rr) {          // too crowded (ties): the host finishes this matrix
+    if (n > (uint32_t)WS_CAP || n < rr) {          // too crowded (ties): the fallback launch finishes this matrix
         if (threadIdx.x == 0) bs->fallback = 2u;
         return;
     }
+    // the list's metrics relative to the bin's low edge: all below binw <= 2^shift, so the rr-th
+    // smallest takes ceil(shift / 12) digit passes (one for the usual bin of <= 4096 bit patterns)
     for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS)
-        arr[i] = __hip_atomic_load(&bs->list_bits[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // rr-th smallest of arr[0..n): radix select, 11 + 11 + 10 bits
+        arr[i] = __hip_atomic_load(&bs->list_bits[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - binlo;
     uint32_t prefix = 0, remaining = rr;
+    const int passes = shift <= 12 ? 1 : (shift <= 24 ? 2 : 3);
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-        const int sh = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-        const uint32_t himask = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
-        const uint32_t dmask = pass == 2 ? 1023u : 2047u;
-        for (int i = threadIdx.x; i < 2048; i += WM_THREADS) hsel[i] = 0;
+    for (int pass = 3 - passes; pass < 3; ++pass) {
+        const int sh = pass == 0 ? 24 : (pass == 1 ? 12 : 0);
+        const uint32_t himask = pass == 0 ? 0u : (pass == 1 ? 0xff000000u : 0xfffff000u);
+        const uint32_t dmask = pass == 0 ? 255u : 4095u;
+        for (int i = threadIdx.x; i < 4096; i += WM_THREADS) hsel[i] = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS) {
             const uint32_t b = arr[i];
             if ((b & himask) == prefix) atomicAdd(&hsel[(b >> sh) & dmask], 1u);
         }
         __syncthreads();
-        const uint32_t c0 = hsel[2 * threadIdx.x], c1 = hsel[2 * threadIdx.x + 1];
+        const u32x4 c4 = *(const u32x4*)(hsel + 4 * threadIdx.x);
+        const uint32_t csum = c4[0] + c4[1] + c4[2] + c4[3];
         uint32_t tot;
-        const uint32_t inc = block_scan_wm(c0 + c1, wave4, tot);
-        const uint32_t exc = inc - (c0 + c1);
+        const uint32_t inc = block_scan_wm(csum, wave4, tot);
+        uint32_t exc = inc - csum;
         if (exc < remaining && remaining <= inc) {
-            const bool second = remaining > exc + c0;
-            out2[0] = 2 * threadIdx.x + (second ? 1u : 0u);
-            out2[1] = remaining - exc - (second ? c0 : 0u);
+            int d = 0;
+            while (remaining > exc + c4[d]) { exc += c4[d]; ++d; }
+            out2[0] = 4 * threadIdx.x + (uint32_t)d;
+            out2[1] = remaining - exc;
         }
         __syncthreads();
         prefix |= out2[0] << sh;
         remaining = out2[1];
         __syncthreads();
     }
-    const uint32_t thres = prefix;           // bits of sorted[k]
+    const uint32_t thres = prefix;           // sorted[k], relative to the bin's low edge
     for (uint32_t i = threadIdx.x; i < n; i += WM_THREADS) {
         const uint32_t idx = __hip_atomic_load(&bs->list_idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool prune = arr[i] <= thres;
@@ -2180,6 +2335,22 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
 // already zeroed lay below the threshold's bin and stays below it as a zero, so the order
 // statistic is unchanged.  Until round 5 this decision sat on the host: a flag read-back and a
 // stream round trip per call (105 us from the stream for 64 us of kernels).
+// how often the finish below actually ran, by reason (1: bracket miss / non-finite bin, 2: crowded
+// bin): read and cleared by ecoflap_wanda_fallback_counts (tests: ordinary data must not take it)
+__device__ unsigned int eco_k7_fallbacks[4];
+extern "C" int ecoflap_wanda_fallback_counts(unsigned int* out4, int reset) {
+    if (out4) {
+        const hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(eco_k7_fallbacks), sizeof(unsigned int) * 4);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (reset) {
+        const unsigned int z[4] = {0u, 0u, 0u, 0u};
+        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_fallbacks), z, sizeof(z));
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 template <int DT, int PASS>
 static __device__ __forceinline__ void fallback_hist_pass(const void* __restrict__ w, const float* sq,
                                                           int64_t nvec, uint32_t vpr32, uint32_t* h,
@@ -2214,6 +2385,7 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_fallback_kernel(const
     BracketState* bs = bg.bs[it];
     K7_ENTER(4); K7_EXIT(4);
     if (bs->fallback == 0u) return;              // settled by the sampled passes
+    if (threadIdx.x == 0) atomicAdd(&eco_k7_fallbacks[bs->fallback & 3u], 1u);
     constexpr int N = Vec<DT>::N;
     void* w = g.w[it];
     const int64_t rows = g.rows[it], cols = g.cols[it];
@@ -2266,13 +2438,16 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_fallback_kernel(const
     }
 }
 
+// the counting pass's slots, one per workgroup of a launch (matrix-mode groups run one after the
+// other on the stream and share them)
+#define WS_PART_BYTES ((size_t)(WM_TOTAL_WGS + WMAX) * WS_PART_WORDS * sizeof(uint32_t))
 static inline size_t sq_bytes(int64_t cols) { return (((size_t)cols * sizeof(float) + 255) / 256) * 256; }
 
 extern "C" size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols) {
     (void)rows;
     if (cols <= 0) return 0;
     // sqrt table (padded to 256 B) + matrix-mode selection states
-    return sq_bytes(cols) + sizeof(MatrixSelState) + sizeof(BracketState);
+    return sq_bytes(cols) + sizeof(MatrixSelState) + sizeof(BracketState) + WS_PART_BYTES;
 }
 
 extern "C" size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* items, int n_items) {
@@ -2281,7 +2456,7 @@ extern "C" size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* 
     for (int i = 0; i < n_items; ++i)
         if (items[i].cols > 0)
             total += sq_bytes(items[i].cols) + sizeof(MatrixSelState) + sizeof(BracketState);
-    return total;
+    return total ? total + WS_PART_BYTES : 0;
 }
 
 static inline bool item_vector_ok(const ecoflap_wanda_item& it, const float* sq) {
@@ -2336,6 +2511,7 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     }
     BracketState* bst[WMAX];
     for (int i = 0; i < n_items; ++i) { bst[i] = (BracketState*)p; p += sizeof(BracketState); }
+    uint32_t* part = (uint32_t*)p;
     // The sampled-bracket path (matrix-mode items big enough to sample one vector per stride; it
     // stages sqrt(scaler_row) itself and clears its own state): 2 reads + 1 write of W instead of
     // 4 + 1.  DEFAULT since round 5 — the matrices it cannot settle are finished by ONE conditional
@@ -2349,19 +2525,17 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
         const ecoflap_wanda_item& a = items[i];
         const int64_t nv = a.rows * a.cols / (a.dtype == ECOFLAP_F32 ? 4 : 8);
         sampled_item[i] = a.mode == ECOFLAP_WANDA_MATRIX && !force_legacy && item_vector_ok(a, sq[i]) &&
-                          nv >= 8 * WS_SAMPLE_VECS && a.cols <= WM_SQ_LDS &&
+                          nv >= 8 * WS_SAMPLE_VECS && a.cols <= WM_SQ_LDS && a.rows * a.cols <= WS_MAX_NUMEL &&
                           (((uintptr_t)a.scaler_row) & 15u) == 0;
     }
     auto launch_sqrt = [&](const bool* want) -> int {
         SqrtGroup g;
         g.n = n_items;
         g.zero_words = (int)(sizeof(MatrixSelState) / sizeof(uint32_t));
-        g.zero2_words = WS_ZERO_WORDS;
         g.start[0] = 0;
         for (int i = 0; i < n_items; ++i) {
             g.src[i] = items[i].scaler_row; g.dst[i] = sq[i]; g.cols[i] = items[i].cols;
             g.zero[i] = items[i].mode == ECOFLAP_WANDA_MATRIX ? (uint32_t*)st[i] : nullptr;
-            g.zero2[i] = nullptr;
             g.start[i + 1] = g.start[i] + (want[i] ? (int32_t)((items[i].cols + 255) / 256) : 0);
         }
         if (g.start[n_items] == 0) return 0;
@@ -2517,21 +2691,17 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
             ECO_CHECK_LAUNCH();
             continue;
         }
-        SampleGroup sg;
         BracketGroup bg;
         bg.m = g;
-        sg.n = g.n;
         for (int q = 0; q < g.n; ++q) {
-            const ecoflap_wanda_item& b = items[members[q]];
-            sg.w[q] = b.w; sg.scaler_row[q] = b.scaler_row; sg.rows[q] = b.rows; sg.cols[q] = b.cols;
-            sg.rank0[q] = g.rank0[q]; sg.bs[q] = bst[members[q]]; bg.bs[q] = bst[members[q]];
-            bg.sr[q] = b.scaler_row;
+            bg.bs[q] = bst[members[q]];
+            bg.sr[q] = items[members[q]].scaler_row;
         }
+        if ((size_t)g.start[g.n] > (size_t)(WM_TOTAL_WGS + WMAX)) return ECOFLAP_ESIZE;   // (cannot happen: see nb)
 #define MATRIX_GO(DT_)                                                                              \
     do {                                                                                            \
-        hipLaunchKernelGGL((wanda_matrix_sample_kernel<DT_>), dim3((unsigned)g.n), blk, 0, s, sg); \
-        hipLaunchKernelGGL((wanda_matrix_bracket_kernel<DT_>), grid, blk, 0, s, bg);                \
-        hipLaunchKernelGGL((wanda_matrix_apply2_kernel<DT_>), grid, blk, 0, s, bg);                 \
+        hipLaunchKernelGGL((wanda_matrix_sbracket_kernel<DT_>), grid, blk, 0, s, bg, part);         \
+        hipLaunchKernelGGL((wanda_matrix_apply2_kernel<DT_>), grid, blk, 0, s, bg, (const uint32_t*)part); \
     } while (0)
         DT_SWITCH(a.dtype, MATRIX_GO);
 #undef MATRIX_GO

@@ -30,7 +30,7 @@ EXPORTS = [
     "ecoflap_colsqnorm_multi_workspace_bytes", "ecoflap_colsqnorm_accum_multi", "ecoflap_colsq_replay",
     "ecoflap_wanda_workspace_bytes", "ecoflap_wanda_prune_rows",
     "ecoflap_wanda_prune_matrix", "ecoflap_wanda_prune_nm", "ecoflap_wanda_block_workspace_bytes",
-    "ecoflap_wanda_prune_block",
+    "ecoflap_wanda_prune_block", "ecoflap_wanda_fallback_counts",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block", "ecoflap_sparsegpt_block_nm",
     "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
@@ -120,6 +120,7 @@ def load_library():
     lib.ecoflap_wanda_block_workspace_bytes.restype = sz
     lib.ecoflap_wanda_block_workspace_bytes.argtypes = [vp, ci]
     lib.ecoflap_wanda_prune_block.argtypes = [vp, ci, vp, sz, vp]
+    lib.ecoflap_wanda_fallback_counts.argtypes = [vp, ci]
     lib.ecoflap_mask_mul.argtypes = [vp, vp, i64, ci, vp]
     lib.ecoflap_grad_accum_multi.argtypes = [vp, ci, vp]
     lib.ecoflap_global_prune_workspace_bytes.restype = sz
@@ -645,6 +646,13 @@ class HipKernels:
         _check(self.lib.ecoflap_wanda_prune_nm(_ptr(w), _ptr(scaler_row), rows, cols, DTYPE_CODE[w.dtype],
                                                int(n), int(m), _ptr(mask_out) if mask_out is not None else None,
                                                _stream()), "ecoflap_wanda_prune_nm")
+
+    def wanda_fallback_counts(self, reset=True):
+        """(bracket misses, crowded bins): matrices the matrix-mode selection handed to its exact
+        on-device fallback since the last reset (include/ecoflap_hip.h).  Synchronises."""
+        out = (ctypes.c_uint * 4)()
+        _check(self.lib.ecoflap_wanda_fallback_counts(out, 1 if reset else 0), "ecoflap_wanda_fallback_counts")
+        return int(out[1]) + int(out[3]), int(out[2])
 
     def wanda_prune_block(self, items):
         """items: [(w, scaler_row, mode, k, mask_out_or_None)], mode "rows" / "matrix": all

@@ -348,6 +348,12 @@ typedef struct ecoflap_wanda_item {
 size_t ecoflap_wanda_block_workspace_bytes(const ecoflap_wanda_item* items, int n_items);
 int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_items,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* Diagnostics of the matrix-mode selection: how many matrices since the last reset were finished by
+ * the exact on-device fallback instead of the sampled two-pass selection — out4[1]: the sample's
+ * bracket missed the threshold or its bin reaches non-finite bit patterns, out4[2]: the
+ * threshold's bin was too crowded (massive ties).  Results are identical either way; the fallback
+ * streams the matrix from one workgroup (~1 ms for 8 M elements).  Synchronises the device. */
+int ecoflap_wanda_fallback_counts(unsigned int* out4, int reset);
 
 /* ---------------------------------------------------------------------------
  * SparseGPT block step

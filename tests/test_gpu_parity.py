@@ -750,17 +750,17 @@ def test_wanda_full_size_properties(kern):
                                   "half_zero", "nan_column", "heavy_tail"])
 @pytest.mark.parametrize("path", ["sampled", "histograms"])
 def test_wanda_matrix_sampled_bracket_path_equals_sort(kern, dt, case, path, monkeypatch):
-    """Both matrix-mode selections (the default three histogram passes; ECOFLAP_WANDA_SAMPLED=1,
-    read at every call: the sampled bracket) on the same cases.
+    """Both matrix-mode selections (the default since round 5: the sampled bracket;
+    ECOFLAP_WANDA_SAMPLED=0, read at every call: the three histogram passes) on the same cases.
     Matrices big enough for the sampled-bracket selection (2 reads + 1 write) against the
     reference's own expression on the GPU (`thres = sort(metric.flatten())[k]; metric <= thres`,
     wanda_pruner.py:555-558): ordinary data, and the cases the pass flags and hands to the
     three-histogram path (massive ties, a threshold at zero, the extremes of k) or must keep out
     of the threshold (NaN metrics)."""
     if path == "sampled":
-        monkeypatch.setenv("ECOFLAP_WANDA_SAMPLED", "1")
-    else:
         monkeypatch.delenv("ECOFLAP_WANDA_SAMPLED", raising=False)
+    else:
+        monkeypatch.setenv("ECOFLAP_WANDA_SAMPLED", "0")
     rows, cols = 512, 1408
     g = torch.Generator(device="cuda").manual_seed(len(case) * 7 + 1)
     w = torch.randn(rows, cols, device="cuda", generator=g) * 0.02
@@ -785,9 +785,17 @@ def test_wanda_matrix_sampled_bracket_path_equals_sort(kern, dt, case, path, mon
     want = metric <= thres
     mask = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
     w2 = w.clone()
+    kern.wanda_fallback_counts()
     kern.wanda_prune_matrix(w2, s, k, mask)
+    fell_back = sum(kern.wanda_fallback_counts())
     assert torch.equal(mask.bool(), want), (case, int(mask.sum()), int(want.sum()))
     assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
+    if path == "histograms":
+        assert fell_back == 0                               # (that path has no fallback to take)
+    elif case.startswith("normal_") or case == "heavy_tail":
+        assert fell_back == 0, "ordinary data must be settled by the two sampled passes"
+    elif case == "half_zero":
+        assert fell_back == 1                               # half the matrix ties at the threshold
     # block call: the same matrix next to two others of other sizes, no mask
     w3 = w.clone()
     other = (torch.randn(1408, 1408, device="cuda", generator=g) * 0.02).to(dt)
@@ -914,10 +922,39 @@ def test_wanda_block_full_size_blocks_equal_single_calls(kern):
         for w, sr, k in zip(single, srs, ks):
             (kern.wanda_prune_rows if mode == "rows" else kern.wanda_prune_matrix)(w, sr, k)
         block = [w.clone() for w in ws]
+        kern.wanda_fallback_counts()
         kern.wanda_prune_block([(w, sr, mode, k, None) for w, sr, k in zip(block, srs, ks)])
         for a, b in zip(single, block):
             assert torch.equal(a, b)
             assert abs((b == 0).float().mean().item() - 0.5) < 0.01
+        if mode == "matrix":
+            # ordinary weights are settled by the two sampled passes; the exact fallback (one
+            # workgroup streaming a matrix, ~1 ms) is for misses and massive ties only
+            for rep in range(6):
+                more = [(torch.randn(r, c, device="cuda") * 0.02).to(dt) for r, c in shapes]
+                kern.wanda_prune_block([(w, sr, mode, k, None) for w, sr, k in zip(more, srs, ks)])
+            assert kern.wanda_fallback_counts() == (0, 0)
+
+
+@pytest.mark.parametrize("rows,cols,sampled", [(4096, 8192, True), (7168, 8192, False)])
+def test_wanda_matrix_large_matrices_equal_sort(kern, rows, cols, sampled):
+    """Matrix mode beyond BLIP-2's sizes: 33.5 M elements (the sampled two-pass selection, settled
+    without the fallback: the threshold bin's list and the per-workgroup slots at 4x the ViT-g
+    sizes) and 58.7 M (above WS_MAX_NUMEL: the three-histogram selection) against
+    `sort(metric.flatten())[k]; metric <= thres` (wanda_pruner.py:555-558)."""
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    w = (torch.randn(rows, cols, device="cuda", generator=g) * 0.02).half()
+    s = torch.rand(cols, device="cuda", generator=g) + 0.05
+    k = int(rows * cols * 0.6)
+    metric = w.abs().float() * torch.sqrt(s).reshape(1, -1)
+    thres = torch.sort(metric.flatten())[0][k]
+    want = metric <= thres
+    del metric
+    kern.wanda_fallback_counts()
+    w2 = w.clone()
+    kern.wanda_prune_matrix(w2, s, k)
+    assert kern.wanda_fallback_counts() == (0, 0)
+    assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
 
 
 # ------------------------------------------------------------------------------ K8

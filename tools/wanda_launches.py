@@ -110,18 +110,22 @@ def main():
         ks = [int((c if mode == "rows" else r * c) * 0.5) for r, c in shapes]
         fn = lambda i: kern.wanda_prune_block(                                   # noqa: E731
             [(w, sr, mode, k, None) for w, sr, k in zip(wsets[i], srs, ks)])
+        if mode == "matrix":
+            kern.wanda_fallback_counts()
         med, mn = timed(fn, sets, fresh=True)
+        if mode == "matrix":
+            name += "  [fallbacks (misses, crowded): %d, %d]" % kern.wanda_fallback_counts()
         res.append((f"K7 {mode} block", name, nbytes, med, mn))
         if mode == "matrix":
-            # the opt-in sampled-bracket selection (one stream round trip per call for its flag)
-            os.environ["ECOFLAP_WANDA_SAMPLED"] = "1"
+            # the three-histogram selection (4 reads + 1 write), for comparison
+            os.environ["ECOFLAP_WANDA_SAMPLED"] = "0"
             wsets2 = [[(torch.randn(r, c, device="cuda") * 0.02).to(dt) for r, c in shapes]
                       for _ in range(sets)]
             fn2 = lambda i: kern.wanda_prune_block(                              # noqa: E731
                 [(w, sr, mode, k, None) for w, sr, k in zip(wsets2[i], srs, ks)])
             med, mn = timed(fn2, sets, fresh=True)
             del os.environ["ECOFLAP_WANDA_SAMPLED"]
-            res.append((f"K7 {mode} block", name + " ECOFLAP_WANDA_SAMPLED=1", nbytes, med, mn))
+            res.append((f"K7 {mode} block", name + " ECOFLAP_WANDA_SAMPLED=0", nbytes, med, mn))
             del wsets2
         del wsets
     # SparseGPT Hessian (MFMA SYRK): flops against the dense fp16 / bf16 peak
