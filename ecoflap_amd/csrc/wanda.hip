@@ -1806,9 +1806,9 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply_kernel(const Ma
 // to a list; the last workgroup to finish selects the threshold among them exactly and settles
 // them.  Every count is exact, so the result is the reference's (W:555-558) bit for bit; when the
 // bracket misses (probability ~1e-6 per matrix), the bin is too crowded for the list (massive
-// ties) or the threshold is not finite, the pass flags the matrix WITHOUT having decided anything
-// wrongly (elements below the bin are pruned in the exact answer too) and one more workgroup per
-// matrix runs the three-histogram selection on it (wanda_matrix_fallback_kernel).
+// ties) or the threshold is not finite, every workgroup of the matrix sees that from the counts
+// before it has written anything, and the matrix's first workgroup runs the three-histogram
+// selection on it by itself (matrix_fallback_body).
 //
 // Round 5, after a phase clock on the device (tools/diag/k7_clock.py: sample 14.9 us alone on 4
 // workgroups, 1.6 us to the next launch, bracket pass 19 us of which 11 streaming, apply pass 21 us
@@ -2053,6 +2053,112 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_sbracket_kernel(const
     K7_EXIT(1);
 }
 
+// The exact finish for a matrix the sampled passes cannot settle (the bracket missed, ~1e-6 per
+// matrix; the threshold's bin reaches non-finite bit patterns; the bin is too crowded for the
+// list: massive ties), ON THE DEVICE and inside the apply pass: every one of these conditions is
+// known from the counts in the prologue, to every workgroup of the matrix alike, BEFORE anything
+// of W has been written — so all of them leave, and the matrix's first workgroup runs the whole
+// three-histogram selection and the apply pass by itself (LDS histograms, no other workgroup to
+// wait for: no grid barrier, nothing that could deadlock with another resident instance, and no
+// question of one XCD seeing another's stores).  Slow (one CU streams the matrix four times:
+// ~1 ms for 8.6 M elements) and rare.  Rounds 3-4 decided this on the host (a flag read-back and a
+// stream round trip per call), round 5 first by a conditional launch of its own (4 us at the end
+// of every call for a launch that almost never had anything to do).
+// How often it ran, by reason (1: bracket miss / non-finite bin, 2: crowded bin, 3: a list that
+// does not match its count — cannot happen, counted so that a test would see it): read and cleared
+// by ecoflap_wanda_fallback_counts (tests: ordinary data must not take it).
+__device__ unsigned int eco_k7_fallbacks[4];
+extern "C" int ecoflap_wanda_fallback_counts(unsigned int* out4, int reset) {
+    if (out4) {
+        const hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(eco_k7_fallbacks), sizeof(unsigned int) * 4);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (reset) {
+        const unsigned int z[4] = {0u, 0u, 0u, 0u};
+        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_fallbacks), z, sizeof(z));
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <int DT, int PASS>
+static __device__ __forceinline__ void fallback_hist_pass(const void* __restrict__ w, const float* sq,
+                                                          int64_t nvec, uint32_t vpr32, uint32_t* h,
+                                                          uint32_t prefix) {
+    constexpr int N = Vec<DT>::N;
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr uint32_t DMASK = PASS == 2 ? 1023u : 2047u;
+    constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
+    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) h[i] = 0;
+    __syncthreads();
+    uint32_t cv = threadIdx.x % vpr32;
+    const uint32_t step32 = WM_THREADS % vpr32;
+    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
+        const int64_t c0 = (int64_t)cv * N;
+        cv += step32;
+        if (cv >= vpr32) cv -= vpr32;
+        float f[N];
+        Vec<DT>::unpack(ld16(w, v), f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * sq[c0 + e]);
+            if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & DMASK], 1u);
+        }
+    }
+    __syncthreads();
+}
+
+// one workgroup, the whole matrix: h = 2048 words of LDS, sq = the staged sqrt table
+template <int DT>
+static __device__ void matrix_fallback_body(void* w, const float* sq, int64_t rows, int64_t cols, uint32_t rank0,
+                                            uint8_t* mask_out, uint32_t* h, uint32_t* wave4, uint32_t* out2,
+                                            unsigned reason) {
+    if (threadIdx.x == 0) atomicAdd(&eco_k7_fallbacks[reason & 3u], 1u);
+    constexpr int N = Vec<DT>::N;
+    const int64_t vpr = cols / N, nvec = rows * vpr;
+    const uint32_t vpr32 = (uint32_t)vpr;
+    uint32_t prefix = 0, remaining = rank0;
+    __syncthreads();
+    fallback_hist_pass<DT, 0>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0] << 21; remaining = out2[1];
+    __syncthreads();
+    fallback_hist_pass<DT, 1>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0] << 10; remaining = out2[1];
+    __syncthreads();
+    fallback_hist_pass<DT, 2>(w, sq, nvec, vpr32, h, prefix);
+    find_rank_wm(h, remaining, wave4, out2);
+    prefix |= out2[0];
+    __syncthreads();
+    const float thres = __uint_as_float(prefix);     // sorted[k]
+    uint32_t cv = threadIdx.x % vpr32;
+    const uint32_t step32 = WM_THREADS % vpr32;
+    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
+        const int64_t c0 = (int64_t)cv * N;
+        cv += step32;
+        if (cv >= vpr32) cv -= vpr32;
+        float f[N];
+        Vec<DT>::unpack(ld16(w, v), f);
+        uint32_t lo = 0, hi = 0;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            // W_metric <= thres (W:556): false for NaN metrics, as in torch
+            const bool prune = (__builtin_fabsf(f[e]) * sq[c0 + e]) <= thres;
+            if (prune) { f[e] = 0.0f; any = true; }
+            if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
+            else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
+        }
+        if (any) st16(w, v, Vec<DT>::pack(f));
+        if (mask_out) {
+            uint8_t* m = mask_out + v * N;
+            *(uint32_t*)m = lo;
+            if (N == 8) *(uint32_t*)(m + 4) = hi;
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const BracketGroup bg,
                                                                          const uint32_t* __restrict__ part) {
@@ -2067,13 +2173,16 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     constexpr int N = Vec<DT>::N;
     __shared__ uint32_t wave4[WM_WAVES];
     __shared__ uint32_t out2[2];
-    __shared__ uint32_t is_last, below_s, ln, lbase;
+    __shared__ uint32_t is_last, below_s, ln, lbase, binc_s;
     __shared__ __attribute__((aligned(16))) uint32_t arr[WS_CAP];   // (first the slots' sums, 8 x 512)
     __shared__ __attribute__((aligned(16))) uint32_t hsel[4096];
     __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
     K7_ENTER(2); K7_STAMP(2, 0);
-    if (!bs->valid) {
-        if (lb == 0 && threadIdx.x == 0) bs->fallback = 1u;
+    if (!bs->valid) {                          // (an empty bracket: cannot happen, handled all the same)
+        if (lb == 0) {
+            const float* sq0 = stage_sqrt(bg.sr[it], cols, sq_lds);
+            matrix_fallback_body<DT>(w, sq0, rows, cols, rank0, mask_out, hsel, wave4, out2, 1u);
+        }
         return;
     }
     const uint32_t lo = bs->lo, hi = bs->hi, shift = bs->shift;
@@ -2146,16 +2255,20 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     const uint32_t incl = block_scan_wm<true>(c, wave4, total);
     const bool miss = rank0 <= below || rank0 - below > total;
     const uint32_t r = rank0 - below;
-    if (threadIdx.x == 0) { out2[0] = 0xffffffffu; out2[1] = 0; }
+    if (threadIdx.x == 0) { out2[0] = 0xffffffffu; out2[1] = 0; binc_s = 0; }
     lds_barrier();
-    if (!miss && incl - c < r && r <= incl) { out2[0] = threadIdx.x; out2[1] = r - (incl - c); }
+    if (!miss && incl - c < r && r <= incl) { out2[0] = threadIdx.x; out2[1] = r - (incl - c); binc_s = c; }
     lds_barrier();
-    const uint32_t bin = out2[0], rr = out2[1];
+    const uint32_t bin = out2[0], rr = out2[1], binc = binc_s;
     uint64_t binhi64 = (uint64_t)lo + ((uint64_t)(bin + 1u) << shift);
     if (binhi64 > (uint64_t)hi) binhi64 = hi;
-    // (a bin reaching into Inf / NaN bit patterns: `metric <= thres` is not an order on bits there)
-    if (miss || bin == 0xffffffffu || binhi64 > 0x7f800000ull) {
-        if (lb == 0 && threadIdx.x == 0) bs->fallback = 1u;
+    // The cases the two passes cannot settle, known here to every workgroup of the matrix and
+    // before any of them has written a byte of W: the bracket missed, the threshold's bin reaches
+    // into Inf / NaN bit patterns (`metric <= thres` is not an order on bits there), the bin holds
+    // more elements than the list (massive ties).  All leave; the first runs the exact finish.
+    const bool unsettled = miss || bin == 0xffffffffu || binhi64 > 0x7f800000ull;
+    if (unsettled || binc > (uint32_t)WS_CAP) {
+        if (lb == 0) matrix_fallback_body<DT>(w, sq, rows, cols, rank0, mask_out, hsel, wave4, out2, unsettled ? 1u : 2u);
         return;
     }
     const uint32_t binlo = lo + (bin << shift), binw = (uint32_t)binhi64 - binlo;
@@ -2277,8 +2390,8 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
     if (threadIdx.x == 0) atomicMin(&eco_k7_clk[3][14], wall_clock64());
 #endif
     const uint32_t n = __hip_atomic_load(&bs->list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n > (uint32_t)WS_CAP || n < rr) {          // too crowded (ties): the fallback launch finishes this matrix
-        if (threadIdx.x == 0) bs->fallback = 2u;
+    if (n != binc) {       // every element of the bin is appended exactly once: cannot happen; counted, never silent
+        if (threadIdx.x == 0) { bs->fallback = 3u; atomicAdd(&eco_k7_fallbacks[3], 1u); }
         return;
     }
     // the list's metrics relative to the bin's low edge: all below binw <= 2^shift, so the rr-th
@@ -2323,119 +2436,6 @@ __global__ __launch_bounds__(WM_THREADS) void wanda_matrix_apply2_kernel(const B
         if (mask_out) mask_out[idx] = prune ? 1 : 0;
     }
     K7_EXIT(3);
-}
-
-// The exact finish for a matrix the sampled passes could not settle (bracket miss ~1e-6 per
-// matrix, a threshold bin crowded by massive ties, a non-finite threshold), ON THE DEVICE: one
-// conditional launch, one workgroup per matrix, which leaves at once when `fallback` is 0 — the
-// usual case costs the launch of 4 idle workgroups — and otherwise runs the whole three-histogram
-// selection and the apply pass by itself (LDS histograms, no other workgroup to wait for: no
-// grid barrier, nothing that could deadlock with another resident instance).  Slow (one CU
-// streams the matrix four times: ~1 ms for 8.6 M elements) and rare; what the apply2 pass has
-// already zeroed lay below the threshold's bin and stays below it as a zero, so the order
-// statistic is unchanged.  Until round 5 this decision sat on the host: a flag read-back and a
-// stream round trip per call (105 us from the stream for 64 us of kernels).
-// how often the finish below actually ran, by reason (1: bracket miss / non-finite bin, 2: crowded
-// bin): read and cleared by ecoflap_wanda_fallback_counts (tests: ordinary data must not take it)
-__device__ unsigned int eco_k7_fallbacks[4];
-extern "C" int ecoflap_wanda_fallback_counts(unsigned int* out4, int reset) {
-    if (out4) {
-        const hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(eco_k7_fallbacks), sizeof(unsigned int) * 4);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (reset) {
-        const unsigned int z[4] = {0u, 0u, 0u, 0u};
-        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_fallbacks), z, sizeof(z));
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
-
-template <int DT, int PASS>
-static __device__ __forceinline__ void fallback_hist_pass(const void* __restrict__ w, const float* sq,
-                                                          int64_t nvec, uint32_t vpr32, uint32_t* h,
-                                                          uint32_t prefix) {
-    constexpr int N = Vec<DT>::N;
-    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
-    constexpr uint32_t DMASK = PASS == 2 ? 1023u : 2047u;
-    constexpr uint32_t HI_MASK = PASS == 0 ? 0u : (PASS == 1 ? 0xffe00000u : 0xfffffc00u);
-    for (int i = threadIdx.x; i < 2048; i += WM_THREADS) h[i] = 0;
-    __syncthreads();
-    uint32_t cv = threadIdx.x % vpr32;
-    const uint32_t step32 = WM_THREADS % vpr32;
-    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
-        const int64_t c0 = (int64_t)cv * N;
-        cv += step32;
-        if (cv >= vpr32) cv -= vpr32;
-        float f[N];
-        Vec<DT>::unpack(ld16(w, v), f);
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const uint32_t b = __float_as_uint(__builtin_fabsf(f[e]) * sq[c0 + e]);
-            if ((b & HI_MASK) == prefix) atomicAdd(&h[(b >> SHIFT) & DMASK], 1u);
-        }
-    }
-    __syncthreads();
-}
-
-template <int DT>
-__global__ __launch_bounds__(WM_THREADS) void wanda_matrix_fallback_kernel(const BracketGroup bg) {
-    const MatGroup& g = bg.m;
-    const int it = blockIdx.x;                   // one workgroup per matrix
-    BracketState* bs = bg.bs[it];
-    K7_ENTER(4); K7_EXIT(4);
-    if (bs->fallback == 0u) return;              // settled by the sampled passes
-    if (threadIdx.x == 0) atomicAdd(&eco_k7_fallbacks[bs->fallback & 3u], 1u);
-    constexpr int N = Vec<DT>::N;
-    void* w = g.w[it];
-    const int64_t rows = g.rows[it], cols = g.cols[it];
-    uint8_t* mask_out = g.mask[it];
-    __shared__ uint32_t h[2048];
-    __shared__ uint32_t wave4[WM_WAVES];
-    __shared__ uint32_t out2[2];
-    __shared__ __attribute__((aligned(16))) float sq_lds[WM_SQ_LDS];
-    const float* sq = stage_sqrt(bg.sr[it], cols, sq_lds);
-    const int64_t vpr = cols / N, nvec = rows * vpr;
-    const uint32_t vpr32 = (uint32_t)vpr;
-    uint32_t prefix = 0, remaining = g.rank0[it];
-    fallback_hist_pass<DT, 0>(w, sq, nvec, vpr32, h, prefix);
-    find_rank_wm(h, remaining, wave4, out2);
-    prefix |= out2[0] << 21; remaining = out2[1];
-    __syncthreads();
-    fallback_hist_pass<DT, 1>(w, sq, nvec, vpr32, h, prefix);
-    find_rank_wm(h, remaining, wave4, out2);
-    prefix |= out2[0] << 10; remaining = out2[1];
-    __syncthreads();
-    fallback_hist_pass<DT, 2>(w, sq, nvec, vpr32, h, prefix);
-    find_rank_wm(h, remaining, wave4, out2);
-    prefix |= out2[0];
-    __syncthreads();
-    const float thres = __uint_as_float(prefix);     // sorted[k]
-    uint32_t cv = threadIdx.x % vpr32;
-    const uint32_t step32 = WM_THREADS % vpr32;
-    for (int64_t v = threadIdx.x; v < nvec; v += WM_THREADS) {
-        const int64_t c0 = (int64_t)cv * N;
-        cv += step32;
-        if (cv >= vpr32) cv -= vpr32;
-        float f[N];
-        Vec<DT>::unpack(ld16(w, v), f);
-        uint32_t lo = 0, hi = 0;
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-            // W_metric <= thres (W:556): false for NaN metrics, as in torch
-            const bool prune = (__builtin_fabsf(f[e]) * sq[c0 + e]) <= thres;
-            if (prune) { f[e] = 0.0f; any = true; }
-            if (e < 4) lo |= (prune ? 1u : 0u) << (8 * e);
-            else hi |= (prune ? 1u : 0u) << (8 * (e - 4));
-        }
-        if (any) st16(w, v, Vec<DT>::pack(f));
-        if (mask_out) {
-            uint8_t* m = mask_out + v * N;
-            *(uint32_t*)m = lo;
-            if (N == 8) *(uint32_t*)(m + 4) = hi;
-        }
-    }
 }
 
 // the counting pass's slots, one per workgroup of a launch (matrix-mode groups run one after the
@@ -2514,9 +2514,9 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     uint32_t* part = (uint32_t*)p;
     // The sampled-bracket path (matrix-mode items big enough to sample one vector per stride; it
     // stages sqrt(scaler_row) itself and clears its own state): 2 reads + 1 write of W instead of
-    // 4 + 1.  DEFAULT since round 5 — the matrices it cannot settle are finished by ONE conditional
-    // launch on the device (`wanda_matrix_fallback_kernel`), no flag crosses to the host and the
-    // call stays asynchronous.  ECOFLAP_WANDA_SAMPLED=0 (read at every call) selects the
+    // 4 + 1, in two launches.  DEFAULT since round 5 — the matrices it cannot settle are finished
+    // exactly inside the second launch (`matrix_fallback_body`), no flag crosses to the host and
+    // the call stays asynchronous.  ECOFLAP_WANDA_SAMPLED=0 (read at every call) selects the
     // three-histogram path for every matrix.
     const char* sampled_env = getenv("ECOFLAP_WANDA_SAMPLED");
     const bool force_legacy = sampled_env != nullptr && sampled_env[0] == '0';
@@ -2705,13 +2705,6 @@ extern "C" int ecoflap_wanda_prune_block(const ecoflap_wanda_item* items, int n_
     } while (0)
         DT_SWITCH(a.dtype, MATRIX_GO);
 #undef MATRIX_GO
-        ECO_CHECK_LAUNCH();
-        // every count above is exact; a matrix the pass could not settle (bracket miss, a crowded
-        // threshold bin, a non-finite threshold) carries a flag and nothing wrongly decided: one
-        // workgroup per matrix looks at its flag and, if set, finishes the matrix exactly by itself
-#define FALLBACK_GO(DT_) hipLaunchKernelGGL((wanda_matrix_fallback_kernel<DT_>), dim3((unsigned)g.n), blk, 0, s, bg)
-        DT_SWITCH(a.dtype, FALLBACK_GO);
-#undef FALLBACK_GO
         ECO_CHECK_LAUNCH();
 #undef MATRIX_LEGACY
     }

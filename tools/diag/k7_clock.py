@@ -47,7 +47,7 @@ def main():
     us = lambda t: t / 100.0                                                       # noqa: E731
     print(f"events: median {statistics.median(t for t, _ in rows):.1f} us per call")
     t0 = lambda c: c[1][14]                                                        # noqa: E731
-    names = [None, "sample + bracket", "apply2", "apply2 last workgroups", "fallback"]
+    names = [None, "sample + bracket", "apply2", "apply2 last workgroups"]
     for k, n in enumerate(names):
         if n is None:
             continue
