@@ -297,15 +297,16 @@ int ecoflap_colsq_replay(float* scaler_row, const float* sq, const int64_t* batc
  *                                                   wanda_pruner.py:555-558
  * mask_out (optional): uint8[rows*cols], 1 where zeroed.
  * ------------------------------------------------------------------------- */
-/* Matrix mode: three histogram passes (11 + 11 + 10 bits) for the k-th order statistic, then
- * `metric <= thres`; asynchronous, graph-capturable.  With ECOFLAP_WANDA_SAMPLED=1 in the
- * environment (read at every call) big matrices take a sampled-bracket selection instead (2 reads
- * + 1 write of W: a sample brackets the threshold, one pass counts below / histograms inside the
- * bracket, the apply pass settles all but the threshold bin's few hundred elements, which its last
- * workgroup sorts; every count exact; a matrix the pass cannot settle — bracket miss, massive
- * ties, non-finite threshold — is flagged and finished by the three-histogram path).  That flag is
- * read on the host: ONE stream synchronisation per call, which costs more than the saved pass
- *  — hence opt-in. */
+/* Matrix mode, asynchronous and graph-capturable.  Matrices of 16384 .. 48 Mi 16-byte-aligned vectors'
+ * worth of elements take the sampled-bracket selection (2 reads + 1 write of W in two launches: a
+ * sample taken by every workgroup of the counting pass brackets the threshold, the pass counts
+ * below / histograms inside the bracket exactly, the apply pass settles all but the threshold bin's
+ * ~1000 elements, which its last workgroup sorts; every count exact; a matrix the passes cannot
+ * settle — bracket miss, massive ties, non-finite threshold — is finished exactly by one workgroup
+ * inside the apply pass, see ecoflap_wanda_fallback_counts).  Others, and every matrix when
+ * ECOFLAP_WANDA_SAMPLED=0 is in the environment (read at every call): three histogram passes
+ * (11 + 11 + 10 bits) for the k-th order statistic, then `metric <= thres`.  Same result, bit for
+ * bit, either way. */
 size_t ecoflap_wanda_workspace_bytes(int64_t rows, int64_t cols);
 int ecoflap_wanda_prune_rows(void* w, const float* scaler_row, int64_t rows,
                              int64_t cols, int dtype, int64_t k,
