@@ -31,7 +31,7 @@ def timed(fn, n_sets, reps=3, fresh=False):
 
 
 def main():
-    # --only k6,rows,matrix,syrk: sections to run (default all)
+    # --only k6,rows,matrix,syrk,matrixblock,rowsblock: sections to run (default all)
     only = None
     if "--only" in sys.argv:
         only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
@@ -99,7 +99,7 @@ def main():
               ("t5 decoder block (11 bf16)", "rows", torch.bfloat16,
                [(2048, 2048)] * 8 + [(5120, 2048)] * 2 + [(2048, 5120)])]
     for name, mode, dt, shapes in blocks:
-        if not want(mode):
+        if not (want(mode) or want(mode + "block")):      # --only matrixblock: the block call alone
             continue
         es = 2
         nbytes = sum(2 * es * r * c + 4 * c for r, c in shapes)
