@@ -20,8 +20,11 @@ def timed(fn, n_sets, reps=3, fresh=False):
     torch.cuda.synchronize()
     out = []
     for _ in range(1 if fresh else reps):
-        torch.cuda._sleep(2000000)     # keeps the stream busy while the host enqueues (no GEMMs:
-        evs = []                       # they would pull the clock down for what follows)
+        # keeps the stream busy while the host enqueues (no GEMMs: they would pull the clock down
+        # for what follows); ~100 us per call, or a cheap call with many arguments (the FlanT5
+        # decoder block's 11 K6 inputs: 7 us of kernel, 30 us of Python) reads as the host's time
+        torch.cuda._sleep(max(2000000, 240000 * n_sets))
+        evs = []
         for i in range(1 if fresh else 0, n_sets):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); fn(i); e.record(); evs.append((s, e))
