@@ -42,9 +42,6 @@ struct ColsqArgs {
     int small;               // 1: few rows — one workgroup per 64 columns reduces ALL rows (colsq_small_body)
 };
 
-#ifndef COLSQ_DEPTH
-#define COLSQ_DEPTH 8
-#endif
 // the work of workgroup (bx = column block, by = row chunk) of one hooked input
 template <int DT, bool VECTOR>
 __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, const int by,
@@ -62,25 +59,8 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.f;
     if (cvec < ncvec) {
-        // COLSQ_DEPTH independent 16-byte loads in flight per lane before the first use (a workgroup
-        // streams 64+ rows of 1 KB per wave: with two waves per SIMD on the chip the reduction is
-        // bound by how much it keeps in flight, not by HBM); squares added in row order, as the
-        // one-row-at-a-time loop below adds them
+        // four independent 16-byte loads in flight per lane before the first use
         int64_t r = r0 + wave;
-        if (VECTOR) {
-            for (; r + 4 * (COLSQ_DEPTH - 1) < r1; r += 4 * COLSQ_DEPTH) {
-                u32x4 v[COLSQ_DEPTH];
-#pragma unroll
-                for (int j = 0; j < COLSQ_DEPTH; ++j) v[j] = ld16(x, (r + 4 * j) * ncvec + cvec);
-#pragma unroll
-                for (int j = 0; j < COLSQ_DEPTH; ++j) {
-                    float f[N];
-                    Vec<DT>::unpack(v[j], f);
-#pragma unroll
-                    for (int i = 0; i < N; ++i) acc[i] += f[i] * f[i];
-                }
-            }
-        }
         for (; r + 12 < r1; r += 16) {
             float f0[N], f1[N], f2[N], f3[N];
             if (VECTOR) {
