@@ -17,6 +17,28 @@
 
 // =====================================================================================
 // K6  column sum of squares -> running mean
+// Phase clock for the K6 / K7 matrix-mode kernels, compiled in only by tools/diag/k7_clock.sh
+// (-DECO_K7_CLOCK, its own .so): workgroup 0 stamps the 100 MHz wall clock at its phase boundaries,
+// every workgroup folds its entry / exit into a min / max.
+#ifdef ECO_K7_CLOCK
+__device__ unsigned long long eco_k7_clk[8][16];
+#define K7_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) eco_k7_clk[k][i] = wall_clock64(); } while (0)
+#define K7_ENTER(k) do { if (threadIdx.x == 0) atomicMin(&eco_k7_clk[k][14], wall_clock64()); } while (0)
+#define K7_EXIT(k) do { if (threadIdx.x == 0) atomicMax(&eco_k7_clk[k][15], wall_clock64()); } while (0)
+extern "C" int ecoflap_debug_k7_clock_reset(void) {
+    unsigned long long z[8][16];
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 16; ++i) z[k][i] = i == 14 ? ~0ull : 0ull;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_clk), z, sizeof(z));
+}
+extern "C" int ecoflap_debug_k7_clock_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eco_k7_clk), sizeof(unsigned long long) * 8 * 16);
+}
+#else
+#define K7_STAMP(k, i) do { } while (0)
+#define K7_ENTER(k) do { } while (0)
+#define K7_EXIT(k) do { } while (0)
+#endif
+
 // =====================================================================================
 // ONE launch per hooked input.  Workgroup (column block, row chunk) writes
 // partial[chunk][col] = sum over the chunk's rows of x^2 (fp32); the LAST chunk of a column block
@@ -58,6 +80,7 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
     float acc[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    K7_ENTER(5); K7_STAMP(5, 0);
     if (cvec < ncvec) {
         // four independent 16-byte loads in flight per lane before the first use
         int64_t r = r0 + wave;
@@ -93,6 +116,7 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
             for (int i = 0; i < N; ++i) acc[i] += f[i] * f[i];
         }
     }
+    K7_STAMP(5, 1);
 #pragma unroll
     for (int i = 0; i < N; ++i) lds[wave][lane * N + i] = acc[i];
     __syncthreads();
@@ -111,11 +135,17 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
     // ---- last chunk of this column block finishes the update ------------------------------
     __builtin_amdgcn_s_waitcnt(0);         // this wave's partial stores have been performed
     __syncthreads();
+    K7_STAMP(5, 2);
     if (threadIdx.x == 0)
         *last = (__hip_atomic_fetch_add(&a.tickets[bx], 1u, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.nchunks - 1u);
     __syncthreads();
+    K7_STAMP(5, 3);
+    K7_EXIT(5);
     if (!*last) return;
+#ifdef ECO_K7_CLOCK
+    if (threadIdx.x == 0) { atomicMin(&eco_k7_clk[6][14], wall_clock64()); }
+#endif
     float decay = a.decay, n_new = a.n_new;
     if (a.n_dev) {                         // formed as the host form does (double, then float)
         const int64_t n0 = a.n_dev[0];
@@ -150,6 +180,7 @@ __device__ __forceinline__ void colsq_body(const ColsqArgs& a, const int bx, con
     // every wave of this workgroup has read n_dev (and used it) before thread 0 takes the
     // grid-level ticket: the workgroup that takes the LAST one bumps the count
     __syncthreads();
+    K7_EXIT(6);
     if (threadIdx.x == 0) {
         __hip_atomic_store(&a.tickets[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.n_dev) {                     // every column block has read n_dev before its ticket
@@ -1448,28 +1479,6 @@ static void launch_rows_reg(const RowsGroup& g, int nv, hipStream_t s) {
 // K7 matrix mode: global (k+1)-th smallest over rows*cols by 3 histogram passes
 // (11 + 11 + 10 bits), then zero metric <= threshold.
 // =====================================================================================
-// Phase clock for the matrix-mode kernels, compiled in only by tools/diag/k7_clock.sh
-// (-DECO_K7_CLOCK, its own .so): workgroup 0 stamps the 100 MHz wall clock at its phase boundaries,
-// every workgroup folds its entry / exit into a min / max.
-#ifdef ECO_K7_CLOCK
-__device__ unsigned long long eco_k7_clk[8][16];
-#define K7_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) eco_k7_clk[k][i] = wall_clock64(); } while (0)
-#define K7_ENTER(k) do { if (threadIdx.x == 0) atomicMin(&eco_k7_clk[k][14], wall_clock64()); } while (0)
-#define K7_EXIT(k) do { if (threadIdx.x == 0) atomicMax(&eco_k7_clk[k][15], wall_clock64()); } while (0)
-extern "C" int ecoflap_debug_k7_clock_reset(void) {
-    unsigned long long z[8][16];
-    for (int k = 0; k < 8; ++k) for (int i = 0; i < 16; ++i) z[k][i] = i == 14 ? ~0ull : 0ull;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eco_k7_clk), z, sizeof(z));
-}
-extern "C" int ecoflap_debug_k7_clock_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eco_k7_clk), sizeof(unsigned long long) * 8 * 16);
-}
-#else
-#define K7_STAMP(k, i) do { } while (0)
-#define K7_ENTER(k) do { } while (0)
-#define K7_EXIT(k) do { } while (0)
-#endif
-
 struct MatrixSelState {
     uint32_t hist[3][2048];
     uint32_t resolved[3][2];      // (prefix, remaining rank) after pass 1, 2, 3
