@@ -22,3 +22,14 @@ def to_bits(t):
         return t.view(torch.int16).numpy()
     return t.numpy()
 
+
+def free_port():
+    """A TCP port nobody holds right now, from the kernel (bind to 0).  The rendezvous ports of the
+    multi-process tests used to be computed from the pid inside 33500-42500, i.e. inside Linux's
+    ephemeral range: any outgoing connection of any process on the box — the previous test's gloo
+    pairs in TIME_WAIT included — could be sitting on one, and the run then failed in the
+    TCPStore's bind."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

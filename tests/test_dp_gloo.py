@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import free_port  # noqa: E402
 
 
 def _run_case(method, k1_form, rank, world, cached, n_samples=8, batch=2, checkpoint=None, die_after=None):
@@ -73,7 +74,7 @@ def _worker(rank, world, port, method, k1_form, cached, out_dir, n_samples=8, ba
     ("MEZO-GradMagAbs_sum", "units", True), ("GradMagAbs_sum", "units", False)])
 def test_two_ranks_reproduce_single_process(tmp_path, method, k1_form, cached):
     single = _run_case(method, k1_form, 0, 1, cached)
-    port = 29500 + (os.getpid() + hash((method, k1_form))) % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, method, k1_form, cached, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         sp, table, weights, sums, stats = torch.load(tmp_path / f"rank{r}.pt", weights_only=False)
@@ -99,7 +100,7 @@ def test_two_ranks_resume_from_their_own_checkpoints(tmp_path):
     method, k1_form = "MEZO-GradOnly_sum", "units"
     single = _run_case(method, k1_form, 0, 1, False)
     ck = str(tmp_path / "stage1.npz")
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     # 4 batches over 2 ranks = 2 losses pairs per layer and rank -> 4 loss calls per layer
     mp.spawn(_worker, args=(2, port, method, k1_form, False, str(tmp_path), 8, 2, ck, (4 * 7 + 1, 4 * 4 + 2)),
              nprocs=2, join=True)
@@ -124,7 +125,7 @@ def test_uneven_shards_and_more_ranks_reproduce_single_process(tmp_path, world, 
                                                                k1_form):
     method = "MEZO-GradOnly_sum"
     single = _run_case(method, k1_form, 0, 1, False, n_samples, batch)
-    port = 35500 + (os.getpid() + 7 * world + n_samples) % 2000
+    port = free_port()
     mp.spawn(_worker, args=(world, port, method, k1_form, False, str(tmp_path), n_samples, batch),
              nprocs=world, join=True)
     n_forward = 0
@@ -178,7 +179,7 @@ def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
     every rank: both replicas AND the one-process run end with the same pruned state_dict,
     bit for bit."""
     single_table, single_w = _run_wanda(0, 1)
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_wanda_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t0, w0 = torch.load(tmp_path / "w0.pt", weights_only=False)
     t1, w1 = torch.load(tmp_path / "w1.pt", weights_only=False)
@@ -193,7 +194,7 @@ def test_two_ranks_full_pruner_stage1_and_wanda(tmp_path):
 def test_three_ranks_uneven_shards_wanda_equals_one_process(tmp_path):
     """4 calibration batches over 3 ranks (2 + 1 + 1): same pruned state_dict as one process."""
     single_table, single_w = _run_wanda(0, 1)
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_wanda_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     for r in range(3):
         t, w = torch.load(tmp_path / f"w{r}.pt", weights_only=False)
@@ -238,7 +239,7 @@ def test_real_two_ranks_agree_and_track_single_process(tmp_path):
     sums -> identical thresholds and tables; vs the single process the fp32 batch sums
     re-associate, which can move elements that tie at the threshold only."""
     single, _ = _run_real(0, 1)
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_real_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, st0 = torch.load(tmp_path / "real0.pt", weights_only=False)
     r1, st1 = torch.load(tmp_path / "real1.pt", weights_only=False)
@@ -301,7 +302,7 @@ def test_two_ranks_sparsegpt_hessian_allreduce(tmp_path):
     count-weighted Hessians per block -> both replicas hold identical pruned weights; against one
     process the Hessian sums re-associate, so the OBS result agrees to rounding."""
     single, h_single = _run_sparsegpt(0, 1)
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     mp.spawn(_sparsegpt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     w0, h0 = torch.load(tmp_path / "s0.pt", weights_only=False)
     w1, h1 = torch.load(tmp_path / "s1.pt", weights_only=False)

@@ -28,6 +28,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import free_port  # noqa: E402
 
 N_SAMPLES, BATCH = 16, 2          # 8 calibration batches: 4+4, 3+3+2, one per rank at world 8
 
@@ -170,9 +171,6 @@ def _worker(rank, world, port, job, kwargs, out_dir, transport="gloo"):
         dist.destroy_process_group()
 
 
-_port = [41000 + os.getpid() % 1500]
-
-
 TRANSPORTS = ["gloo", "nccl"]
 
 
@@ -186,14 +184,12 @@ def _launch(tmp_path, world, job, transport="gloo", **kwargs):
     well: every run starts from a fresh process, like the ranks — the test process may carry GEMM
     plans and probes of earlier tests (shapes/fused.py decides per process, when a weight shape
     first comes up, whether the library's choice is batch invariant for it)."""
-    _port[0] += 7
     _needs(transport, world)
-    mp.spawn(_worker, args=(world, _port[0], job, kwargs, str(tmp_path), transport), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), job, kwargs, str(tmp_path), transport), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(world)]
     one = tmp_path / "one_process"
     one.mkdir(exist_ok=True)
-    _port[0] += 7
-    mp.spawn(_worker, args=(1, _port[0], job, kwargs, str(one), "gloo"), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, free_port(), job, kwargs, str(one), "gloo"), nprocs=1, join=True)
     return ranks, torch.load(one / "r0.pt", weights_only=False)
 
 
