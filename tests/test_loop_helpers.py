@@ -635,3 +635,77 @@ def test_unstaged_single_tower_pruners_equal_their_staged_runs(name):
                 assert torch.equal(got[1][k], staged[1][k]), (eb, k)
             sf = got[2]["stage1"]["suffix_forward"]
             assert sf["events_served"] > 0 and (sf.get("lockstep_evals", 0) > 0) == (eb > 1), sf
+
+
+def test_lock_step_shares_blocks_that_return_key_value_tuples_and_a_broadcast_bias():
+    """The block interface of the T5 the reference vendors (LAVIS modeling_t5.py, old-HF style):
+    a block returns `(hidden, (key, value), position_bias)`, the first block makes the
+    position bias ([1, heads, S, S]: one for the whole batch) and every later block receives it,
+    the stack keeps the key / value tuples.  Nested tuples of batch-leading tensors plus one tensor
+    shared by value: the blocks behind the owner are wired and run once per chunk, losses equal
+    the plain forwards bit for bit."""
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Block(torch.nn.Module):
+        def __init__(self, first):
+            super().__init__()
+            self.q, self.k, self.v, self.o = (torch.nn.Linear(8, 8, bias=False) for _ in range(4))
+            self.bias_table = torch.nn.Parameter(torch.randn(2, 5, 5) * 0.1) if first else None
+
+        def forward(self, hidden, position_bias=None, use_cache=True):
+            B, S, _ = hidden.shape
+            sp = lambda t: t.view(B, S, 2, 4).transpose(1, 2)                       # noqa: E731
+            q, k, v = sp(self.q(hidden)), sp(self.k(hidden)), sp(self.v(hidden))
+            if position_bias is None:
+                position_bias = self.bias_table.unsqueeze(0)                            # [1, heads, S, S]
+            a = torch.softmax(q @ k.transpose(-1, -2) + position_bias, -1) @ v
+            hidden = hidden + self.o(a.transpose(1, 2).reshape(B, S, 8))
+            return (hidden, (k, v) if use_cache else None, position_bias)
+
+    class Stack(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.block = torch.nn.ModuleList([Block(i == 0) for i in range(4)])
+            self.head = torch.nn.Linear(8, 3)
+
+        def forward(self, batch):
+            hidden, bias, present = batch["x"], None, ()
+            for blk in self.block:
+                hidden, kv, bias = blk(hidden, position_bias=bias, use_cache=True)
+                present = present + (kv,)
+            return {"loss": torch.nn.functional.cross_entropy(self.head(hidden).flatten(0, 1), batch["y"].flatten()),
+                    "past": present}
+
+    def loss(m, b, c):
+        return m(b)["loss"], b["x"].shape[0]
+
+    torch.manual_seed(0)
+    model = Stack().eval()
+    name = "block.1.k.weight"
+    param = dict(model.named_parameters())[name]
+    home = param.data
+    g = torch.Generator().manual_seed(1)
+    batches = [{"x": torch.randn(3, 5, 8, generator=g), "y": torch.randint(0, 3, (3, 5), generator=g)}
+               for _ in range(2)]
+    thetas = [home + 1e-2 * torch.randn(home.shape, generator=g) for _ in range(4)]
+    hooked = HookedPrefixLoss(model, loss, ["block"], eval_batch=4)
+    hooked.begin_layer(name)
+    hooked.begin_layer_weights(name, home)
+    items = [(b, thetas[2 * i], thetas[2 * i + 1]) for i, b in enumerate(batches)]
+    with torch.no_grad():
+        for rep in range(3):
+            got = hooked.multi(model, items, False)
+        want = []
+        for b, tp, tm in items:
+            pair = []
+            for th in (tp, tm):
+                param.data = th
+                pair.append(loss(model, b, False)[0])
+            param.data = home
+            want.append(pair)
+    hooked.end_layer_weights(None)
+    for (l1, l2, n), (w1, w2) in zip(got, want):
+        assert torch.equal(l1, w1) and torch.equal(l2, w2) and n == 3
+    assert hooked.stats["lockstep_evals"] == 8 and {2, 3} <= set(hooked.wired), (hooked.stats, sorted(hooked.wired))
+    assert hooked.stats["events_shared"] > 0
+    hooked.close()
