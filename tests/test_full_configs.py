@@ -41,6 +41,29 @@ def test_config3_blip2_zeroth_order_full_size():
     assert a["stage_stats"]["stage1"]["z_mode"] == "torch-registers"
     assert a["table_sha256"].startswith(CONFIG3_TABLE_SHA256_PREFIX), a["table_sha256"]
     _check_config3(a)
+    _STAGED["pruned_weights_sha256"] = a["pruned_weights_sha256"]
+
+
+_STAGED = {}
+
+
+def test_config3_full_size_with_the_stage_plan_hidden_equals_the_staged_run():
+    """The same config on the model as a reference user hands it over (block
+    lists and a forward, `--unstaged` hides `stage_plan()`): the hook adapter's lock-step path at
+    full size, in a fresh process like the run above — the same table hash, and the same pruned
+    weights as the staged run of this session."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config.py"), "3", "--unstaged"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads(r.stdout.strip().splitlines()[-1])
+    sf = c["stage_stats"]["stage1"]["suffix_forward"]
+    assert sf.get("lockstep_evals", 0) > 15000 and sf.get("lockstep_disabled_at") is None, sf
+    assert c["table_sha256"].startswith(CONFIG3_TABLE_SHA256_PREFIX), c["table_sha256"]
+    assert c["prunable_matrices"] == 588 and c["table_entries"] == 588 and c["distinct_sparsities"] == 87
+    if _STAGED:
+        assert c["pruned_weights_sha256"] == _STAGED["pruned_weights_sha256"]
 
 
 def _check_config3(a):
