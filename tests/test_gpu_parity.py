@@ -936,14 +936,15 @@ def test_wanda_block_full_size_blocks_equal_single_calls(kern):
             assert kern.wanda_fallback_counts() == (0, 0)
 
 
-@pytest.mark.parametrize("rows,cols,sampled", [(4096, 8192, True), (7168, 8192, False)])
-def test_wanda_matrix_large_matrices_equal_sort(kern, rows, cols, sampled):
+@pytest.mark.parametrize("rows,cols,sampled,dt", [(4096, 8192, True, torch.float16), (7168, 8192, False, torch.float16),
+                                                  (3072, 4096, True, torch.float32), (2048, 5120, True, torch.bfloat16)])
+def test_wanda_matrix_large_matrices_equal_sort(kern, rows, cols, sampled, dt):
     """Matrix mode beyond BLIP-2's sizes: 33.5 M elements (the sampled two-pass selection, settled
     without the fallback: the threshold bin's list and the per-workgroup slots at 4x the ViT-g
     sizes) and 58.7 M (above WS_MAX_NUMEL: the three-histogram selection) against
     `sort(metric.flatten())[k]; metric <= thres` (wanda_pruner.py:555-558)."""
     g = torch.Generator(device="cuda").manual_seed(rows)
-    w = (torch.randn(rows, cols, device="cuda", generator=g) * 0.02).half()
+    w = (torch.randn(rows, cols, device="cuda", generator=g) * 0.02).to(dt)
     s = torch.rand(cols, device="cuda", generator=g) + 0.05
     k = int(rows * cols * 0.6)
     metric = w.abs().float() * torch.sqrt(s).reshape(1, -1)
