@@ -709,3 +709,64 @@ def test_lock_step_shares_blocks_that_return_key_value_tuples_and_a_broadcast_bi
     assert hooked.stats["lockstep_evals"] == 8 and {2, 3} <= set(hooked.wired), (hooked.stats, sorted(hooked.wired))
     assert hooked.stats["events_shared"] > 0
     hooked.close()
+
+
+def test_lock_step_hands_an_error_of_the_models_own_code_to_the_caller_and_recovers():
+    """An exception raised by the model's forward in the middle of a lock-step chunk reaches the
+    caller of `multi()` (after the one retry with per-evaluation slices that a failure inside shared
+    values earns), leaves no worker stuck, and the adapter scores the same chunk correctly
+    afterwards; `close()` ends every worker thread."""
+    import threading
+    import warnings
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList(
+                [torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Tanh()) for _ in range(4)])
+            self.calls, self.bomb = 0, None
+
+        def forward(self, batch):
+            x = batch["x"]
+            for blk in self.blocks:
+                x = blk(x)
+            self.calls += 1
+            if self.bomb is not None and self.calls >= self.bomb:
+                raise ValueError("user code failed")
+            return {"loss": x.pow(2).mean()}
+
+    def loss(m, b, c):
+        return m(b)["loss"], b["x"].shape[0]
+
+    before = {t.ident for t in threading.enumerate()}
+    torch.manual_seed(0)
+    model = Net().eval()
+    name = "blocks.1.0.weight"
+    param = dict(model.named_parameters())[name]
+    home = param.data
+    g = torch.Generator().manual_seed(1)
+    batches = [{"x": torch.randn(3, 6, generator=g)} for _ in range(2)]
+    thetas = [home + 1e-2 * torch.randn(home.shape, generator=g) for _ in range(4)]
+    hooked = HookedPrefixLoss(model, loss, ["blocks"], eval_batch=4)
+    hooked.begin_layer(name)
+    hooked.begin_layer_weights(name, home)
+    items = [(b, thetas[2 * i], thetas[2 * i + 1]) for i, b in enumerate(batches)]
+    with torch.no_grad(), warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        hooked.multi(model, items, False)
+        good = hooked.multi(model, items, False)
+        model.bomb = model.calls + 3
+        with pytest.raises(ValueError, match="user code failed"):
+            hooked.multi(model, items, False)
+        model.bomb = None
+        hooked.abort_run()
+        again = hooked.multi(model, items, False)
+    for (a1, a2, _), (b1, b2, _) in zip(good, again):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    hooked.end_layer_weights(None)
+    assert param.data.data_ptr() == home.data_ptr()
+    hooked.close()
+    import time
+    time.sleep(0.3)
+    assert {t.ident for t in threading.enumerate()} <= before
