@@ -958,6 +958,59 @@ def test_wanda_matrix_large_matrices_equal_sort(kern, rows, cols, sampled, dt):
     assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
 
 
+def test_selection_and_perturbation_calls_can_be_captured_in_a_hip_graph(kern):
+    """include/ecoflap_hip.h: no allocation or synchronisation inside a call.  K7 (a ViT-sized
+    matrix-mode item through the sampled two-launch selection, its exact fallback included, and a
+    rows-mode item) and K1 (the reference's draw regenerated in registers) recorded into ONE HIP
+    graph on static buffers, replayed on three different contents: equal to the eager calls."""
+    from ecoflap_amd.hip import TORCH_Z
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wm = torch.empty(1024, 1408, device="cuda", dtype=torch.float16)
+    wr = torch.empty(512, 2048, device="cuda", dtype=torch.bfloat16)
+    sm = torch.rand(1408, device="cuda", generator=g) + 0.05
+    sr = torch.rand(2048, device="cuda", generator=g) + 0.05
+    k1w = torch.empty(4099, device="cuda", dtype=torch.bfloat16)
+    plus, minus, final = (torch.empty_like(k1w) for _ in range(3))
+    km = wm.numel() // 2
+
+    def fill(case):
+        wm.copy_((torch.randn(wm.shape, device="cuda", generator=g) * 0.02).half())
+        if case == 2:                                   # half the matrix ties at the threshold: the fallback
+            wm.mul_((torch.rand(wm.shape, device="cuda", generator=g) < 0.3).half())
+        wr.copy_((torch.randn(wr.shape, device="cuda", generator=g) * 0.02).bfloat16())
+        k1w.copy_((torch.randn(k1w.shape, device="cuda", generator=g) * 0.05).bfloat16())
+
+    def calls():
+        kern.wanda_prune_block([(wm, sm, "matrix", km, None), (wr, sr, "rows", 1024, None)])
+        kern.zo_perturb_layers([(k1w, final, [77], [plus], [minus], TORCH_Z)], 1e-3)
+
+    fill(0)
+    calls()                                             # (warm-up outside the capture: workspaces, lazy init)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    fill(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            calls()
+    torch.cuda.current_stream().wait_stream(side)
+    for case in range(3):
+        fill(case)
+        keep = [t.clone() for t in (wm, wr, k1w)]
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (wm, wr, plus, minus, final)]
+        for t, k in zip((wm, wr, k1w), keep):
+            t.copy_(k)
+        kern.wanda_fallback_counts()
+        calls()
+        torch.cuda.synchronize()
+        assert (sum(kern.wanda_fallback_counts()) > 0) == (case == 2)
+        for a, b in zip(got, (wm, wr, plus, minus, final)):
+            assert torch.equal(a, b), case
+
+
 # ------------------------------------------------------------------------------ K8
 @pytest.mark.parametrize("dt", DTYPES)
 def test_mask_mul(kern, oracle, dt):
