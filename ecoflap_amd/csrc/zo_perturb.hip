@@ -659,8 +659,11 @@ static inline int64_t torch_items(int64_t n, int64_t T, int N) {
     return rounds * ((vpr + 63) / 64);
 }
 static inline int torch_threads_ok(int64_t n, int64_t T) {
-    // T = 256 * grid, grid <= ceil(n / 256); 32-bit subsequence indices
-    return T >= 256 && (T % 256) == 0 && T <= ((n + 255) / 256) * 256 && T < ((int64_t)1 << 31);
+    // T = 256 * grid, grid <= ceil(n / 256); 32-bit subsequence indices.  n < 2^31: a larger tensor
+    // torch draws in several launches (TensorIterator::with_32bit_indexing), each at its own Philox
+    // offset — not the single stream regenerated here; the caller materialises such a draw
+    return n < ((int64_t)1 << 31) && T >= 256 && (T % 256) == 0 && T <= ((n + 255) / 256) * 256 &&
+           T < ((int64_t)1 << 31);
 }
 
 #define ECO_XCD_ITEM(I, total)                                                                \

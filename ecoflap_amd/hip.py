@@ -438,6 +438,9 @@ class HipKernels:
                 if (a is None) != (b is None):
                     raise EcoflapHipError("theta+ and theta- of a unit: both or neither")
             n = w_in.numel()
+            if n >= 2 ** 31:       # (torch draws such a tensor in several launches at advancing offsets)
+                raise EcoflapHipError("zo_perturb_layers_torch: tensors of 2^31 elements or more take the "
+                                      "materialised draw")
             per_vec = 16 // w_in.element_size()
             threads = self.torch_normal_threads(n, w_in.device)
             items = -(-n // (4 * threads)) * -(-(threads // per_vec) // 64)

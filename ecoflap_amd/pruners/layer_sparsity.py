@@ -193,7 +193,9 @@ class LayerSparsity:
         if self.z_source == "philox":
             return None
         if self.z_source == "torch":
-            if not materialise and self._torch_z_in_registers(param):
+            # (a tensor of 2^31 elements or more is drawn by torch in several launches at advancing
+            # Philox offsets: those draws are torch's own, read from memory)
+            if not materialise and param.numel() < 2 ** 31 and self._torch_z_in_registers(param):
                 return _hip.TORCH_Z
             torch.manual_seed(seed)
             return torch.normal(mean=0, std=1, size=param.data.size(), device=param.data.device,

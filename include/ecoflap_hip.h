@@ -165,7 +165,10 @@ int ecoflap_zo_perturb_layers_z(const int64_t* table, int n_layers, int64_t tota
  * (tests/test_gpu_parity.py; probed at start-up by pruners/layer_sparsity.py, which falls back to
  * the materialised draw when a torch / rocRAND upgrade changes the stream).
  * threads: what ATen's calc_execution_policy gives for n on the device at hand:
- * ecoflap_torch_normal_threads(n, multiProcessorCount, maxThreadsPerMultiProcessor). */
+ * ecoflap_torch_normal_threads(n, multiProcessorCount, maxThreadsPerMultiProcessor).
+ * n < 2^31 (ECOFLAP_ESIZE otherwise): a larger tensor torch draws in several launches
+ * (TensorIterator::with_32bit_indexing), each at its own Philox offset; the caller takes the
+ * materialised draw for it (pruners/layer_sparsity.py does). */
 int64_t ecoflap_torch_normal_threads(int64_t n, int multiprocessors, int max_threads_per_mp);
 
 /* z_out <- the tensor torch.manual_seed(seed); torch.normal(0, 1, [n], dtype) returns. */

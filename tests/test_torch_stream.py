@@ -34,6 +34,10 @@ def test_thread_rule_of_atens_launch():
     assert lib.ecoflap_zo_fill_normal_torch(vp(16), 1024, 1, 1, 100, None) == -3      # threads % 256
     assert lib.ecoflap_zo_fill_normal_torch(vp(16), 1024, 1, 1, 2048, None) == -3     # > ceil(n/256)*256
     assert lib.ecoflap_zo_fill_normal_torch(None, 1024, 1, 1, 1024, None) == -2
+    # 2^31 elements or more: torch draws such a tensor in several launches (with_32bit_indexing),
+    # each at its own Philox offset — refused here, LayerSparsity materialises that draw
+    assert lib.ecoflap_zo_fill_normal_torch(vp(16), 2 ** 31, 1, 1, 256 * 2048, None) == -3
+    assert lib.ecoflap_zo_perturb_torch(vp(16), 2 ** 31 + 8, 1, 1.0, 1e-3, 1, 256 * 2048, None) == -3
     assert lib.ecoflap_zo_fill_normal_torch(vp(8), 1024, 1, 1, 1024, None) == -5
     assert lib.ecoflap_zo_perturb_torch(vp(16), 1024, 7, 1.0, 1e-3, 1, 1024, None) == -1
     assert lib.ecoflap_zo_perturb_layers_torch(None, 1, 1, 1, 1e-3, None, None, None) == -2
