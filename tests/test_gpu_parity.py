@@ -958,6 +958,22 @@ def test_wanda_matrix_large_matrices_equal_sort(kern, rows, cols, sampled, dt):
     assert torch.equal(w2, torch.where(want, torch.zeros_like(w), w))
 
 
+def test_wanda_matrix_fuzz_equals_sort(kern):
+    """60 random matrix-mode cases (tools/diag/k7_fuzz.py: shapes around the ViT sizes, three dtypes,
+    k from 0 to numel - 1, ties / zeros / heavy tails / constant scalers / quantised weights)
+    against `sort(metric.flatten())[k]; metric <= thres` on the GPU: no difference."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag"))
+    import k7_fuzz
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bad = []
+    for case in range(60):
+        ok, info = k7_fuzz.one(kern, g, case)
+        if not ok:
+            bad.append(info)
+    assert not bad, bad[:5]
+
+
 def test_selection_and_perturbation_calls_can_be_captured_in_a_hip_graph(kern):
     """include/ecoflap_hip.h: no allocation or synchronisation inside a call.  K7 (a ViT-sized
     matrix-mode item through the sampled two-launch selection, its exact fallback included, and a
