@@ -187,3 +187,34 @@ def test_stage1_in_registers_equals_materialised_draws(kern, k1_form):
     for k in w_r:
         assert torch.equal(w_r[k], w_m[k]), k
     assert torch.equal(st_r[0], st_m[0]) and torch.equal(st_r[1], st_m[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_k1_in_registers_on_every_finite_16_bit_weight_equals_the_references_op_chain(kern, dt):
+    """K1's in-register arithmetic takes shortcuts (one fused step for theta-, packed adds) that are
+    argued, not generic.  Here EVERY finite 16-bit weight value meets 4096 draws of the reference's
+    z (2.7e8 pairs per dtype: all 63 488 / 64 512 weight patterns x the whole range of rounded
+    normals), the triple form with z regenerated in registers, against the reference's own op
+    chain executed by torch on the same GPU (`param.data = param.data + scaling_factor * z * zo_eps`,
+    layer_single_base_pruner.py:485-486, three times: +1, -2, +1 — one rounding per torch op)."""
+    from ecoflap_amd.hip import TORCH_Z
+    allbits = torch.arange(-32768, 32768, dtype=torch.int32, device="cuda").to(torch.int16).view(dt)
+    finite = allbits[torch.isfinite(allbits.float())]
+    reps = 4096
+    w0 = finite.repeat(reps).contiguous()
+    eps, seed = 1e-3, 20260101
+    torch.manual_seed(seed)
+    z = torch.normal(mean=0, std=1, size=w0.shape, device="cuda", dtype=dt)
+    ref_plus = w0 + 1.0 * z * eps
+    ref_minus = ref_plus + -2.0 * z * eps
+    ref_rest = ref_minus + 1.0 * z * eps
+    plus, minus, rest = (torch.empty_like(w0) for _ in range(3))
+    kern.zo_perturb_triple(w0, plus, minus, rest, eps, seed, TORCH_Z)
+    for name, a, b in (("theta+", plus, ref_plus), ("theta-", minus, ref_minus), ("restored", rest, ref_rest)):
+        diff = bits(a) != bits(b)
+        n = int(diff.sum())
+        if n:
+            i = diff.nonzero().flatten()[:4]
+            raise AssertionError(f"{name}: {n} of {a.numel()} differ, e.g. w={w0[i].tolist()} z={z[i].tolist()} "
+                                 f"got {a[i].tolist()} want {b[i].tolist()}")
