@@ -103,63 +103,27 @@ class SparseGPT:
             H[diag, diag] += damp                                 # not positive definite yet
         raise RuntimeError("Hessian could not be made positive definite")
 
-    # ---- the factorisations of a block's Linears, side by side ---------------------------------
-    _pool = None
-    _pool_streams = {}
-
+    # ---- the factorisations of a block's Linears ---------------------------------------------------
     @classmethod
     def factor_all(cls, items, percdamp=.01):
         """`factor` (dead columns, Hinv) for every SparseGPT in `items` — the three torch.linalg
-        calls of `fasterprune` (:84-110) — with the Linears of a transformer block running SIDE BY
-        SIDE: one host thread and one HIP stream each.  Why: rocSOLVER's potrf is latency-bound at
-        these sizes (measured: 4.0 ms at 1408, 6.0 ms at 2048, 20 ms at 6144 = 0.2-3.8 TFLOP/s of
-        fp32; the three calls of one ViT-g block's four Hessians one after the other: 78 ms, of a
-        FlanT5 decoder block's seven: 112 ms — `profiles/r05_sparsegpt/cholesky_bench.log`), the
-        Hessians of a block are independent, and the library's small kernels leave the chip almost
-        empty.  A THREAD per Linear, not just a stream: torch keeps one solver / BLAS handle per
-        host thread, and a handle's device workspace must not serve two streams at once (tried
-        first with streams alone: factors came out corrupted whenever two calls overlapped).  Each
-        thread runs exactly `_factor_alone` — the reference's sequence with its own host-side
-        tests, which now wait on that thread's stream only — so the results are the one-by-one
-        results bit for bit (`tests/test_sparsegpt_parity.py`)."""
-        items = [it for it in items if it.factor is None]
-        if not items:
-            return
-        for it in items:
-            it.flush()
-        if not (items[0].H.is_cuda and len(items) > 1):
-            for it in items:
-                it._factor_alone(percdamp)
-            return
-        import concurrent.futures as cf
-        import threading
-        if cls._pool is None:
-            cls._pool = cf.ThreadPoolExecutor(max_workers=8, thread_name_prefix="sparsegpt-factor")
-        main = torch.cuda.current_stream()
-        device = torch.cuda.current_device()
-        done_streams = []
+        calls of `fasterprune` (:84-110) — up front for a whole transformer block, ONE AT A TIME.
 
-        def work(it):
-            torch.cuda.set_device(device)
-            tid = threading.get_ident()
-            st = cls._pool_streams.get((tid, device))
-            if st is None:
-                st = cls._pool_streams[(tid, device)] = torch.cuda.Stream()
-            st.wait_stream(main)
-            with torch.cuda.stream(st), torch.no_grad():
-                it._factor_alone(percdamp)
-                st.synchronize()
-            done_streams.append(st)
-
-        # (largest first: the block's 5120 / 6144 Hessian is the critical path)
-        order = sorted(items, key=lambda it: -it.columns)
-        for f in [cls._pool.submit(work, it) for it in order]:
-            f.result()
-        for st in done_streams:
-            main.wait_stream(st)
+        Round 5 first ran them side by side (rocSOLVER's potrf is latency-bound at these sizes:
+        4.0 ms at 1408, 20 ms at 6144, `profiles/r05_sparsegpt/cholesky_bench.log`; a block's
+        Hessians are independent): on several streams from one thread the factors came out
+        corrupted at once (one solver handle, one workspace), with one host thread + stream + handle
+        per Linear they matched the one-by-one results in every test run — until a suite run in
+        which one did not.  `tools/diag/factor_determinism.py` then showed 4-8 corrupted factors
+        (differences of 1e-4 .. 1e-2, not rounding) per 400 side-by-side factorisations against 0
+        in 160 one-by-one, with a lock around the Cholesky calls alone and around the inverse
+        alone as well: two solver calls in flight in one process are not safe on this stack,
+        whoever makes them.  So: sequential, on the caller's stream (4.5 s of the BLIP-2 run given
+        back); what stays of the round's SparseGPT work is the graph replays of both block passes."""
         for it in items:
-            for t in it.factor:          # made on a side stream, read by the sweep on this one
-                t.record_stream(main)
+            if it.factor is None:
+                it.flush()
+                it._factor_alone(percdamp)
 
     def _factor_alone(self, percdamp):
         H = self.H

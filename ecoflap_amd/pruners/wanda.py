@@ -577,8 +577,8 @@ class _BlockwiseWanda:
                                 twins[a] = b
                                 break
             if sparsegpt and getattr(self.owner, "sparsegpt_factor_side_by_side", True):
-                # the block's independent factorisations on side-by-side streams (pruners/sparsegpt.py)
-                with PhaseTimer.span("sparsegpt.factor (all Linears of a block side by side: torch.linalg)"):
+                # the block's factorisations up front, one at a time (pruners/sparsegpt.py: why not side by side)
+                with PhaseTimer.span("sparsegpt.factor (all Linears of a block, one at a time: torch.linalg)"):
                     SparseGPT.factor_all([wrapped[n] for n in subset if n not in twins], percdamp=0.01)
             block_items = []
             for name in subset:

@@ -131,11 +131,13 @@ def test_sparsegpt_pruner_n_m_end_to_end(golden_dir):
 
 
 @pytest.mark.gpu
-def test_block_factorisations_side_by_side_equal_one_by_one():
-    """`SparseGPT.factor_all` (round 5: the Linears of a block factored on side-by-side streams,
-    the reference's host-side tests read back once per step for the block) == `fasterprune`'s own
-    one-by-one factorisation, bit for bit: dead columns, Hinv and the pruned weights; including a
-    Hessian with dead columns and one that needs the damping loop."""
+def test_block_factorisations_up_front_equal_fasterprunes_own():
+    """`SparseGPT.factor_all` (the Linears of a block factored up front) == `fasterprune`'s own
+    factorisation, bit for bit: dead columns, Hinv and the pruned weights; including a Hessian
+    with dead columns and one that needs the damping loop, three times over.  The first form of
+    `factor_all` ran the block's factorisations side by side on per-thread streams and returned a
+    corrupted factor once in ~50 (tools/diag/factor_determinism.py) — two rocSOLVER calls in flight
+    in one process are not safe here; it is sequential now and this test holds it to that."""
     import torch.nn as nn
     from ecoflap_amd import hip
     from ecoflap_amd.pruners.sparsegpt import SparseGPT
@@ -157,15 +159,17 @@ def test_block_factorisations_side_by_side_equal_one_by_one():
             out.append(w)
         return out
 
-    one_by_one, together = build(), build()
+    one_by_one = build()
     for w in one_by_one:
         w.fasterprune(0.5)
-    SparseGPT.factor_all(together)
-    assert all(w.factor is not None and w.H is None for w in together)
-    for a, b in zip(one_by_one, together):
-        assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1])
-        b.fasterprune(0.5)
-        assert torch.equal(a.layer.weight.data, b.layer.weight.data)
+    for rep in range(3):
+        together = build()
+        SparseGPT.factor_all(together)
+        assert all(w.factor is not None and w.H is None for w in together)
+        for a, b in zip(one_by_one, together):
+            assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1]), rep
+            b.fasterprune(0.5)
+            assert torch.equal(a.layer.weight.data, b.layer.weight.data), rep
 
 
 @pytest.mark.gpu
