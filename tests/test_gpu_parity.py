@@ -974,6 +974,22 @@ def test_wanda_matrix_fuzz_equals_sort(kern):
     assert not bad, bad[:5]
 
 
+def test_wanda_rows_fuzz_equals_stable_sort(kern):
+    """60 random rows-mode cases (tools/diag/k7_rows_fuzz.py: 1-700 rows of 8-8240 columns, odd widths,
+    three dtypes, k from 0 to cols, ties / zeros / heavy tails) against the reference's
+    `torch.sort(W_metric, dim=-1, stable=True)[1][:, :k]` scatter on the GPU: no difference."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag"))
+    import k7_rows_fuzz
+    g = torch.Generator(device="cuda").manual_seed(13)
+    bad = []
+    for case in range(60):
+        ok, info = k7_rows_fuzz.one(kern, g, case)
+        if not ok:
+            bad.append(info)
+    assert not bad, bad[:5]
+
+
 def test_selection_and_perturbation_calls_can_be_captured_in_a_hip_graph(kern):
     """include/ecoflap_hip.h: no allocation or synchronisation inside a call.  K7 (a ViT-sized
     matrix-mode item through the sampled two-launch selection, its exact fallback included, and a
