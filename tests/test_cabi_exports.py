@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -63,6 +64,52 @@ def test_allocator_through_cabi_matches_reference_goldens(golden_dir):
         sp, mx, keep = g[f"{i}_meta"]
         out, _ = hip.allocate_sparsity(g[f"{i}_scores"], g[f"{i}_nums"], int(keep), float(mx))
         assert np.array_equal(np.array(out), g[f"{i}_out"], equal_nan=True), str(g[f"{i}_tag"])
+
+
+def test_allocator_through_cabi_equals_the_oracle_on_random_problems():
+    """400 fresh random allocation problems (group counts 1-400, parameter counts 1e2-1e8, scores
+    with ties, zeros, huge ranges and NaN, targets 0.1-0.95, caps 0.5-1.0): the C++ allocator
+    behind `ecoflap_allocate_sparsity` == the oracle restatement of
+    `compute_the_sparsity_per_group` (UPop/pruners/layer_single_base_pruner.py:247-314), every
+    float bit for bit (the oracle itself is pinned to 193 reference cases in g4)."""
+    import numpy as np
+    from ecoflap_amd import hip
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import allocator as oracle_alloc
+    rng = np.random.default_rng(20261004)
+    checked = 0
+    for case in range(400):
+        G = int(rng.integers(1, 400)) if case % 7 else int(rng.integers(1, 4))
+        nums = (10 ** rng.uniform(2, 8, size=G)).astype(np.int64)
+        kind = case % 6
+        if kind == 0:
+            scores = rng.random(G)
+        elif kind == 1:
+            scores = np.round(rng.random(G) * 4) / 4                      # ties and zeros
+        elif kind == 2:
+            scores = 10 ** rng.uniform(-12, 12, size=G)                   # huge range
+        elif kind == 3:
+            scores = rng.random(G) * (rng.random(G) < 0.3)                # mostly zero
+        elif kind == 4:
+            scores = np.full(G, 1.0)
+        else:
+            scores = rng.random(G)
+            scores[rng.integers(0, G)] = np.nan
+        scores = scores.astype(np.float32)
+        mx = float(rng.choice([0.5, 0.6, 0.8, 0.9, 1.0]))
+        target = float(rng.uniform(0.1, min(0.95, mx)))
+        keep = int(nums.sum() * (1 - target))
+        try:
+            want, _ = oracle_alloc.compute_sparsity_per_group(keep, scores, nums, mx, max_iters=2000)
+        except RuntimeError:
+            continue                                                      # (the reference would loop forever)
+        got, _ = hip.allocate_sparsity(scores, nums, keep, mx)
+        fg, fw = np.array(got, dtype=np.float32), np.array(want, dtype=np.float32)
+        nan = np.isnan(fw)                                                 # (a NaN is a NaN, whatever its sign bit)
+        assert np.array_equal(nan, np.isnan(fg)), (case, G, kind, mx, target)
+        assert np.array_equal(fg[~nan].view(np.uint32), fw[~nan].view(np.uint32)), (case, G, kind, mx, target)
+        checked += 1
+    assert checked > 300
 
 
 def test_argument_errors_do_not_touch_the_gpu():
