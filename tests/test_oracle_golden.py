@@ -202,3 +202,32 @@ def test_normal_stream_restatement_properties(oracle, dt):
         # second vector of block 0 is vector 64: elements 512..519 come from pairs 4..7
         u1b = np.float32(np.float32(words[4]) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33))
         assert abs(float(z32[512]) ** 2 + float(z32[514]) ** 2 + 2.0 * np.log(float(u1b))) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_oracle_k1_chain_on_every_finite_16_bit_weight_equals_torchs_cpu_ops(oracle, dt):
+    """The oracle's restatement of `param.data = param.data + scaling_factor * z * zo_eps`
+    (layer_single_base_pruner.py:485-486) against the expression itself, evaluated by torch on the
+    CPU as the reference evaluates it: EVERY finite 16-bit weight value x 48 draws of z (incl. +-0,
+    the largest normals a run draws and subnormal products), scaling factors +1 / -2 / +1 in place
+    and the three-output form.  (The GPU twin of this test holds the HIP kernels to torch's ops on
+    the device: tests/test_torch_stream.py.)"""
+    allbits = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).view(dt)
+    finite = allbits[torch.isfinite(allbits.float())]
+    g = torch.Generator().manual_seed(5)
+    zs = torch.randn(44, generator=g).tolist() + [0.0, -0.0, 6.5, -6.25]
+    z = torch.tensor(zs).to(dt).repeat_interleave(finite.numel())
+    w0 = finite.repeat(len(zs)).contiguous()
+    eps = 1e-3
+    ref = w0.clone()
+    got = w0.clone()
+    for sf in (1.0, -2.0, 1.0):
+        ref = ref + sf * z * eps                              # the reference's expression, torch CPU
+        oracle.zo_perturb(got, sf, eps, z)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), sf
+    plus, minus, rest = oracle.zo_perturb_triple(w0.clone(), eps, z)
+    rp = w0 + 1.0 * z * eps
+    rm = rp + -2.0 * z * eps
+    rr = rm + 1.0 * z * eps
+    for a, b in ((plus, rp), (minus, rm), (rest, rr)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
