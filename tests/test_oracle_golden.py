@@ -231,3 +231,53 @@ def test_oracle_k1_chain_on_every_finite_16_bit_weight_equals_torchs_cpu_ops(ora
     rr = rm + 1.0 * z * eps
     for a, b in ((plus, rp), (minus, rm), (rest, rr)):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_oracle_wanda_selection_fuzz_equals_the_references_expressions():
+    """180 random cases of the three Wanda selections, the oracle against the reference's own torch
+    expressions evaluated on the CPU (wanda_pruner.py:260-279 rows: stable sort + scatter; :541-558
+    matrix: `sort(metric.flatten())[k]`, `metric <= thres`; :265-270 n:m: topk per group): ties,
+    zeros, heavy tails, three dtypes, k from 0 to the row / matrix size."""
+    from oracle_backend import OracleKernels
+    ok = OracleKernels()
+    g = torch.Generator().manual_seed(99)
+    for case in range(180):
+        rows = int(torch.randint(1, 40, (1,), generator=g))
+        cols = int(torch.randint(1, 30, (1,), generator=g)) * 4
+        dt = [torch.float32, torch.float16, torch.bfloat16][case % 3]
+        kind = ["normal", "ties", "zeros", "heavy"][case % 4]
+        w = torch.randn(rows, cols, generator=g) * 0.02
+        s = torch.rand(cols, generator=g) + 0.05
+        if kind == "ties":
+            w = torch.round(w * 50) / 50
+            s = torch.full((cols,), 0.25)
+        elif kind == "zeros":
+            w = w * (torch.rand(rows, cols, generator=g) < 0.4)
+        elif kind == "heavy":
+            w = w * torch.exp(2.5 * torch.randn(rows, cols, generator=g))
+        w = w.to(dt)
+        metric = torch.abs(w) * torch.sqrt(s.reshape((1, -1)))
+        frac = [0.5, 0.37, 0.9, 0.0, 0.6, 1.0, 0.25][case % 7]
+        mode = case % 3 if kind == "normal" else case % 2          # (n:m: topk's tie order is not the subject)
+        if mode == 0:                                              # rows
+            k = int(cols * frac)
+            mask = torch.zeros_like(metric) == 1
+            mask.scatter_(1, torch.sort(metric, dim=-1, stable=True)[1][:, :k], True)
+            got = w.clone()
+            ok.wanda_prune_rows(got, s, k)
+        elif mode == 1:                                            # matrix
+            k = min(rows * cols - 1, int(rows * cols * frac))
+            thres = torch.sort(metric.flatten())[0][k]
+            mask = metric <= thres
+            got = w.clone()
+            ok.wanda_prune_matrix(got, s, k)
+        else:                                                      # 2:4
+            mask = torch.zeros_like(metric) == 1
+            for ii in range(0, cols, 4):
+                tmp = metric[:, ii:ii + 4].float()
+                mask.scatter_(1, ii + torch.topk(tmp, 2, dim=1, largest=False)[1], True)
+            got = w.clone()
+            ok.wanda_prune_nm(got, s, 2, 4)
+        want = w.clone()
+        want[mask] = 0
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (case, rows, cols, str(dt), kind, mode)
