@@ -281,3 +281,29 @@ def test_oracle_wanda_selection_fuzz_equals_the_references_expressions():
         want = w.clone()
         want[mask] = 0
         assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (case, rows, cols, str(dt), kind, mode)
+
+
+def test_oracle_k6_fuzz_equals_the_references_add_batch_on_the_cpu():
+    """120 random sequences of `WrappedGPT.add_batch` calls (wanda_pruner.py:71-84: 1-3 batches of
+    1-4 samples x 1-300 tokens x 2-700 columns, three dtypes): the oracle's running statistic equals
+    the reference's expression evaluated by torch on the CPU — `scaler_row *= n / (n + b)`,
+    `+= torch.norm(inp.float(), p=2, dim=1) ** 2 / n` — float bit for float bit, i.e. the oracle sums
+    in torch's own CPU order.  (One column is the one shape where it does not: torch reduces a single
+    contiguous row with another kernel; no Linear has one input feature.)"""
+    from oracle_backend import OracleKernels
+    ok = OracleKernels()
+    g = torch.Generator().manual_seed(3)
+    for case in range(120):
+        cols = int(torch.randint(2, 700, (1,), generator=g))
+        dt = [torch.float32, torch.float16, torch.bfloat16][case % 3]
+        srow, ref, n = torch.zeros(cols), torch.zeros(cols), 0
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            B = int(torch.randint(1, 5, (1,), generator=g))
+            T = int(torch.randint(1, 300, (1,), generator=g))
+            x = (torch.randn(B, T, cols, generator=g) * 1.7).to(dt)
+            inp = x.reshape((-1, cols)).t()
+            ref *= n / (n + B)
+            ref += torch.norm(inp.type(torch.float32), p=2, dim=1) ** 2 / (n + B)
+            ok.colsqnorm_accum(srow, x.reshape(-1, cols), n, B)
+            n += B
+        assert torch.equal(ref.view(torch.int32), srow.view(torch.int32)), (case, cols, str(dt))
