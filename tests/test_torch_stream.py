@@ -218,3 +218,40 @@ def test_k1_in_registers_on_every_finite_16_bit_weight_equals_the_references_op_
             i = diff.nonzero().flatten()[:4]
             raise AssertionError(f"{name}: {n} of {a.numel()} differ, e.g. w={w0[i].tolist()} z={z[i].tolist()} "
                                  f"got {a[i].tolist()} want {b[i].tolist()}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_block_batched_k1_on_every_finite_16_bit_weight_equals_the_references_op_chain(kern, dt):
+    """The production form (`ecoflap_zo_perturb_layers_torch`: one launch for a block's layers, U
+    units chained on the drifting weights, z regenerated in registers) on every finite 16-bit weight
+    value x 1024 positions, two layers of different sizes in one launch, three units: theta+ /
+    theta- of every unit and the drifted weights equal the reference's op chain evaluated by torch
+    on the same GPU with torch's own draws."""
+    from ecoflap_amd.hip import TORCH_Z
+    allbits = torch.arange(-32768, 32768, dtype=torch.int32, device="cuda").to(torch.int16).view(dt)
+    finite = allbits[torch.isfinite(allbits.float())]
+    eps = 1e-3
+    layers, want = [], []
+    for li, reps in enumerate((1024, 37)):
+        w0 = finite.repeat(reps)[: finite.numel() * reps - 5 * li].contiguous()     # (a ragged tail on the second)
+        seeds = [901 + 10 * li, 17 + li, 2 ** 33 + 5 + li]
+        plus = [torch.empty_like(w0) for _ in seeds]
+        minus = [torch.empty_like(w0) for _ in seeds]
+        final = torch.empty_like(w0)
+        layers.append((w0, final, seeds, plus, minus, TORCH_Z))
+        cur, chain = w0.clone(), []
+        for sd in seeds:
+            torch.manual_seed(sd)
+            z = torch.normal(mean=0, std=1, size=w0.shape, device="cuda", dtype=dt)
+            p_ = cur + 1.0 * z * eps
+            m_ = p_ + -2.0 * z * eps
+            cur = m_ + 1.0 * z * eps
+            chain.append((p_, m_))
+        want.append((chain, cur))
+    kern.zo_perturb_layers(layers, eps)
+    for (w0, final, seeds, plus, minus, _), (chain, cur) in zip(layers, want):
+        assert torch.equal(bits(final), bits(cur))
+        for u in range(len(seeds)):
+            assert torch.equal(bits(plus[u]), bits(chain[u][0])), u
+            assert torch.equal(bits(minus[u]), bits(chain[u][1])), u
