@@ -28,7 +28,14 @@ blocks = {k: v for k, v in model.state_dict().items() if v.dim() == 2 and ".bloc
           and "relative_attention_bias" not in k}
 zeros = sum(int((v == 0).sum()) for v in blocks.values())
 total = sum(v.numel() for v in blocks.values())
-print(json.dumps({"wall_seconds": time.time() - t0, "pruned_fraction": zeros / total,
+wall = time.time() - t0
+import hashlib  # noqa: E402
+weights_sha = hashlib.sha256()          # (run-to-run reproducibility of the whole pipeline: same hash)
+for k in sorted(blocks):
+    weights_sha.update(blocks[k].detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+table_sha = hashlib.sha256(repr(sorted(table.items())).encode()).hexdigest() if isinstance(table, dict) else None
+print(json.dumps({"wall_seconds": wall, "pruned_fraction": zeros / total,
+                  "table_sha256": table_sha, "pruned_weights_sha256": weights_sha.hexdigest(),
                   "stage_stats": getattr(harness.main, "last_stage_stats", None),
                   "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
                   "stage2_phases": phase_report,
