@@ -255,3 +255,26 @@ def test_block_batched_k1_on_every_finite_16_bit_weight_equals_the_references_op
         for u in range(len(seeds)):
             assert torch.equal(bits(plus[u]), bits(chain[u][0])), u
             assert torch.equal(bits(minus[u]), bits(chain[u][1])), u
+
+
+@pytest.mark.gpu
+def test_k1_in_registers_on_random_fp32_bit_patterns_equals_the_references_op_chain(kern):
+    """fp32 cannot be enumerated: 2^26 weights drawn as random 32-bit PATTERNS (every exponent,
+    subnormals, huge values; non-finite ones dropped) through the triple form with z regenerated in
+    registers, against the reference's op chain evaluated by torch on the same GPU."""
+    from ecoflap_amd.hip import TORCH_Z
+    g = torch.Generator(device="cuda").manual_seed(8)
+    raw = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 26,), device="cuda", dtype=torch.int64, generator=g).to(torch.int32)
+    w0 = raw.view(torch.float32)
+    w0 = w0[torch.isfinite(w0)].contiguous()
+    eps, seed = 1e-3, 424243
+    torch.manual_seed(seed)
+    z = torch.normal(mean=0, std=1, size=w0.shape, device="cuda", dtype=torch.float32)
+    rp = w0 + 1.0 * z * eps
+    rm = rp + -2.0 * z * eps
+    rr = rm + 1.0 * z * eps
+    plus, minus, rest = (torch.empty_like(w0) for _ in range(3))
+    kern.zo_perturb_triple(w0, plus, minus, rest, eps, seed, TORCH_Z)
+    for name, a, b in (("theta+", plus, rp), ("theta-", minus, rm), ("restored", rest, rr)):
+        n = int((bits(a) != bits(b)).sum())
+        assert n == 0, f"{name}: {n} of {a.numel()} differ"
