@@ -568,28 +568,58 @@ static __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, u
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// rocrand box_muller(x, y) -> (sin(v) * s, cos(v) * s), as compiled into torch's kernel
-static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, float& zs, float& zc) {
+// rocRAND's radius s = sqrtf(-2 logf(u)) of a 32-bit word, restated instruction for instruction
+// from torch's kernel (the reference sequence: ocml's logf = v_log_f32 times a two-constant ln 2,
+// the correctly rounded sqrtf = v_sqrt_f32 and one step either way).  Kept as the yardstick of
+// `torch_radius` below (ecoflap_zo_torch_radius_sweep); no product kernel calls it.
+static __device__ __forceinline__ float torch_radius_reference(uint32_t x) {
     const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
     // logf(u) (ocml, u is never subnormal here: u >= 2^-32)
     const float r = __builtin_amdgcn_logf(u);                       // v_log_f32: log2
     // ocml's split of ln 2 (hi 0x3f317217 + lo 0x3377d1cf) with rocRAND's "-2 *" folded into both
     // constants: scaling by -2 is exact at every step (no value here is subnormal), so
-    // x2 = -2 * (yl + fma(lo, r, fma(r, hi, -yl))) bit for bit, one multiply less per pair
+    // x2 = -2 * (yl + fma(lo, r, fma(r, hi, -yl))) bit for bit
     const float m2ln2_hi = __uint_as_float(0xbfb17217u);
     const float yl = r * m2ln2_hi;
     float t = __builtin_fmaf(r, m2ln2_hi, -yl);
     t = __builtin_fmaf(__uint_as_float(0xb3f7d1cfu), r, t);
     const float x2 = yl + t;
     // sqrtf(x2), correctly rounded: v_sqrt_f32 and one step either way (x2 is 0 or >= 1e-7:
-    // ocml's rescaling of tiny arguments never triggers; u = 1 gives x2 = +0 here where the
-    // unfolded form has -0: every comparison below is false either way and the final "+ 0"
-    // produces torch's +0 from both)
+    // ocml's rescaling of tiny arguments never triggers)
     const float s0 = __builtin_amdgcn_sqrtf(x2);
     const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
     const float rm = __builtin_fmaf(-sm, s0, x2), rp = __builtin_fmaf(-sp, s0, x2);
     float s = (0.0f >= rm) ? sm : s0;
     s = (0.0f < rp) ? sp : s;
+    return s;
+}
+
+// The same VALUE for every one of the 2^32 words in 6 fewer instructions per pair (round 6; K1 in
+// this mode is VALU-bound, tools/micro/k1_torch_bound.hip):
+//   * ln 2 product: x2 = fma(r, hi, rn(lo * r)) — the exact product r * hi plus the rounded low
+//     term, rounded once, instead of ocml's four-instruction compensated form;
+//   * sqrt: y = v_rsq_f32(x2), g = x2 * y, s = fma(fma(-g, g, x2), y / 2, g) — one Newton step on
+//     an exact residual instead of v_sqrt_f32 + two trial residuals + two selects;
+//   * the 128 words that round to u = 1 (x2 = -0 here, +0 in the reference; rsq gives an
+//     infinity and g a NaN): v_max_f32 against +0 returns the +0 the reference has.
+// Neither shortcut is correctly rounded IN GENERAL; on this function's whole domain — which is
+// enumerable — they are: ecoflap_zo_torch_radius_sweep compares the two sequences over every
+// 32-bit word on the device (tests/test_torch_stream.py runs all 2^32; 0 differ).
+static __device__ __forceinline__ float torch_radius(uint32_t x) {
+    const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+    const float r = __builtin_amdgcn_logf(u);
+    const float x2 = __builtin_fmaf(r, __uint_as_float(0xbfb17217u), __uint_as_float(0xb3f7d1cfu) * r);
+    const float y = __builtin_amdgcn_rsqf(x2);
+    const float g = x2 * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-g, g, x2);
+    float s = __builtin_fmaf(e, h, g);
+    asm("v_max_f32 %0, 0, %1" : "=v"(s) : "v"(s));   // NaN (u = 1) -> +0; s >= 3e-4 otherwise
+    return s;
+}
+
+// rocrand box_muller(x, y) -> (sin(v) * s, cos(v) * s), as compiled into torch's kernel
+static __device__ __forceinline__ void torch_box_muller(uint32_t x, uint32_t y, float& zs, float& zc) {
+    const float s = torch_radius(x);
     const float v = __builtin_fmaf((float)y, __uint_as_float(0x30c90fdbu), __uint_as_float(0x30c90fdbu));
     const float a = v * __uint_as_float(0x3e22f983u);               // 1/(2 pi): revolutions for v_sin / v_cos
     // rocRAND's product, then ATen's transform fma(std = 1, x, mean = 0) = x + 0 (a -0 becomes
@@ -730,8 +760,52 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_perturb_kernel(void* 
 // (2*U_owned + 2) * s per element — the same as the build's own in-register stream: no z bytes.
 #define ECO_LAYER_ROW_T (6 + 3 * ECOFLAP_MAX_UNITS)
 
+// Philox4x32-10 of counter {j, 0, idx, 0} given the first round's per-lane product (hi1, lo1) =
+// M1 * idx: that product does not depend on the key, so a lane computes it once for all the
+// units of its item.  (j is wave-uniform: its round-1 product and the round-2 product of
+// hi(M0 * j) ^ k1 are scalar work; 16 vector multiplies per call are left of 20.)
+static __device__ __forceinline__ void philox4x32_10_r1(uint32_t j, uint32_t hi1, uint32_t lo1, uint32_t k0,
+                                                        uint32_t k1, uint32_t out[4]) {
+    const uint64_t pj = (uint64_t)PHILOX_M0 * j;
+    uint32_t c0 = hi1 ^ k0, c1 = lo1, c2 = (uint32_t)(pj >> 32) ^ k1, c3 = (uint32_t)pj;
+    k0 += PHILOX_W0;
+    k1 += PHILOX_W1;
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// global_* memory instructions for the table's pointers (the table holds int64: as generic
+// pointers they compile to flat_*, which also count against lgkmcnt — the counter the unit
+// loop's scalar loads of seeds and pointers wait on)
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+static __device__ __forceinline__ u32x4 ldg16_if(bool ok, const void* p, int64_t v) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (ok) r = ((const g_u32x4*)p)[v];
+    return r;
+}
+static __device__ __forceinline__ void stg16(void* p, int64_t v, const u32x4& x) { ((g_u32x4*)p)[v] = x; }
+static __device__ __forceinline__ void stg16_nt(void* p, int64_t v, const u32x4& x) {
+    __builtin_nontemporal_store(x, ((g_u32x4*)p) + v);
+}
+
+#ifndef ECO_K1_TORCH_WAVES
+#define ECO_K1_TORCH_WAVES 5
+#endif
 template <int DT>
-__global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_layers_kernel(
+__global__ __launch_bounds__(ECO_K1_THREADS) __attribute__((amdgpu_waves_per_eu(ECO_K1_TORCH_WAVES)))
+void zo_torch_layers_kernel(
     const int64_t* __restrict__ table, int n_layers, int64_t total_items, float eps) {
     constexpr int N = Vec<DT>::N;
     ECO_XCD_ITEM(Ig, total_items);
@@ -746,30 +820,63 @@ __global__ __launch_bounds__(ECO_K1_THREADS) void zo_torch_layers_kernel(
     const int64_t T = row[5];
     const int64_t nvec = n / N;
     const TorchLane L = torch_lane<N>(I, T, nvec);
+    // Rows of the item that hold any vector of the tensor: a prefix of the four (row ii + 1 lies
+    // T elements behind row ii) known from lane 0 (the wave's lowest vector of each row).  The
+    // LAST round of a tensor is rarely full — a 6144 x 1408 matrix is 16.5 rows of T = 524288:
+    // four full rounds and a fifth with half a row — and torch's own kernel draws and discards
+    // there; this one skips what no element needs: the item itself when it is empty, the second
+    // Box-Muller pair (rows 2 and 3) and the updates of absent rows.  Philox calls are per
+    // (round, subsequence) and cannot be cut.
+    int nv = 0;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) nv += __builtin_amdgcn_readfirstlane((int)L.ok[ii]);
+    const int64_t tail0 = nvec * N;                // ragged tail of this layer: its first wave
+    const bool has_tail = I == 0 && n != tail0;
+    if (nv == 0 && !has_tail) return;
     u32x4 s[4];
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) s[ii] = ld16_if(L.ok[ii], win, L.v[ii]);
-    for (int u = 0; u < n_units; ++u) {
+    for (int ii = 0; ii < 4; ++ii) s[ii] = ldg16_if(L.ok[ii], win, L.v[ii]);
+    uint32_t hi1[N], lo1[N];                       // M1 * idx: the key-independent half of Philox round 1
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * (L.idx0 + t);
+        hi1[t] = (uint32_t)(p1 >> 32);
+        lo1[t] = (uint32_t)p1;
+    }
+    for (int u = 0; u < n_units && nv > 0; ++u) {
         const uint64_t seed = (uint64_t)row[6 + u];
+        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
         float z[4 * N];
-        torch_z_tile<DT>(L.j, L.idx0, (uint32_t)seed, (uint32_t)(seed >> 32), z);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            uint32_t w[4];
+            philox4x32_10_r1(L.j, hi1[t], lo1[t], k0, k1, w);
+            torch_box_muller(w[0], w[1], z[0 * N + t], z[1 * N + t]);
+            if (nv > 2) torch_box_muller(w[2], w[3], z[2 * N + t], z[3 * N + t]);
+        }
         void* dp = (void*)row[6 + ECOFLAP_MAX_UNITS + u];
         void* dm = (void*)row[6 + 2 * ECOFLAP_MAX_UNITS + u];
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
+            if (ii >= nv) break;                   // wave-uniform
+            // ATen: static_cast<scalar_t>(...), one rounding to the storage dtype
+            if constexpr (DT != ECOFLAP_F32) {
+#pragma unroll
+                for (int i = 0; i < N; i += 2)
+                    Vec<DT>::round_pair(z[ii * N + i], z[ii * N + i + 1], z[ii * N + i], z[ii * N + i + 1]);
+            }
             u32x4 p, m;
             unit_update<DT, true>(s[ii], z + ii * N, eps, p, m);
             if (dp && L.ok[ii]) {   // dp wave-uniform: not-owned units only carry the drift
-                st16_nt(dp, L.v[ii], p);
-                st16_nt(dm, L.v[ii], m);
+                stg16_nt(dp, L.v[ii], p);
+                stg16_nt(dm, L.v[ii], m);
             }
         }
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-        if (L.ok[ii]) st16(wout, L.v[ii], s[ii]);
-    const int64_t tail0 = nvec * N;                // ragged tail of this layer: its first wave
-    if (I == 0 && threadIdx.x < (unsigned)(n - tail0)) {
+        if (L.ok[ii]) stg16(wout, L.v[ii], s[ii]);
+    if (has_tail && threadIdx.x < (unsigned)(n - tail0)) {
         const int64_t e = tail0 + threadIdx.x;
         float a = Vec<DT>::load1(win, e);
         for (int u = 0; u < n_units; ++u) {
@@ -1072,6 +1179,32 @@ extern "C" int ecoflap_zo_perturb_layers_torch(const int64_t* table, int n_layer
                               0, s, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, table, n_layers,
                               total_items, zo_eps);
     });
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
+// every word of [first, first + count): the shipped radius against rocRAND's restated one
+__global__ __launch_bounds__(256) void torch_radius_sweep_kernel(uint64_t first, uint64_t count,
+                                                                  unsigned long long* __restrict__ differ) {
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t x = (uint32_t)(first + i);
+        bad += __float_as_uint(torch_radius(x)) != __float_as_uint(torch_radius_reference(x));
+    }
+    bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(differ, bad);
+}
+
+extern "C" int ecoflap_zo_torch_radius_sweep(uint64_t first_word, uint64_t n_words,
+                                             unsigned long long* differ, void* stream) {
+    if (first_word > 0xffffffffull || n_words > (1ull << 32) - first_word) return ECOFLAP_ESIZE;
+    if (n_words == 0) return 0;
+    if (!differ) return ECOFLAP_ENULL;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(torch_radius_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       first_word, n_words, differ);
     ECO_CHECK_LAUNCH();
     return 0;
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "ecoflap_version", "ecoflap_error_string", "ecoflap_zo_perturb", "ecoflap_zo_perturb_triple",
     "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
     "ecoflap_zo_perturb_layers_z", "ecoflap_torch_normal_threads", "ecoflap_zo_fill_normal_torch",
-    "ecoflap_zo_perturb_torch", "ecoflap_zo_perturb_layers_torch",
+    "ecoflap_zo_perturb_torch", "ecoflap_zo_perturb_layers_torch", "ecoflap_zo_torch_radius_sweep",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_absprod_reduce_mixed", "ecoflap_colsqnorm_workspace_bytes",
@@ -96,6 +96,7 @@ def load_library():
     lib.ecoflap_zo_fill_normal_torch.argtypes = [vp, i64, ci, u64, i64, vp]
     lib.ecoflap_zo_perturb_torch.argtypes = [vp, i64, ci, f32, f32, u64, i64, vp]
     lib.ecoflap_zo_perturb_layers_torch.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
+    lib.ecoflap_zo_torch_radius_sweep.argtypes = [u64, u64, vp, vp]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
     lib.ecoflap_absprod_reduce_workspace_bytes.argtypes = [i64]
@@ -392,8 +393,10 @@ class HipKernels:
             cache = self._probe_cache = {}
         if key in cache:
             return cache[key]
+        # torch.manual_seed reseeds the CPU generator and the generator of EVERY GPU: all of them
+        # are put back (a single-process multi-GPU caller's other streams included)
         cpu_state = torch.get_rng_state()
-        gpu_state = torch.cuda.get_rng_state(device)
+        gpu_states = torch.cuda.get_rng_state_all()
         ok = True
         try:
             t_full = self.torch_normal_threads(1 << 40, device)
@@ -407,9 +410,20 @@ class HipKernels:
                                                  got.view(torch.int16 if dt != torch.float32 else torch.int32)))
         finally:
             torch.set_rng_state(cpu_state)
-            torch.cuda.set_rng_state(gpu_state, device)
+            torch.cuda.set_rng_state_all(gpu_states)
         cache[key] = ok
         return ok
+
+    def torch_radius_sweep(self, first_word=0, n_words=1 << 32, device=None):
+        """How many 32-bit words of [first_word, first_word + n_words) give a Box-Muller radius
+        that differs in any bit from rocRAND's own instruction sequence (the kernels compute it
+        with a shorter one; include/ecoflap_hip.h).  The whole domain by default."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        differ = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _check(self.lib.ecoflap_zo_torch_radius_sweep(int(first_word), int(n_words), _ptr(differ), _stream()),
+                   "ecoflap_zo_torch_radius_sweep")
+        return int(differ.item())
 
     def zo_perturb_layers_torch(self, layers, zo_eps, events=None):
         """Block-batched K1 with z = torch.normal's draw regenerated in registers: layers =

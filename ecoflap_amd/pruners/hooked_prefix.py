@@ -298,10 +298,16 @@ class HookedPrefixLoss:
         self._uninstall()
 
     def finish_run(self):
-        """Called by `LayerSparsity` before it reads the loss table: the assumptions made without
-        a host sync must have held."""
+        """Called by `LayerSparsity` before it reads the loss table: the instances get their
+        forwards back and the assumptions made without a host sync must have held."""
         self._keep_patched = False
         self._uninstall()
+        self.check_assumed()
+
+    def check_assumed(self):
+        """Read the checks that were queued without a host sync (one sync); raises if one failed.
+        No other effect: the forward patches stay as they are — `LayerSparsity` calls this before
+        every stage-1 checkpoint it writes, the lock-step guard after every entry block."""
         if self._assumed is not None and bool(self._assumed.item()):
             raise RuntimeError("HookedPrefixLoss: a check that was queued without a host sync failed (a "
                                "tensor assumed equal across the evaluations of a chunk differed, or the "
@@ -623,7 +629,7 @@ class HookedPrefixLoss:
             t1 = time.time()
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))
             self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t1
-            self.finish_run()
+            self.check_assumed()      # (not finish_run: the forward patches stay on for the layer's next chunks)
             if not same and every and len(sel) == k and not os.environ.get("ECOFLAP_VERIFY_BATCHED"):
                 # every chunk is being checked (small tensors: the probes cannot be trusted): the
                 # chunk takes its per-evaluation losses, the next chunk is checked again

@@ -223,7 +223,9 @@ class LayerSparsity:
         TORCH_Z marker (torch's stream in registers) or one tensor per unit."""
         if self.z_source == "philox":
             return None
-        if self._torch_z_in_registers(param):
+        # (2^31 elements or more: torch draws in several launches at advancing Philox offsets —
+        # not the single stream the kernels regenerate; those draws are torch's own, as in _draw_z)
+        if param.numel() < 2 ** 31 and self._torch_z_in_registers(param):
             return _hip.TORCH_Z
         return [self._draw_z(sd, param) for sd in seeds]
 
@@ -296,9 +298,16 @@ class LayerSparsity:
         import hashlib
         import json
         zsrc = self.z_source if isinstance(self.z_source, str) else "callable"
+        # (the loss closure and how many evaluations it batches are part of the identity: a table
+        # whose deferred lock-step checks failed is never written — `_save_stage1_checkpoint` —
+        # and the rerun that failure asks for, eval_batch=1, must not pick up a table of the
+        # batched run either)
+        eval_batch = getattr(self.loss_func, "eval_batch", None)
         head = {"zo_eps": float(self.noise_eps), "z_source": zsrc, "num_samples": int(self.num_samples),
                 "num_noise": int(self.num_noise), "n_batches": len(batches),
-                "dtypes": sorted({str(p.dtype) for p in params}), "score_method": str(self.score_method)}
+                "dtypes": sorted({str(p.dtype) for p in params}), "score_method": str(self.score_method),
+                "loss_closure": type(self.loss_func).__name__,
+                "eval_batch": None if eval_batch is None else int(eval_batch)}
         h = hashlib.sha256(json.dumps(head, sort_keys=True).encode())
         if params:
             sums = self._weight_sums(params, _hip.RED_ABSW)
@@ -320,6 +329,12 @@ class LayerSparsity:
         atomically.  complete: the pass is over — a later run with the same identity takes the
         whole table from the file and replays only the K1 drift."""
         import os
+        # checks the loss closure queued without a host sync (pruners/hooked_prefix.py) are read
+        # BEFORE the rows they cover reach the disk: a failed one raises here and the file keeps
+        # its last verified state
+        check = getattr(self.loss_func, "check_assumed", None)
+        if check is not None:
+            check()
         host = table.detach().float().cpu().numpy() if table is not None else np.zeros(self._table_shape,
                                                                                        np.float32)
         tmp = path + ".tmp.npz"

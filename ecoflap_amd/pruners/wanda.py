@@ -461,6 +461,11 @@ class _BlockwiseWanda:
                 if len(w_._pending) != 1 or w_.nsamples != 0:
                     return False
                 first[name] = w_._pending[0]
+            # (the eager path's guard, SparseGPT.flush: an input written in place after its hook saw
+            # it is not the tensor the reference reduced — leave the pass to that path, whose flush
+            # raises with the explanation)
+            if any(x0._version != ver0 for x0, _, ver0 in first.values()):
+                return False
             rings, static, slot = {}, {}, 1
             for name, (x0, b0, _) in first.items():
                 rings[name] = torch.empty((S_,) + tuple(x0.shape), dtype=x0.dtype, device=x0.device)
@@ -479,8 +484,10 @@ class _BlockwiseWanda:
 
             def recorder(name):
                 def add_batch(inp, out):
-                    x = inp.reshape((-1, inp.shape[-1]))
-                    static[name] = x if x.is_contiguous() else x.contiguous()
+                    # a copy taken INSIDE the capture: the graph records the value at hook time, so
+                    # a block that writes this input in place later in its forward cannot change
+                    # what reaches the ring after the replay
+                    static[name] = inp.reshape((-1, inp.shape[-1])).clone(memory_format=torch.contiguous_format)
                 return add_batch
 
             static_x = inps[0].clone()

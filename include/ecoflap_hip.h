@@ -192,6 +192,18 @@ int ecoflap_zo_perturb_layers_torch(const int64_t* table, int n_layers, int64_t 
                                     int dtype, float zo_eps, void* stream,
                                     void* start_event, void* stop_event);
 
+/* Self-check of the Box-Muller radius those kernels compute.  rocRAND's radius of a 32-bit word
+ * x is s(x) = sqrtf(-2 logf((x + 1) * 2^-32)) through ocml's logf and correctly rounded sqrtf;
+ * the kernels reach the same fp32 value with a shorter instruction sequence that is exact on
+ * this function's domain, not in general (csrc/zo_perturb.hip: torch_radius vs
+ * torch_radius_reference).  The domain is enumerable: this entry point evaluates both for the
+ * words [first_word, first_word + n_words) on the device and ADDS the number of words whose
+ * results differ in any bit to *differ (device memory, zeroed by the caller).  The whole range
+ * (first_word = 0, n_words = 2^32) runs in well under a second; tests/test_torch_stream.py
+ * asserts 0. */
+int ecoflap_zo_torch_radius_sweep(uint64_t first_word, uint64_t n_words,
+                                  unsigned long long* differ, void* stream);
+
 /* An empty kernel through the same instrumented launch: the floor of that event pair. */
 int ecoflap_null_launch_timed(void* stream, void* start_event, void* stop_event);
 

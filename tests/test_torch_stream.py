@@ -44,6 +44,17 @@ def test_thread_rule_of_atens_launch():
     assert lib.ecoflap_zo_perturb_layers_torch(vp(16), 1, 1, 1, 1e-3, None, vp(1), None) == -2
 
 
+def test_radius_sweep_argument_checks():
+    """ecoflap_zo_torch_radius_sweep refuses ranges outside the 2^32 words before any launch."""
+    from ecoflap_amd import hip
+    lib = hip.load_library()
+    vp = __import__("ctypes").c_void_p
+    assert lib.ecoflap_zo_torch_radius_sweep(1 << 32, 1, vp(16), None) == -3
+    assert lib.ecoflap_zo_torch_radius_sweep(5, 1 << 32, vp(16), None) == -3
+    assert lib.ecoflap_zo_torch_radius_sweep(0, 16, None, None) == -2
+    assert lib.ecoflap_zo_torch_radius_sweep(7, 0, None, None) == 0
+
+
 @pytest.fixture(scope="module")
 def kern():
     from ecoflap_amd import hip
@@ -54,6 +65,21 @@ def kern():
 BLIP2_SHAPES = [(4224, 1408), (1408, 1408), (6144, 1408), (2048, 2048), (5120, 2048)]
 RAGGED = [1, 3, 8, 255, 256, 257, 1003, 4099, 256 * 2048 - 8, 256 * 2048 + 3, 4 * 256 * 2048 + 4104,
           768 * 768, 2304 * 768 + 5]
+
+
+@pytest.mark.gpu
+def test_short_radius_sequence_equals_rocrands_on_every_32_bit_word(kern):
+    """The Box-Muller radius the kernels compute — two-instruction ln 2 product, v_rsq_f32 and one
+    Newton step on an exact residual, a v_max against +0 for the 128 words that round to u = 1
+    (csrc/zo_perturb.hip: torch_radius) — equals rocRAND's sqrtf(-2 logf(u)) as compiled into
+    torch's kernel (ocml's compensated logf product, correctly rounded sqrtf: torch_radius_reference)
+    for EVERY 32-bit word: the function's whole domain, enumerated on the device.  Bit for bit; the
+    shortcut is exact here, not in general, and this is its proof."""
+    assert kern.torch_radius_sweep(0, 1 << 32) == 0
+    # the words that round to u = 1 (x2 = 0), the first word, a mid-range slice
+    assert kern.torch_radius_sweep((1 << 32) - 256, 256) == 0
+    assert kern.torch_radius_sweep(0, 1) == 0
+    assert kern.torch_radius_sweep(0x7fff0000, 1 << 17) == 0
 
 
 @pytest.mark.gpu

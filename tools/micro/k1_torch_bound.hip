@@ -1,0 +1,402 @@
+// k1_torch_bound.hip — what bounds zo_torch_layers_kernel (K1 with torch's draw regenerated in
+// registers, the default mode) and which cheaper instruction sequences are bit-identical to it.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 \
+//       tools/micro/k1_torch_bound.hip -o tools/micro/k1_torch_bound
+//   tools/micro/k1_torch_bound radius      exhaustive: every 32-bit radius word, candidate radius
+//                                          sequences against the shipped one (rocRAND's, restated)
+//   tools/micro/k1_torch_bound time [U]    the product kernel next to flag-selected variants on the
+//                                          bench's block launches, cold buffers, HIP events
+//
+// Variants are flags of ONE restated kernel (F = 0 is instruction-for-instruction the shipped one
+// and is timed next to the shipped kernel itself as a control).
+#include "../../ecoflap_amd/csrc/zo_perturb.hip"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+enum {
+    F_NOSTORE = 1,    // VALU only: stores never taken
+    F_MEMONLY = 2,    // memory only: trivial arithmetic, same loads / stores
+    F_RAWSQRT = 4,    // v_sqrt_f32 without the correctly-rounded fix-up (NOT bit-exact: cost probe)
+    F_ROWSKIP = 8,    // skip the Box-Muller pairs / updates of rows past the end of the tensor
+    F_GLOBAL = 16,    // global_* instead of flat_* memory instructions
+    F_HOIST = 32,     // first Philox round's M1 * idx out of the unit loop
+    F_SHORTLOG = 64,  // two-instruction ln 2 product (NOT bit-exact: cost probe)
+    F_MARKSTEIN = 128 // rsq + one fma correction instead of sqrt + fix-up (cost probe)
+};
+
+// ------------------------------------------------------------------ radius sequences
+static __device__ __forceinline__ float radius_x2(uint32_t x) {
+    const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+    const float r = __builtin_amdgcn_logf(u);
+    const float m2ln2_hi = __uint_as_float(0xbfb17217u);
+    const float yl = r * m2ln2_hi;
+    float t = __builtin_fmaf(r, m2ln2_hi, -yl);
+    t = __builtin_fmaf(__uint_as_float(0xb3f7d1cfu), r, t);
+    return yl + t;
+}
+static __device__ __forceinline__ float radius_x2_short(uint32_t x) {
+    const float u = __builtin_fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+    const float r = __builtin_amdgcn_logf(u);
+    return __builtin_fmaf(r, __uint_as_float(0xbfb17217u), __uint_as_float(0xb3f7d1cfu) * r);
+}
+static __device__ __forceinline__ float sqrt_exact(float x2) {
+    const float s0 = __builtin_amdgcn_sqrtf(x2);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    const float rm = __builtin_fmaf(-sm, s0, x2), rp = __builtin_fmaf(-sp, s0, x2);
+    float s = (0.0f >= rm) ? sm : s0;
+    s = (0.0f < rp) ? sp : s;
+    return s;
+}
+static __device__ __forceinline__ float sqrt_markstein(float x2) {
+    const float y = __builtin_amdgcn_rsqf(x2);
+    const float g = x2 * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-g, g, x2);
+    return __builtin_fmaf(e, h, g);
+}
+// sqrt + ONE residual fma + sign-driven step: s0 +- 1 ulp when |x2 - s0^2| exceeds s0 * ulp(s0)
+static __device__ __forceinline__ float sqrt_onefma(float x2) {
+    const float s0 = __builtin_amdgcn_sqrtf(x2);
+    const float r0 = __builtin_fmaf(-s0, s0, x2);
+    // ulp(s0) * s0 = s0 scaled by 2^-23 of its own binade: exponent field arithmetic
+    const float t = __uint_as_float((__float_as_uint(s0) & 0x7f800000u) - (23u << 23)) * s0;
+    float s = (r0 <= -t) ? __uint_as_float(__float_as_uint(s0) - 1u) : s0;
+    s = (r0 > t) ? __uint_as_float(__float_as_uint(s0) + 1u) : s;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void radius_sweep(unsigned long long* cnt, uint32_t* examples) {
+    // cnt: 0 raw sqrt != exact, 1 markstein != exact (x2 > 0), 2 short log x2 != x2, 3 short log s != s,
+    //      4 x2 == 0 words, 5 onefma != exact, 6 raw sqrt off by more than 1 ulp
+    unsigned long long c[7] = {0, 0, 0, 0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const uint32_t x = (uint32_t)i;
+        const float x2 = radius_x2(x);
+        const float s = sqrt_exact(x2);
+        const float sr = __builtin_amdgcn_sqrtf(x2);
+        if (__float_as_uint(sr) != __float_as_uint(s)) {
+            if (c[0] == 0 && atomicAdd(&examples[0], 1u) < 8u) examples[8 + (atomicAdd(&examples[1], 1u) & 7u)] = x;
+            ++c[0];
+            const int d = (int)__float_as_uint(sr) - (int)__float_as_uint(s);
+            if (d > 1 || d < -1) ++c[6];
+        }
+        if (x2 > 0.0f) {
+            if (__float_as_uint(sqrt_markstein(x2)) != __float_as_uint(s)) ++c[1];
+        } else {
+            ++c[4];
+        }
+        const float x2s = radius_x2_short(x);
+        if (__float_as_uint(x2s) != __float_as_uint(x2)) ++c[2];
+        if (__float_as_uint(sqrt_exact(x2s)) != __float_as_uint(s)) ++c[3];
+        if (__float_as_uint(sqrt_onefma(x2)) != __float_as_uint(s)) ++c[5];
+    }
+    for (int k = 0; k < 7; ++k)
+        if (c[k]) atomicAdd(&cnt[k], c[k]);
+}
+
+static int run_radius() {
+    unsigned long long* cnt;
+    uint32_t* ex;
+    hipMalloc(&cnt, 7 * sizeof(unsigned long long));
+    hipMalloc(&ex, 16 * sizeof(uint32_t));
+    hipMemset(cnt, 0, 7 * sizeof(unsigned long long));
+    hipMemset(ex, 0, 16 * sizeof(uint32_t));
+    hipLaunchKernelGGL(radius_sweep, dim3(256 * 32), dim3(256), 0, 0, cnt, ex);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("radius sweep failed\n"); return 1; }
+    unsigned long long h[7];
+    uint32_t hx[16];
+    hipMemcpy(h, cnt, sizeof(h), hipMemcpyDeviceToHost);
+    hipMemcpy(hx, ex, sizeof(hx), hipMemcpyDeviceToHost);
+    printf("radius sweep over all 2^32 words (shipped sequence = rocRAND's as compiled into torch):\n");
+    printf("  raw v_sqrt_f32 != correctly rounded        : %llu  (more than 1 ulp: %llu)\n", h[0], h[6]);
+    printf("  rsq + one fma correction != correctly rnd  : %llu  (x2 > 0 only; x2 == 0 words: %llu)\n", h[1], h[4]);
+    printf("  sqrt + one residual fma + step != correct  : %llu\n", h[5]);
+    printf("  two-instruction ln2 product: x2 differs    : %llu,  s differs: %llu\n", h[2], h[3]);
+    printf("  first raw-sqrt mismatches:");
+    for (int i = 0; i < 8 && i < (int)hx[1]; ++i) printf(" %08x", hx[8 + i]);
+    printf("\n");
+    return 0;
+}
+
+// ------------------------------------------------------------------ the kernel, flag-selected
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+template <int F>
+static __device__ __forceinline__ u32x4 v_ld16_if(bool ok, const void* p, int64_t v) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (ok) {
+        if constexpr (F & F_GLOBAL) r = ((const g_u32x4*)p)[v];
+        else r = ld16(p, v);
+    }
+    return r;
+}
+template <int F>
+static __device__ __forceinline__ void v_st16(void* p, int64_t v, const u32x4& x) {
+    if constexpr (F & F_GLOBAL) ((g_u32x4*)p)[v] = x;
+    else st16(p, v, x);
+}
+template <int F>
+static __device__ __forceinline__ void v_st16_nt(void* p, int64_t v, const u32x4& x) {
+    if constexpr (F & F_GLOBAL) __builtin_nontemporal_store(x, ((g_u32x4*)p) + v);
+    else st16_nt(p, v, x);
+}
+
+template <int F>
+static __device__ __forceinline__ void v_box_muller(uint32_t x, uint32_t y, float& zs, float& zc, bool want_c) {
+    float x2;
+    if constexpr (F & F_SHORTLOG) x2 = radius_x2_short(x);
+    else x2 = radius_x2(x);
+    float s;
+    if constexpr (F & F_RAWSQRT) s = __builtin_amdgcn_sqrtf(x2);
+    else if constexpr (F & F_MARKSTEIN) s = sqrt_markstein(x2);
+    else s = sqrt_exact(x2);
+    const float v = __builtin_fmaf((float)y, __uint_as_float(0x30c90fdbu), __uint_as_float(0x30c90fdbu));
+    const float a = v * __uint_as_float(0x3e22f983u);
+    zs = __builtin_fmaf(__builtin_amdgcn_sinf(a), s, 0.0f);
+    if (want_c) zc = __builtin_fmaf(__builtin_amdgcn_cosf(a), s, 0.0f);
+}
+
+// Philox4x32-10 of counter {j, 0, idx, 0} from the first round's per-lane product (hi1, lo1) =
+// M1 * idx, which does not depend on the key
+static __device__ __forceinline__ void philox10_hoisted(uint32_t j, uint32_t hi1, uint32_t lo1, uint32_t k0,
+                                                        uint32_t k1, uint32_t out[4]) {
+    const uint64_t p0 = (uint64_t)PHILOX_M0 * j;
+    uint32_t c0 = hi1 ^ k0, c1 = lo1, c2 = (uint32_t)(p0 >> 32) ^ k1, c3 = (uint32_t)p0;
+    k0 += PHILOX_W0;
+    k1 += PHILOX_W1;
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+        const uint64_t q0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t q1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(q1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(q0 >> 32), c3, k1, 0x96);
+        c1 = (uint32_t)q1;
+        c3 = (uint32_t)q0;
+        c0 = n0;
+        c2 = n2;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int DT, int F>
+__global__ __launch_bounds__(ECO_K1_THREADS) void torch_layers_variant(const int64_t* __restrict__ table,
+                                                                      int n_layers, int64_t total_items,
+                                                                      float eps, int never) {
+    constexpr int N = Vec<DT>::N;
+    ECO_XCD_ITEM(Ig, total_items);
+    int l = 0;
+    while (l + 1 < n_layers && Ig >= table[(int64_t)(l + 1) * ECO_LAYER_ROW_T + 4]) ++l;
+    const int64_t* __restrict__ row = table + (int64_t)l * ECO_LAYER_ROW_T;
+    const void* win = (const void*)row[0];
+    void* wout = (void*)row[1];
+    const int64_t n = row[2];
+    const int n_units = (int)row[3];
+    const int64_t I = Ig - row[4];
+    const int64_t T = row[5];
+    const int64_t nvec = n / N;
+    const TorchLane L = torch_lane<N>(I, T, nvec);
+    int nv = 4;                                  // valid rows of this wave (a prefix; lane 0 is the lowest vector)
+    if constexpr (F & F_ROWSKIP) {
+        nv = 0;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) nv += __builtin_amdgcn_readfirstlane((int)L.ok[ii]);
+        if (nv == 0 && !(I == 0 && n != nvec * N)) return;
+    }
+    u32x4 s[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) s[ii] = v_ld16_if<F>(L.ok[ii], win, L.v[ii]);
+    uint32_t hi1[N], lo1[N];
+    if constexpr (F & F_HOIST) {
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const uint64_t p1 = (uint64_t)PHILOX_M1 * (L.idx0 + t);
+            hi1[t] = (uint32_t)(p1 >> 32);
+            lo1[t] = (uint32_t)p1;
+        }
+    }
+    for (int u = 0; u < n_units; ++u) {
+        const uint64_t seed = (uint64_t)row[6 + u];
+        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        void* dp = (void*)row[6 + ECOFLAP_MAX_UNITS + u];
+        void* dm = (void*)row[6 + 2 * ECOFLAP_MAX_UNITS + u];
+        if constexpr (F & F_MEMONLY) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const u32x4 p = s[ii] + k0, m = s[ii] ^ k0;
+                s[ii] = s[ii] + 1u;
+                if (dp && L.ok[ii]) {
+                    v_st16_nt<F>(dp, L.v[ii], p);
+                    v_st16_nt<F>(dm, L.v[ii], m);
+                }
+            }
+            continue;
+        }
+        float z[4 * N];
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            uint32_t w[4];
+            if constexpr (F & F_HOIST) philox10_hoisted(L.j, hi1[t], lo1[t], k0, k1, w);
+            else philox4x32_10(L.j, 0u, L.idx0 + t, 0u, k0, k1, w);
+            v_box_muller<F>(w[0], w[1], z[0 * N + t], z[1 * N + t], nv > 1);
+            if (nv > 2) v_box_muller<F>(w[2], w[3], z[2 * N + t], z[3 * N + t], nv > 3);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            if ((F & F_ROWSKIP) && ii >= nv) break;
+            if constexpr (DT != ECOFLAP_F32) {
+#pragma unroll
+                for (int i = 0; i < N; i += 2)
+                    Vec<DT>::round_pair(z[ii * N + i], z[ii * N + i + 1], z[ii * N + i], z[ii * N + i + 1]);
+            }
+            u32x4 p, m;
+            unit_update<DT, true>(s[ii], z + ii * N, eps, p, m);
+            bool store = dp && L.ok[ii];
+            if constexpr (F & F_NOSTORE) store = never != 0 && p[0] == 0x12345u && m[1] == 0x54321u;
+            if (store) {
+                v_st16_nt<F>(dp, L.v[ii], p);
+                v_st16_nt<F>(dm, L.v[ii], m);
+            }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        bool store = L.ok[ii];
+        if constexpr (F & F_NOSTORE) store = never != 0 && s[ii][0] == 0x7654321u;
+        if (store) v_st16<F>(wout, L.v[ii], s[ii]);
+    }
+}
+
+// ------------------------------------------------------------------ timing harness
+struct Block {
+    const char* name;
+    int dt;
+    std::vector<int64_t> numels;
+};
+
+struct BufSet {
+    std::vector<char*> w;          // per layer: [w | 2U scratch copies]
+    int64_t* table_dev;
+    int64_t total_items;
+    double bytes;
+};
+
+static BufSet make_set(const Block& b, int U, int64_t T, uint64_t seed0) {
+    BufSet S;
+    const int N = 8;
+    std::vector<int64_t> tab((size_t)b.numels.size() * ECO_LAYER_ROW_T, 0);
+    int64_t first = 0;
+    S.bytes = 0;
+    for (size_t l = 0; l < b.numels.size(); ++l) {
+        const int64_t n = b.numels[l];
+        const size_t bytes = (size_t)n * 2;
+        char* p;
+        if (hipMalloc(&p, (2 * U + 1) * bytes) != hipSuccess) { printf("alloc failed\n"); exit(1); }
+        hipMemset(p, 0x3c, (2 * U + 1) * bytes);
+        S.w.push_back(p);
+        int64_t* r = tab.data() + l * ECO_LAYER_ROW_T;
+        r[0] = (int64_t)p; r[1] = (int64_t)p; r[2] = n; r[3] = U; r[4] = first; r[5] = T;
+        for (int u = 0; u < U; ++u) {
+            r[6 + u] = (int64_t)(seed0 + 977 * l + u);
+            r[6 + ECOFLAP_MAX_UNITS + u] = (int64_t)(p + (size_t)(1 + 2 * u) * bytes);
+            r[6 + 2 * ECOFLAP_MAX_UNITS + u] = (int64_t)(p + (size_t)(2 + 2 * u) * bytes);
+        }
+        first += torch_items(n, T, N);
+        S.bytes += (2.0 * U + 2) * bytes;
+    }
+    S.total_items = first;
+    hipMalloc(&S.table_dev, tab.size() * sizeof(int64_t));
+    hipMemcpy(S.table_dev, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    return S;
+}
+
+template <int DT, int F>
+static void launch_v(const BufSet& S, int n_layers) {
+    hipLaunchKernelGGL((torch_layers_variant<DT, F>), dim3(grid_items(S.total_items)), dim3(ECO_K1_THREADS), 0, 0,
+                       S.table_dev, n_layers, S.total_items, 1e-3f, 0);
+}
+template <int DT>
+static void launch_shipped(const BufSet& S, int n_layers) {
+    hipLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items(S.total_items)), dim3(ECO_K1_THREADS), 0, 0,
+                       S.table_dev, n_layers, S.total_items, 1e-3f);
+}
+
+typedef void (*launch_fn)(const BufSet&, int);
+struct Variant {
+    const char* name;
+    launch_fn f16, bf16;
+};
+#define VAR(name, F) {name, launch_v<ECOFLAP_F16, F>, launch_v<ECOFLAP_BF16, F>}
+
+static int run_time(int U) {
+    const int64_t T = ecoflap_torch_normal_threads(1 << 30, 256, 2048);
+    const int64_t q = 2048 * 2048, wi = 5120 * 2048;
+    const Block blocks[] = {
+        {"vit_block f16 (qkv proj fc1 fc2)", ECOFLAP_F16, {4224 * 1408, 1408 * 1408, 6144 * 1408, 6144 * 1408}},
+        {"t5 4xqkvo + 2xwi bf16", ECOFLAP_BF16, {q, q, q, q, wi, wi}},
+        {"t5 lone pair 2xqkvo bf16", ECOFLAP_BF16, {q, q}},
+        {"t5 wo alone bf16", ECOFLAP_BF16, {wi}},
+    };
+    const Variant vars[] = {
+        {"shipped kernel", launch_shipped<ECOFLAP_F16>, launch_shipped<ECOFLAP_BF16>},
+        VAR("restated F=0", 0),
+        VAR("VALU only", F_NOSTORE),
+        VAR("memory only", F_MEMONLY),
+        VAR("global mem instrs", F_GLOBAL),
+        VAR("row skip", F_ROWSKIP),
+        VAR("hoist round 1", F_HOIST),
+        VAR("raw sqrt (inexact)", F_RAWSQRT),
+        VAR("markstein sqrt", F_MARKSTEIN),
+        VAR("short log (inexact)", F_SHORTLOG),
+        VAR("global+rowskip+hoist", F_GLOBAL | F_ROWSKIP | F_HOIST),
+        VAR("global+rowskip+hoist+markstein", F_GLOBAL | F_ROWSKIP | F_HOIST | F_MARKSTEIN),
+        VAR("global+rowskip+hoist+rawsqrt", F_GLOBAL | F_ROWSKIP | F_HOIST | F_RAWSQRT),
+        VAR("all + shortlog", F_GLOBAL | F_ROWSKIP | F_HOIST | F_RAWSQRT | F_SHORTLOG),
+        VAR("VALU only, all", F_NOSTORE | F_GLOBAL | F_ROWSKIP | F_HOIST | F_RAWSQRT | F_SHORTLOG),
+        VAR("VALU only, rowskip+hoist+markstein", F_NOSTORE | F_GLOBAL | F_ROWSKIP | F_HOIST | F_MARKSTEIN),
+        VAR("memory only, global", F_MEMONLY | F_GLOBAL),
+    };
+    printf("units %d, T %lld\n", U, (long long)T);
+    for (const Block& b : blocks) {
+        BufSet sets[2] = {make_set(b, U, T, 1000003ull), make_set(b, U, T, 7000003ull)};
+        hipDeviceSynchronize();
+        printf("%s: %.0f MB algorithmic per launch, %lld items\n", b.name, sets[0].bytes / 1e6,
+               (long long)sets[0].total_items);
+        for (const Variant& v : vars) {
+            std::vector<float> us;
+            for (int it = 0; it < 8; ++it) {
+                const BufSet& S = sets[it & 1];
+                hipEvent_t s, e;
+                hipEventCreate(&s); hipEventCreate(&e);
+                hipEventRecord(s);
+                (b.dt == ECOFLAP_F16 ? v.f16 : v.bf16)(S, (int)b.numels.size());
+                hipEventRecord(e);
+                hipEventSynchronize(e);
+                float ms;
+                hipEventElapsedTime(&ms, s, e);
+                hipEventDestroy(s); hipEventDestroy(e);
+                if (it >= 2) us.push_back(ms * 1e3f);
+            }
+            std::sort(us.begin(), us.end());
+            const double med = 0.5 * (us[2] + us[3]);
+            printf("  %-36s median %8.2f us  min %8.2f   %5.1f %% of 8 TB/s (median)\n", v.name, med, us[0],
+                   sets[0].bytes / med / 8e6 * 100.0);
+        }
+        for (BufSet& S : sets) {
+            for (char* p : S.w) hipFree(p);
+            hipFree(S.table_dev);
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "radius")) return run_radius();
+    if (argc > 1 && !strcmp(argv[1], "time")) return run_time(argc > 2 ? atoi(argv[2]) : 16);
+    printf("usage: k1_torch_bound radius | time [units]\n");
+    return 2;
+}
