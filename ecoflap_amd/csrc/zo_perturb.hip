@@ -685,8 +685,16 @@ static __device__ __forceinline__ TorchLane torch_lane(int64_t I, int64_t T, int
     return L;
 }
 static inline int64_t torch_items(int64_t n, int64_t T, int N) {
-    const int64_t rounds = (n + 4 * T - 1) / (4 * T), vpr = T / N;
-    return rounds * ((vpr + 63) / 64);
+    // full rounds take wpr items each; of the LAST round only the wave chunks that hold a vector
+    // of its first row (the items behind them are empty: torch's own kernel draws and discards
+    // there).  At least one item: item 0 also carries the ragged tail.
+    const int64_t rounds = (n + 4 * T - 1) / (4 * T), vpr = T / N, wpr = (vpr + 63) / 64, nvec = n / N;
+    if (rounds == 0) return 0;
+    int64_t row0 = nvec - 4 * (rounds - 1) * vpr;          // vectors in the last round's first row
+    if (row0 > vpr) row0 = vpr;
+    int64_t last = row0 > 0 ? (row0 + 63) / 64 : 0;
+    const int64_t items = (rounds - 1) * wpr + last;
+    return items > 0 ? items : 1;
 }
 static inline int torch_threads_ok(int64_t n, int64_t T) {
     // T = 256 * grid, grid <= ceil(n / 256); 32-bit subsequence indices.  n < 2^31: a larger tensor
@@ -803,12 +811,29 @@ static __device__ __forceinline__ void stg16_nt(void* p, int64_t v, const u32x4&
 #ifndef ECO_K1_TORCH_WAVES
 #define ECO_K1_TORCH_WAVES 5
 #endif
+// Workgroup -> work item of the block launch.  Workgroup b runs on XCD b % 8; XCD x takes the
+// 64-item blocks x, x + 8, x + 16, ... of the launch's item sequence (64 items = 64 KiB of every
+// stream of a row: long sequential runs per XCD, as the contiguous eighths of the other K1 kernels
+// give) — interleaved, not one contiguous eighth each, because items are NOT of equal cost here:
+// the light and empty items of a tensor's last round sit together at the end of each layer, and
+// with contiguous eighths whole XCDs ran out of work early (a ViT-g block: XCDs 4 and 7 held
+// 35-45 % light items; the launch took as long as the full ones, +12 %).
+#ifndef ECO_K1_XCD_BLOCK_LOG2
+#define ECO_K1_XCD_BLOCK_LOG2 6
+#endif
+static inline unsigned grid_items_blocked(int64_t items) {
+    const int64_t q = (int64_t)ECO_XCDS << ECO_K1_XCD_BLOCK_LOG2;
+    return (unsigned)((items + q - 1) / q * q);
+}
 template <int DT>
 __global__ __launch_bounds__(ECO_K1_THREADS) __attribute__((amdgpu_waves_per_eu(ECO_K1_TORCH_WAVES)))
 void zo_torch_layers_kernel(
     const int64_t* __restrict__ table, int n_layers, int64_t total_items, float eps) {
     constexpr int N = Vec<DT>::N;
-    ECO_XCD_ITEM(Ig, total_items);
+    const int64_t slot = blockIdx.x / ECO_XCDS;
+    const int64_t Ig = ((((slot >> ECO_K1_XCD_BLOCK_LOG2) * ECO_XCDS) + blockIdx.x % ECO_XCDS) << ECO_K1_XCD_BLOCK_LOG2)
+                       + (slot & ((1 << ECO_K1_XCD_BLOCK_LOG2) - 1));
+    if (Ig >= total_items) return;
     int l = 0;                                     // wave-uniform scan: scalar loads
     while (l + 1 < n_layers && Ig >= table[(int64_t)(l + 1) * ECO_LAYER_ROW_T + 4]) ++l;
     const int64_t* __restrict__ row = table + (int64_t)l * ECO_LAYER_ROW_T;
@@ -873,9 +898,18 @@ void zo_torch_layers_kernel(
             }
         }
     }
+    // the drifted weights: in place they hit the lines the loads brought in; PARKED in a buffer of
+    // their own (the block form: read back once, by a copy, after the layer's forwards) they are
+    // one more write-once stream and go out non-temporal like the unit buffers (-6 % per launch)
+    if (wout == win) {
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-        if (L.ok[ii]) stg16(wout, L.v[ii], s[ii]);
+        for (int ii = 0; ii < 4; ++ii)
+            if (L.ok[ii]) stg16(wout, L.v[ii], s[ii]);
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            if (L.ok[ii]) stg16_nt(wout, L.v[ii], s[ii]);
+    }
     if (has_tail && threadIdx.x < (unsigned)(n - tail0)) {
         const int64_t e = tail0 + threadIdx.x;
         float a = Vec<DT>::load1(win, e);
@@ -1123,6 +1157,11 @@ extern "C" int64_t ecoflap_torch_normal_threads(int64_t n, int multiprocessors, 
     return grid * 256;
 }
 
+extern "C" int64_t ecoflap_torch_layer_items(int64_t n, int64_t threads, int dtype) {
+    if (!dtype_ok(dtype) || n <= 0 || !torch_threads_ok(n, threads)) return 0;
+    return torch_items(n, threads, dtype == ECOFLAP_F32 ? 4 : 8);
+}
+
 static inline unsigned grid_items(int64_t items) {
     return (unsigned)((items + ECO_XCDS - 1) / ECO_XCDS * ECO_XCDS);
 }
@@ -1175,7 +1214,7 @@ extern "C" int ecoflap_zo_perturb_layers_torch(const int64_t* table, int n_layer
     if ((start_event == nullptr) != (stop_event == nullptr)) return ECOFLAP_ENULL;
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DT(dtype, {
-        hipExtLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items(total_items)), dim3(ECO_K1_THREADS),
+        hipExtLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items_blocked(total_items)), dim3(ECO_K1_THREADS),
                               0, s, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, table, n_layers,
                               total_items, zo_eps);
     });

@@ -23,6 +23,7 @@ EXPORTS = [
     "ecoflap_zo_perturb_units", "ecoflap_zo_perturb_units_timed", "ecoflap_null_launch_timed", "ecoflap_zo_perturb_layers",
     "ecoflap_zo_perturb_layers_z", "ecoflap_torch_normal_threads", "ecoflap_zo_fill_normal_torch",
     "ecoflap_zo_perturb_torch", "ecoflap_zo_perturb_layers_torch", "ecoflap_zo_torch_radius_sweep",
+    "ecoflap_torch_layer_items",
     "ecoflap_zo_fill_normal", "ecoflap_philox_u32", "ecoflap_absprod_reduce_workspace_bytes",
     "ecoflap_absprod_reduce", "ecoflap_absprod_reduce_multi_workspace_bytes",
     "ecoflap_absprod_reduce_multi", "ecoflap_absprod_reduce_mixed", "ecoflap_colsqnorm_workspace_bytes",
@@ -97,6 +98,8 @@ def load_library():
     lib.ecoflap_zo_perturb_torch.argtypes = [vp, i64, ci, f32, f32, u64, i64, vp]
     lib.ecoflap_zo_perturb_layers_torch.argtypes = [vp, ci, i64, ci, f32, vp, vp, vp]
     lib.ecoflap_zo_torch_radius_sweep.argtypes = [u64, u64, vp, vp]
+    lib.ecoflap_torch_layer_items.restype = i64
+    lib.ecoflap_torch_layer_items.argtypes = [i64, i64, ci]
     lib.ecoflap_philox_u32.argtypes = [vp, i64, u64, vp]
     lib.ecoflap_absprod_reduce_workspace_bytes.restype = sz
     lib.ecoflap_absprod_reduce_workspace_bytes.argtypes = [i64]
@@ -455,9 +458,10 @@ class HipKernels:
             if n >= 2 ** 31:       # (torch draws such a tensor in several launches at advancing offsets)
                 raise EcoflapHipError("zo_perturb_layers_torch: tensors of 2^31 elements or more take the "
                                       "materialised draw")
-            per_vec = 16 // w_in.element_size()
             threads = self.torch_normal_threads(n, w_in.device)
-            items = -(-n // (4 * threads)) * -(-(threads // per_vec) // 64)
+            items = int(self.lib.ecoflap_torch_layer_items(n, threads, DTYPE_CODE[dt]))
+            if items <= 0:
+                raise EcoflapHipError("zo_perturb_layers_torch: no work items for this tensor / thread count")
             row = [w_in.data_ptr(), w_final.data_ptr(), n, n_units, total, threads]
             row += [(int(x) & (2 ** 64 - 1)) - (2 ** 64 if (int(x) & (2 ** 63)) else 0) for x in seeds]
             row += [0] * (U - n_units)

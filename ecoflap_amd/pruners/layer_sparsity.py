@@ -418,6 +418,24 @@ class LayerSparsity:
                     if li - start > 1:
                         groups[start] = list(range(start, li))
                     start = li
+            # A run of fewer than three matrices (a block the caller selected only part of; a
+            # whole pass has none) is a launch too small to fill the chip for long — one wave
+            # round, and the clock ramp after the forward's GEMMs is a sixth of it: its K1 rides
+            # with the launch of the run in front of it when that one has the dtype (legal for
+            # the reason block batching is: K1 of a layer depends on its original weights and
+            # seeds only, and nothing writes those before the layer's own turn).
+            starts = sorted(set(groups) | {i for i in range(len(names))
+                                          if not any(i in g for g in groups.values())})
+            runs = [groups.get(st, [st]) for st in starts]
+            merged = []
+            for run_ in runs:
+                if (merged and len(run_) < 3 and len(merged[-1]) >= 3
+                        and params[run_[0]].dtype == params[merged[-1][0]].dtype
+                        and len(merged[-1]) + len(run_) <= 16):
+                    merged[-1] = merged[-1] + run_
+                else:
+                    merged.append(list(run_))
+            groups = {g[0]: g for g in merged if len(g) > 1}
         max_units = getattr(self.kernels, "MAX_UNITS", 32)
         ck_file = self._checkpoint_file(rank, world)
         if ck_file:

@@ -710,6 +710,7 @@ class _StageOneMixin:
         self.kernels = ls.kernels
         out = ls.return_sparsity()
         self.stage_stats["stage1"] = dict(ls.stats)
+        self.last_loss_table = ls.loss_table      # [units, 2] fp32 (zeroth order; None otherwise)
         if getattr(ls, "resumed_layers", 0):
             self.stage_stats["stage1"]["resumed_layers"] = ls.resumed_layers
         if hasattr(loss_func, "stats"):

@@ -179,12 +179,19 @@ int ecoflap_zo_fill_normal_torch(void* z_out, int64_t n, int dtype, uint64_t see
 int ecoflap_zo_perturb_torch(void* w, int64_t n, int dtype, float scaling_factor, float zo_eps,
                              uint64_t seed, int64_t threads, void* stream);
 
+/* Work items of one layer in ecoflap_zo_perturb_layers_torch's table: a tensor of n elements
+ * drawn by `threads` threads is R = ceil(n / (4*threads)) rounds; a full round is
+ * wpr = ceil(threads / (16/s) / 64) items (one wave each: the four 16-byte vectors per lane that
+ * one Philox call per element column feeds), of the last round only the ceil(v / 64) items that
+ * hold one of the v vectors of its first row (the rest are empty; torch's own kernel draws and
+ * discards there), at least 1 (item 0 also carries a ragged tail).  0 for invalid arguments. */
+int64_t ecoflap_torch_layer_items(int64_t n, int64_t threads, int dtype);
+
 /* ecoflap_zo_perturb_layers with z = that draw per unit.  table: DEVICE int64
  * [n_layers][6 + 3*ECOFLAP_MAX_UNITS], row = {w_in, w_final, numel, n_units, first_item, threads,
- * seeds[MAX_UNITS], w_plus[MAX_UNITS], w_minus[MAX_UNITS]}; a layer of numel elements drawn by
- * `threads` threads is items_l = ceil(numel / (4*threads)) * ceil(threads / (16/s) / 64) work
- * items (one wave each: the four 16-byte vectors per lane that one Philox call per element
- * column feeds); first_item = sum of the earlier layers' items, total_items = the sum over all.
+ * seeds[MAX_UNITS], w_plus[MAX_UNITS], w_minus[MAX_UNITS]}; items_l =
+ * ecoflap_torch_layer_items(numel, threads, dtype);
+ * first_item = sum of the earlier layers' items, total_items = the sum over all.
  * w_final may equal w_in and a unit's w_plus may alias w_in (a lane reads its elements before it
  * writes them), so this one entry point also serves the units form (one layer, in place) and the
  * triple form (one unit).  Algorithmic bytes: (2*owned_units + 2) * s per element: no z bytes. */

@@ -44,6 +44,32 @@ def test_thread_rule_of_atens_launch():
     assert lib.ecoflap_zo_perturb_layers_torch(vp(16), 1, 1, 1, 1e-3, None, vp(1), None) == -2
 
 
+def test_layer_items_count_the_items_that_hold_a_vector():
+    """ecoflap_torch_layer_items: full rounds take ceil(T / N / 64) items, the last round only the
+    wave chunks that hold a vector of its first row (the items behind them are empty), at least
+    one — against a brute-force count over the lane geometry of csrc/zo_perturb.hip (item I =
+    round j * wpr + chunk c owns vectors (4j + ii) * vpr + 64c + lane, ii = 0..3)."""
+    from ecoflap_amd import hip
+    lib = hip.load_library()
+    f = lib.ecoflap_torch_layer_items
+    T_full = 256 * 2048
+    for dt, N in ((1, 8), (2, 8), (0, 4)):
+        for n in (1, 3, 8, 255, 1003, 4099, T_full - 8, T_full + 3, 4 * T_full + 4104, 1408 * 1408, 4224 * 1408,
+                  6144 * 1408, 2048 * 2048, 5120 * 2048, 768 * 768, 2304 * 768 + 5):
+            T = 256 * min(2048, -(-n // 256))
+            vpr, nvec = T // N, n // N
+            wpr = -(-vpr // 64)
+            rounds = -(-n // (4 * T))
+            last = 0                                   # highest item with any valid vector, + 1
+            for j in range(rounds):
+                for c in range(wpr):
+                    if 64 * c < vpr and 4 * j * vpr + 64 * c < nvec:      # row 0, lane 0
+                        last = j * wpr + c + 1
+            assert f(n, T, dt) == max(last, 1), (n, dt)
+            assert f(n, T, dt) <= rounds * wpr
+    assert f(0, 256, 1) == 0 and f(1024, 100, 1) == 0 and f(1024, 1024, 9) == 0
+
+
 def test_radius_sweep_argument_checks():
     """ecoflap_zo_torch_radius_sweep refuses ranges outside the 2^32 words before any launch."""
     from ecoflap_amd import hip

@@ -285,7 +285,7 @@ struct BufSet {
     double bytes;
 };
 
-static BufSet make_set(const Block& b, int U, int64_t T, uint64_t seed0) {
+static BufSet make_set(const Block& b, int U, int64_t T, uint64_t seed0, bool parked = false) {
     BufSet S;
     const int N = 8;
     std::vector<int64_t> tab((size_t)b.numels.size() * ECO_LAYER_ROW_T, 0);
@@ -299,7 +299,12 @@ static BufSet make_set(const Block& b, int U, int64_t T, uint64_t seed0) {
         hipMemset(p, 0x3c, (2 * U + 1) * bytes);
         S.w.push_back(p);
         int64_t* r = tab.data() + l * ECO_LAYER_ROW_T;
-        r[0] = (int64_t)p; r[1] = (int64_t)p; r[2] = n; r[3] = U; r[4] = first; r[5] = T;
+        char* fin = p;
+        if (parked) {
+            if (hipMalloc(&fin, bytes) != hipSuccess) { printf("alloc failed\n"); exit(1); }
+            S.w.push_back(fin);
+        }
+        r[0] = (int64_t)p; r[1] = (int64_t)fin; r[2] = n; r[3] = U; r[4] = first; r[5] = T;
         for (int u = 0; u < U; ++u) {
             r[6 + u] = (int64_t)(seed0 + 977 * l + u);
             r[6 + ECOFLAP_MAX_UNITS + u] = (int64_t)(p + (size_t)(1 + 2 * u) * bytes);
@@ -321,7 +326,7 @@ static void launch_v(const BufSet& S, int n_layers) {
 }
 template <int DT>
 static void launch_shipped(const BufSet& S, int n_layers) {
-    hipLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items(S.total_items)), dim3(ECO_K1_THREADS), 0, 0,
+    hipLaunchKernelGGL((zo_torch_layers_kernel<DT>), dim3(grid_items_blocked(S.total_items)), dim3(ECO_K1_THREADS), 0, 0,
                        S.table_dev, n_layers, S.total_items, 1e-3f);
 }
 
@@ -394,7 +399,53 @@ static int run_time(int U) {
     return 0;
 }
 
+// the shipped kernel alone, parked finals as in the scoring loop, after a warm-up
+static int run_shipped(int U) {
+    const int64_t T = ecoflap_torch_normal_threads(1 << 30, 256, 2048);
+    const int64_t q = 2048 * 2048, wi = 5120 * 2048;
+    const Block blocks[] = {
+        {"vit_block f16 (qkv proj fc1 fc2)", ECOFLAP_F16, {4224 * 1408, 1408 * 1408, 6144 * 1408, 6144 * 1408}},
+        {"vit_block + next qkv proj f16", ECOFLAP_F16, {4224 * 1408, 1408 * 1408, 6144 * 1408, 6144 * 1408, 4224 * 1408, 1408 * 1408}},
+        {"t5 enc block bf16 (4 qkvo 3 wi/wo)", ECOFLAP_BF16, {q, q, q, q, wi, wi, wi}},
+        {"t5 4xqkvo + 2xwi bf16", ECOFLAP_BF16, {q, q, q, q, wi, wi}},
+        {"t5 dec 6xqkvo bf16", ECOFLAP_BF16, {q, q, q, q, q, q}},
+        {"t5 lone pair 2xqkvo bf16", ECOFLAP_BF16, {q, q}},
+    };
+    printf("shipped kernel, units %d, XCD block log2 %d, waves %d\n", U, ECO_K1_XCD_BLOCK_LOG2, ECO_K1_TORCH_WAVES);
+    for (const Block& b : blocks) {
+        for (int parked = 0; parked < 2; ++parked) {
+            BufSet sets[2] = {make_set(b, U, T, 1000003ull, parked), make_set(b, U, T, 7000003ull, parked)};
+            hipDeviceSynchronize();
+            std::vector<float> us;
+            for (int it = 0; it < 12; ++it) {
+                const BufSet& S = sets[it & 1];
+                hipEvent_t s, e;
+                hipEventCreate(&s); hipEventCreate(&e);
+                hipEventRecord(s);
+                (b.dt == ECOFLAP_F16 ? launch_shipped<ECOFLAP_F16> : launch_shipped<ECOFLAP_BF16>)(S, (int)b.numels.size());
+                hipEventRecord(e);
+                hipEventSynchronize(e);
+                float ms;
+                hipEventElapsedTime(&ms, s, e);
+                hipEventDestroy(s); hipEventDestroy(e);
+                if (it >= 4) us.push_back(ms * 1e3f);
+            }
+            std::sort(us.begin(), us.end());
+            const double med = 0.5 * (us[3] + us[4]);
+            printf("  %-36s %-8s %6lld items  median %8.2f us  min %8.2f   %5.1f %% of 8 TB/s (median)\n", b.name,
+                   parked ? "parked" : "in place", (long long)sets[0].total_items, med, us[0],
+                   sets[0].bytes / med / 8e6 * 100.0);
+            for (BufSet& S : sets) {
+                for (char* p : S.w) hipFree(p);
+                hipFree(S.table_dev);
+            }
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "shipped")) return run_shipped(argc > 2 ? atoi(argv[2]) : 16);
     if (argc > 1 && !strcmp(argv[1], "radius")) return run_radius();
     if (argc > 1 && !strcmp(argv[1], "time")) return run_time(argc > 2 ? atoi(argv[2]) : 16);
     printf("usage: k1_torch_bound radius | time [units]\n");
