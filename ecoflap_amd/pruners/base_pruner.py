@@ -113,6 +113,10 @@ class LayerWiseBasePruner(BasePruner):
             from ..shapes.fused import pin_linears
             pin_linears(model)
         if device.type == "cuda":
+            # which GEMM each weight shape runs is bound afresh for this run, as in a fresh process
+            # (shapes/fused.py: begin_run) — not inherited from whatever the process ran before
+            from ..shapes import fused
+            fused.begin_run()
             from .. import blas_guard
             # the GEMM library must be in its reproducible mode; batch invariance on top only
             # when evaluations are going to be concatenated

@@ -245,7 +245,22 @@ def multi_compare(pairs, flag=None):
 # ---- 16-bit Linears through hipBLASLt with the solution pinned per weight shape -----------------
 # (csrc/gemm_pinned.hip, include/ecoflap_shape_ops.h: why, and how the solution is chosen)
 _gemm = None            # libecoflap_gemm.so (None: not loaded yet; False: unavailable)
-_plans = {}             # (N, K, dtype, has_bias, bias dtype) -> dict (index, name, ...) or None = keep torch's GEMM
+_plans = {}             # (N, K, dtype) -> dict (index, name, ...) or None = keep torch's GEMM: THIS RUN's binding
+# What a weight shape is bound to is decided when the shape first comes up in a run, at the row
+# count it comes up with.  The decisions themselves are pure functions of their inputs (candidate
+# solutions in ascending index order, the first that measures batch invariant; the library's own
+# choice compared at 16 slots against one) and are remembered per (weight shape, epilogue, probe row
+# count) for the life of the process; the BINDING of a weight shape to one of them is per run
+# (`begin_run`, called where a pruner's prune() starts): a run in a process that has multiplied
+# the same weight shape at other row counts before — another model, a test at batch size 1 —
+# binds what a fresh process would bind, and ends with the same table.
+_plan_memo = {}         # (N, K, dtype, has_bias, bias dtype, probe rows) -> plan dict (without the per-run part) or None
+_invariance_memo = {}   # (N, K, dtype, has_bias, bias dtype, probe rows) -> bool: the library's own choice, 16 slots vs 1
+
+
+def begin_run():
+    """Forget which solution each weight shape is bound to (not the decisions: see above)."""
+    _plans.clear()
 _gemm_ws = {}           # stream -> workspace tensor
 
 
@@ -375,24 +390,29 @@ def linear(x, weight, bias, library_bias=None):
                         "library_batch_invariant": {}}
                        if (N % 128 == 0 and K % 32 == 0) else None)
     if key not in _plans:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError(f"pinned GEMM: the solution for weight shape {N}x{K} has not been "
-                               "chosen yet and a graph is being captured (run the stage eagerly once)")
-        idx, tried, passed = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
-        us, default_us = ctypes.c_float(0.0), ctypes.c_float(0.0)
-        name = ctypes.create_string_buffer(512)
-        torch.cuda.synchronize()
-        rc = lib.ecoflap_linear_pinned_plan(M if M <= 4096 else 2048, N, K, dt, int(bias is not None), bdt,
-                                            ctypes.byref(idx), ctypes.byref(tried), ctypes.byref(passed),
-                                            ctypes.byref(us), ctypes.byref(default_us), name, 512)
-        if rc == 0:
-            _plans[key] = {"index": idx.value, "name": name.value.decode(errors="replace"),
-                           "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value,
-                           "library_first_choice_us": default_us.value, "library_batch_invariant": {}}
-        elif rc == -3:          # ECOFLAP_ESIZE: no candidate survived; torch's GEMM for this shape
-            _plans[key] = None
-        else:
-            raise _hip.EcoflapHipError(f"ecoflap_linear_pinned_plan failed ({rc}) for {N}x{K}")
+        mp = M if M <= 4096 else 2048
+        memo_key = (N, K, weight.dtype, bias is not None, bdt, mp)
+        if memo_key not in _plan_memo:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"pinned GEMM: the solution for weight shape {N}x{K} has not been "
+                                   "chosen yet and a graph is being captured (run the stage eagerly once)")
+            idx, tried, passed = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
+            us, default_us = ctypes.c_float(0.0), ctypes.c_float(0.0)
+            name = ctypes.create_string_buffer(512)
+            torch.cuda.synchronize()
+            rc = lib.ecoflap_linear_pinned_plan(mp, N, K, dt, int(bias is not None), bdt,
+                                                ctypes.byref(idx), ctypes.byref(tried), ctypes.byref(passed),
+                                                ctypes.byref(us), ctypes.byref(default_us), name, 512)
+            if rc == 0:
+                _plan_memo[memo_key] = {"index": idx.value, "name": name.value.decode(errors="replace"),
+                                        "tried": tried.value, "passed": passed.value, "us_at_16_slots": us.value,
+                                        "library_first_choice_us": default_us.value, "probe_rows": mp}
+            elif rc == -3:          # ECOFLAP_ESIZE: no candidate survived; torch's GEMM for this shape
+                _plan_memo[memo_key] = None
+            else:
+                raise _hip.EcoflapHipError(f"ecoflap_linear_pinned_plan failed ({rc}) for {N}x{K}")
+        found = _plan_memo[memo_key]
+        _plans[key] = None if found is None else dict(found, library_batch_invariant={})
     plan = _plans[key]
     if plan is None:
         return None
@@ -401,22 +421,25 @@ def linear(x, weight, bias, library_bias=None):
     if has_lib_bias not in plan["library_batch_invariant"]:
         # what the framework's own choice does with this weight (and this epilogue) at the row
         # counts the loop uses: 16 slots against one alone, bit for bit
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError(f"pinned GEMM: weight shape {N}x{K} has not been probed yet and a "
-                               "graph is being captured (run the stage eagerly once)")
-        import torch.nn.functional as F
         mp = M if M <= 4096 else 2048
-        with torch.no_grad():
-            xs = x2[:mp].contiguous()
-            alone = F.linear(xs, weight, lib_bias)
-            many = F.linear(xs.repeat(16, 1), weight, lib_bias)
-            # fp32 (the Q-Former): the library treats the LAST rows of a problem differently at any
-            # size, which the loop's padding slots absorb at no cost; what the padding cannot absorb
-            # is a difference in the other slots (batch size 1)
-            last = 7 if weight.dtype == torch.float32 else 15
-            plan["library_batch_invariant"][has_lib_bias] = bool(
-                torch.equal(many[:mp], alone) and torch.equal(many[last * mp:(last + 1) * mp], alone))
-            del alone, many
+        inv_key = (N, K, weight.dtype, has_lib_bias, lib_bias.dtype if has_lib_bias else None, mp)
+        if inv_key not in _invariance_memo:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"pinned GEMM: weight shape {N}x{K} has not been probed yet and a "
+                                   "graph is being captured (run the stage eagerly once)")
+            import torch.nn.functional as F
+            with torch.no_grad():
+                xs = x2[:mp].contiguous()
+                alone = F.linear(xs, weight, lib_bias)
+                many = F.linear(xs.repeat(16, 1), weight, lib_bias)
+                # fp32 (the Q-Former): the library treats the LAST rows of a problem differently at any
+                # size, which the loop's padding slots absorb at no cost; what the padding cannot absorb
+                # is a difference in the other slots (batch size 1)
+                last = 7 if weight.dtype == torch.float32 else 15
+                _invariance_memo[inv_key] = bool(
+                    torch.equal(many[:mp], alone) and torch.equal(many[last * mp:(last + 1) * mp], alone))
+                del alone, many
+        plan["library_batch_invariant"][has_lib_bias] = _invariance_memo[inv_key]
     if not _pinned_wanted(plan, has_lib_bias):
         return None
     stream = torch.cuda.current_stream()
