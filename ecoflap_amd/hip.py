@@ -34,7 +34,7 @@ EXPORTS = [
     "ecoflap_wanda_prune_block", "ecoflap_wanda_fallback_counts",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block", "ecoflap_sparsegpt_block_nm",
-    "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum",
+    "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum", "ecoflap_cholesky_f32",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_global_prune_protected_workspace_bytes",
     "ecoflap_global_threshold_prune_protected", "ecoflap_count_zeros_multi",
@@ -147,6 +147,7 @@ def load_library():
     lib.ecoflap_global_threshold_prune_protected.argtypes = [vp, ci, ci, f32, i64, i64, vp, vp, sz, vp]
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
+    lib.ecoflap_cholesky_f32.argtypes = [vp, i64, i64, ci, vp, vp]
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
     lib.ecoflap_sparsegpt_block_nm.argtypes = [vp, i64, i64, vp, i64, i64, ci, ci, ci, vp, vp, vp]
     lib.ecoflap_hessian_workspace_bytes.restype = sz
@@ -800,6 +801,20 @@ class HipKernels:
             int(n), int(m), _ptr(err_out), _ptr(mask_out), _stream()), "ecoflap_sparsegpt_block_nm")
 
     # ---- K8 ---------------------------------------------------------------------------
+    def cholesky(self, H, upper=False):
+        """-> (factor, info): torch.linalg.cholesky_ex(H, upper=upper) by this library's blocked fp32
+        kernel (csrc/cholesky.hip) on a COPY of H — H itself is left as it is, for the caller's
+        damped retry.  info: python int, 0 or the 1-based index of the first non-positive pivot
+        (one host sync, as `int(info)` after cholesky_ex is)."""
+        _gpu(H, "H")
+        if H.dim() != 2 or H.shape[0] != H.shape[1] or H.dtype != torch.float32:
+            raise EcoflapHipError("cholesky: a square fp32 matrix")
+        L = H.clone()
+        info = torch.empty(1, dtype=torch.int32, device=H.device)
+        _check(self.lib.ecoflap_cholesky_f32(_ptr(L), L.shape[0], L.stride(0), int(bool(upper)), _ptr(info),
+                                             _stream()), "ecoflap_cholesky_f32")
+        return L, int(info.item())
+
     def hessian_accum(self, H, x2d, nsamples_before, batch):
         """H <- n/(n+b) H + 2/(n+b) x^T x on the matrix cores (fp16 / bf16 x, fp32 H)."""
         _gpu(H, "H")

@@ -93,13 +93,28 @@ class SparseGPT:
         if (torch.isinf(H) * (H < 0)).float().sum() > 0:
             H[torch.isinf(H) * (H < 0)] = torch.quantile(H, 0.001)
 
-    @staticmethod
-    def _damped_cholesky(H, damp, upper):
+    # The two Cholesky factorisations by this build's own blocked fp32 kernel (csrc/cholesky.hip,
+    # round 6) where the backend has one: rocSOLVER's potrf is latency-bound at these sizes (4-20 ms
+    # where the flops are worth 0.1-1.5) and not safe with two calls in flight.  The factor agrees
+    # with the library's to a few 1e-7 relative — fp32 factorisations re-associate — not bit for
+    # bit: the tests that hold the HIP backend to the oracle backend BIT FOR BIT switch this off so
+    # that both sides factor with the same library call (as they do for `use_mfma_hessian`).
+    use_own_cholesky = True
+
+    def _damped_cholesky(self, H, damp, upper):
         diag = torch.arange(H.shape[0], device=H.device)
+        own = (self.use_own_cholesky and H.is_cuda and H.dtype == torch.float32
+               and hasattr(self.kernels, "cholesky"))
         for _ in range(10000):                                    # the reference loops forever
-            L, info = torch.linalg.cholesky_ex(H, upper=upper)
-            if int(info) == 0 and not torch.isnan(L).any():
-                return L
+            if own:
+                # (a NaN anywhere in the lower triangle reaches a pivot and is reported there)
+                L, info = self.kernels.cholesky(H, upper=upper)
+                if info == 0:
+                    return L
+            else:
+                L, info = torch.linalg.cholesky_ex(H, upper=upper)
+                if int(info) == 0 and not torch.isnan(L).any():
+                    return L
             H[diag, diag] += damp                                 # not positive definite yet
         raise RuntimeError("Hessian could not be made positive definite")
 

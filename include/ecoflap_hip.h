@@ -419,6 +419,21 @@ int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, int64_t cols,
                           int dtype, int64_t nsamples_before, int64_t batch,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* SparseGPT's factorisations:
+ * replaces torch.linalg.cholesky(H) / torch.linalg.cholesky(Hinv, upper=True)
+ *     LAVIS/lavis/compression/pruners/sparsegpt_pruner.py:113-123, :146-155
+ * a <- the Cholesky factor of the symmetric fp32 matrix a[n, lda] (row-major, IN PLACE: copy
+ * first to keep the input, as the damped retry loop of the caller must; the LOWER triangle of the
+ * input is read).  upper = 0: L with a = L L^T, strict upper triangle zeroed; upper = 1: U = L^T
+ * with a = U^T U, strict lower triangle zeroed (torch.linalg.cholesky's two forms).
+ * *info (device int): 0, or LAPACK's potrf convention — the 1-based index of the first pivot
+ * that was not positive (or not a number): the matrix is not numerically positive definite and
+ * the contents of a are undefined.  No workspace, no handle, nothing shared between calls: two
+ * factorisations may be in flight on two streams.  Blocked right-looking, 64 columns per step,
+ * trailing updates on v_mfma_f32_32x32x2_f32, every sum in a fixed order (bit-repeatable).
+ * Agreement with rocSOLVER's factor: a few 1e-7 relative (fp32 factorisations re-associate). */
+int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* stream);
+
 /* ---------------------------------------------------------------------------
  * "Real-*" global iterative pruning
  * replaces, in layer_single_base_pruner.py:156-245 / :446-471, the per-element accumulator

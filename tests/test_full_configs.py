@@ -38,6 +38,10 @@ def test_config3_blip2_zeroth_order_full_size():
     import run_config
     a = run_config.run("3")
     torch.cuda.empty_cache()
+    if os.environ.get("ECOFLAP_DUMP_PLANS"):      # (diagnostic: what each weight shape was bound to)
+        import json
+        with open(os.environ["ECOFLAP_DUMP_PLANS"], "w") as f:
+            json.dump({"table_sha256": a["table_sha256"], "pinned_gemm": a["pinned_gemm"]}, f, default=str, indent=1)
     assert a["stage_stats"]["stage1"]["z_mode"] == "torch-registers"
     assert a["table_sha256"].startswith(CONFIG3_TABLE_SHA256_PREFIX), a["table_sha256"]
     _check_config3(a)

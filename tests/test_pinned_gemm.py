@@ -28,7 +28,22 @@ SHAPES = [  # (N, K, dtype, bias, rows of one evaluation)
 
 
 def _check_all():
-    os.environ["ECOFLAP_PINNED_GEMM"] = "1"      # every shape through its pinned solution, fast or not
+    # every shape through its pinned solution, fast or not — for THIS function only: until round 6
+    # the variable stayed set for the rest of the pytest process and every later run in it (a
+    # whole config 3 included) took the pinned solutions, ending with another table than a fresh
+    # process does (tests/test_full_configs.py)
+    before = os.environ.get("ECOFLAP_PINNED_GEMM")
+    os.environ["ECOFLAP_PINNED_GEMM"] = "1"
+    try:
+        return _check_all_pinned()
+    finally:
+        if before is None:
+            del os.environ["ECOFLAP_PINNED_GEMM"]
+        else:
+            os.environ["ECOFLAP_PINNED_GEMM"] = before
+
+
+def _check_all_pinned():
     from ecoflap_amd.shapes import fused
     import torch.nn.functional as F
     report = {}
