@@ -806,10 +806,12 @@ class HipKernels:
         kernel (csrc/cholesky.hip) on a COPY of H — H itself is left as it is, for the caller's
         damped retry.  info: python int, 0 or the 1-based index of the first non-positive pivot
         (one host sync, as `int(info)` after cholesky_ex is)."""
-        _gpu(H, "H")
+        if not isinstance(H, torch.Tensor) or H.device.type != "cuda":
+            _gpu(H, "H")
         if H.dim() != 2 or H.shape[0] != H.shape[1] or H.dtype != torch.float32:
             raise EcoflapHipError("cholesky: a square fp32 matrix")
-        L = H.clone()
+        # (torch.cholesky_inverse hands back a column-major tensor: the copy is row-major either way)
+        L = H.clone(memory_format=torch.contiguous_format)
         info = torch.empty(1, dtype=torch.int32, device=H.device)
         _check(self.lib.ecoflap_cholesky_f32(_ptr(L), L.shape[0], L.stride(0), int(bool(upper)), _ptr(info),
                                              _stream()), "ecoflap_cholesky_f32")

@@ -32,7 +32,7 @@ def main():
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
 
     def own(H, upper):
-        L = H.clone()
+        L = H.clone(memory_format=torch.contiguous_format)
         rc = kern.lib.ecoflap_cholesky_f32(L.data_ptr(), L.shape[0], L.stride(0), int(upper), info.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
         assert rc == 0
