@@ -322,6 +322,226 @@ __global__ __launch_bounds__(256) void chol_finalize_kernel(float* __restrict__ 
     }
 }
 
+// ================================================================================================
+// The inverse from the factor: out = (L L^T)^-1 = X^T X with X = L^-1   (torch.cholesky_inverse,
+// sparsegpt_pruner.py:134; rocSOLVER's potri: 7.2 / 13.0 ms at n = 5120 / 6144)
+//   1. the 64 x 64 diagonal blocks of X: one wave each, rows in registers, as the panel solve;
+//   2. the blocks below them by doubling: with X11 = inv(L11), X22 = inv(L22) known for two
+//      neighbouring diagonal blocks of size s, X21 = -X22 (L21 X11): two launches of tile GEMMs
+//      per level, log2(n / 64) levels, every pair of a level in one launch;
+//   3. out = X^T X on the tiles i >= j (k from the later of the two block rows), mirrored.
+// Every product on v_mfma_f32_32x32x2_f32, 64 x 64 tiles, K in chunks of 64 through LDS, every
+// sum in a fixed order.
+template <int T, int S0>
+static __device__ __forceinline__ void fmac8_regs(float (&b)[CH_NB], const float (&a)[CH_NB], float m) {
+    // b[S0 + k] += m * (a[S0 + k] of lane T), k = 0 .. 7
+    asm volatile(
+        "v_readlane_b32 s20, %8, %17\n\tv_readlane_b32 s21, %9, %17\n\tv_readlane_b32 s22, %10, %17\n\t"
+        "v_readlane_b32 s23, %11, %17\n\tv_readlane_b32 s24, %12, %17\n\tv_readlane_b32 s25, %13, %17\n\t"
+        "v_readlane_b32 s26, %14, %17\n\tv_readlane_b32 s27, %15, %17\n\t"
+        "v_fmac_f32 %0, s20, %16\n\tv_fmac_f32 %1, s21, %16\n\tv_fmac_f32 %2, s22, %16\n\tv_fmac_f32 %3, s23, %16\n\t"
+        "v_fmac_f32 %4, s24, %16\n\tv_fmac_f32 %5, s25, %16\n\tv_fmac_f32 %6, s26, %16\n\tv_fmac_f32 %7, s27, %16"
+        : "+v"(b[S0]), "+v"(b[S0 + 1]), "+v"(b[S0 + 2]), "+v"(b[S0 + 3]), "+v"(b[S0 + 4]), "+v"(b[S0 + 5]),
+          "+v"(b[S0 + 6]), "+v"(b[S0 + 7])
+        : "v"(a[S0]), "v"(a[S0 + 1]), "v"(a[S0 + 2]), "v"(a[S0 + 3]), "v"(a[S0 + 4]), "v"(a[S0 + 5]), "v"(a[S0 + 6]),
+          "v"(a[S0 + 7]), "v"(m), "n"(T)
+        : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+}
+template <int T, int S>
+static __device__ __forceinline__ void fmac1_reg(float (&b)[CH_NB], const float (&a)[CH_NB], float m) {
+    asm volatile("v_readlane_b32 s20, %1, %3\n\ts_nop 3\n\tv_fmac_f32 %0, s20, %2"
+                 : "+v"(b[S]) : "v"(a[S]), "v"(m), "n"(T) : "s20");
+}
+// b[s] += m * (a[s] of lane T) for s = S0 .. T - 1
+template <int T, int S0>
+static __device__ __forceinline__ void fmac_regs_below(float (&b)[CH_NB], const float (&a)[CH_NB], float m) {
+    if constexpr (S0 < T) {
+        if constexpr (S0 + 8 <= T) {
+            fmac8_regs<T, S0>(b, a, m);
+            fmac_regs_below<T, S0 + 8>(b, a, m);
+        } else {
+            fmac1_reg<T, S0>(b, a, m);
+            fmac_regs_below<T, S0 + 1>(b, a, m);
+        }
+    }
+}
+// row `lane` of inv(L): x L = e_lane, from the last column back; L[t][s] is a[s] of lane t
+template <int T>
+struct InverseStep {
+    static __device__ __forceinline__ void run(float (&b)[CH_NB], const float (&a)[CH_NB]) {
+        const float x = b[T] / lane_value(a[T], T);
+        b[T] = x;
+        fmac_regs_below<T, 0>(b, a, -x);
+        if constexpr (T > 0) InverseStep<T - 1>::run(b, a);
+    }
+};
+
+__global__ __launch_bounds__(64) void trinv_diag_kernel(const float* __restrict__ L, float* __restrict__ X,
+                                                        int64_t n, int64_t ldl, int64_t ldx) {
+    // full blocks only (host: the ragged last block goes to trinv_ragged_kernel)
+    const int lane = threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.x * CH_NB;
+    float a[CH_NB], b[CH_NB];
+    const float* p = L + (k0 + lane) * ldl + k0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        a[c] = c <= lane ? p[c] : 0.0f;
+        b[c] = c == lane ? 1.0f : 0.0f;
+    }
+    InverseStep<CH_NB - 1>::run(b, a);
+    float* q = X + (k0 + lane) * ldx + k0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) q[c] = c <= lane ? b[c] : 0.0f;
+}
+
+__global__ __launch_bounds__(64) void trinv_ragged_kernel(const float* __restrict__ L, float* __restrict__ X,
+                                                          int64_t n, int64_t ldl, int64_t ldx, int64_t k0) {
+    // the last, partial diagonal block: row i of inv(L) by thread i, L through LDS
+    __shared__ float Ls[CH_NB][CH_LD];
+    const int i = threadIdx.x, m = (int)(n - k0);
+    for (int c = 0; c < CH_NB; ++c) Ls[i][c] = (i < m && c < m && c <= i) ? L[(k0 + i) * ldl + k0 + c] : (i == c ? 1.0f : 0.0f);
+    __syncthreads();
+    float b[CH_NB];
+    for (int c = 0; c < CH_NB; ++c) b[c] = c == i ? 1.0f : 0.0f;
+    for (int t = CH_NB - 1; t >= 0; --t) {
+        const float x = b[t] / Ls[t][t];
+        b[t] = x;
+        for (int s_ = 0; s_ < t; ++s_) b[s_] -= x * Ls[t][s_];
+    }
+    if (i < m)
+        for (int c = 0; c < m; ++c) X[(k0 + i) * ldx + k0 + c] = c <= i ? b[c] : 0.0f;
+}
+
+// One 64 x 64 tile of C = alpha * op(A) B over k in [k_lo, k_hi): A [i][k] (TA: stored [k][i]),
+// B stored [k][j].  Rows / columns / k past the given extents read as zeros.
+template <bool TA>
+static __device__ __forceinline__ void tile_gemm(const float* __restrict__ Ap, int64_t lda, int64_t a_rows,
+                                                 const float* __restrict__ Bp, int64_t ldb, int64_t b_cols,
+                                                 int64_t k_lo, int64_t k_hi, f32x16& acc, float* As, float* Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1, r32 = lane & 31, kh = lane >> 5;
+    for (int64_t kc = k_lo; kc < k_hi; kc += CH_NB) {
+        __syncthreads();                                   // the previous chunk's operands are consumed
+        for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+            if constexpr (TA) {
+                const int k = e >> 6, i = e & 63;          // global [k][i]: consecutive threads along i
+                As[i * CH_PK + k] = (kc + k < k_hi && i < a_rows) ? Ap[(kc + k) * lda + i] : 0.0f;
+            } else {
+                const int i = e >> 6, k = e & 63;          // global [i][k]: consecutive threads along k
+                As[i * CH_PK + k] = (kc + k < k_hi && i < a_rows) ? Ap[i * lda + kc + k] : 0.0f;
+            }
+            const int k = e >> 6, j = e & 63;              // global [k][j]: consecutive threads along j
+            Bs[j * CH_PK + k] = (kc + k < k_hi && j < b_cols) ? Bp[(kc + k) * ldb + j] : 0.0f;
+        }
+        __syncthreads();
+        const float* A2 = &As[(32 * wy + r32) * CH_PK + 2 * kh];
+        const float* B2 = &Bs[(32 * wx + r32) * CH_PK + 2 * kh];
+#pragma unroll
+        for (int q = 0; q < CH_NB / 4; ++q) {
+            const f32x2 av = *(const f32x2*)(A2 + 4 * q);
+            const f32x2 bv = *(const f32x2*)(B2 + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc, 0, 0, 0);
+        }
+    }
+}
+
+// level of the doubling: pair z owns the diagonal blocks A = [2 z s, 2 z s + s) and B = [2 z s + s,
+// min(2 z s + 2 s, n)).  MODE 0: T = L[B, A] X[A, A] (X[A, A] lower: k from the tile's column on);
+// MODE 1: X[B, A] = -X[B, B] T (X[B, B] lower: k up to the tile's row).  T: [pairs][s][s] floats.
+template <int MODE>
+__global__ __launch_bounds__(256) void trinv_level_kernel(const float* __restrict__ L, int64_t ldl,
+                                                          float* __restrict__ X, int64_t ldx,
+                                                          float* __restrict__ T, int64_t n, int64_t s) {
+    __shared__ __attribute__((aligned(16))) float As[CH_NB * CH_PK];
+    __shared__ __attribute__((aligned(16))) float Bs[CH_NB * CH_PK];
+    const int64_t a0 = 2 * (int64_t)blockIdx.z * s, b0 = a0 + s;
+    const int64_t mb = (b0 + s <= n ? s : n - b0);          // rows of B (<= 0: this pair has no second block)
+    const int64_t ti = (int64_t)blockIdx.y * CH_NB, tj = (int64_t)blockIdx.x * CH_NB;   // tile origin in (B rows, A cols)
+    if (mb <= 0 || ti >= mb) return;
+    float* Tp = T + (int64_t)blockIdx.z * s * s;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int64_t rows = mb - ti < CH_NB ? mb - ti : CH_NB;
+    if constexpr (MODE == 0) {
+        // T[ti.., tj..] = sum_{k >= tj} L[b0 + ti.., a0 + k] X[a0 + k, a0 + tj..]
+        tile_gemm<false>(L + (b0 + ti) * ldl + a0, ldl, rows, X + a0 * ldx + a0 + tj, ldx, CH_NB, tj, s, acc, As, Bs);
+    } else {
+        // X[b0 + ti.., a0 + tj..] = -sum_{k < ti + 64} X[b0 + ti.., b0 + k] T[k, tj..]
+        const int64_t kh_ = ti + CH_NB < mb ? ti + CH_NB : mb;
+        tile_gemm<false>(X + (b0 + ti) * ldx + b0, ldx, rows, Tp + tj, s, CH_NB, 0, kh_, acc, As, Bs);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wy = wave >> 1, wx = wave & 1, r32 = lane & 31, kh = lane >> 5;
+    const int64_t col = tj + 32 * wx + r32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = ti + 32 * wy + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < mb) {
+            if constexpr (MODE == 0) Tp[row * s + col] = acc[r];
+            else X[(b0 + row) * ldx + a0 + col] = -acc[r];
+        }
+    }
+}
+
+// out = X^T X, X lower triangular: out[i][j] = sum_{t >= max(i, j)} X[t][i] X[t][j]; tiles I >= J, mirrored
+__global__ __launch_bounds__(256) void lauum_kernel(const float* __restrict__ X, int64_t ldx, float* __restrict__ out,
+                                                    int64_t ldo, int64_t n) {
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (J > I) return;
+    __shared__ __attribute__((aligned(16))) float As[CH_NB * CH_PK];
+    __shared__ __attribute__((aligned(16))) float Bs[CH_NB * CH_PK];
+    const int64_t i0 = (int64_t)I * CH_NB, j0 = (int64_t)J * CH_NB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int64_t rows = n - i0 < CH_NB ? n - i0 : CH_NB, cols = n - j0 < CH_NB ? n - j0 : CH_NB;
+    // A^T[i][t] = X[t][i0 + i] (stored [t][i]); B[t][j] = X[t][j0 + j]; t from i0 (X[t][i] = 0 for t < i)
+    tile_gemm<true>(X + i0 * ldx + i0, ldx, rows, X + i0 * ldx + j0, ldx, cols, 0, n - i0, acc, As, Bs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wy = wave >> 1, wx = wave & 1, r32 = lane & 31, kh = lane >> 5;
+    const int64_t col = j0 + 32 * wx + r32;
+    if (col >= n) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + 32 * wy + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < n) {
+            if (I != J || col <= row) out[row * ldo + col] = acc[r];
+            if (I != J || col < row) out[col * ldo + row] = acc[r];
+        }
+    }
+}
+
+extern "C" size_t ecoflap_cholesky_inverse_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    const size_t nn = (size_t)n * (size_t)n;
+    return (nn + nn / 2 + 4096) * sizeof(float);       // X, and the level products T
+}
+
+extern "C" int ecoflap_cholesky_inverse_f32(const float* l, int64_t n, int64_t ldl, float* out, int64_t ldo,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || ldl < n || ldo < n || n > (1 << 20)) return ECOFLAP_ESIZE;
+    if (n == 0) return 0;
+    if (!l || !out || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_cholesky_inverse_workspace_bytes(n)) return ECOFLAP_ESIZE;
+    hipStream_t s = (hipStream_t)stream;
+    float* X = (float*)workspace;
+    float* T = X + (size_t)n * (size_t)n;
+    const int64_t full = n / CH_NB, nb = (n + CH_NB - 1) / CH_NB;
+    if (hipMemsetAsync(X, 0, (size_t)n * (size_t)n * sizeof(float), s) != hipSuccess) return ECOFLAP_ENULL;
+    if (full > 0) hipLaunchKernelGGL(trinv_diag_kernel, dim3((unsigned)full), dim3(64), 0, s, l, X, n, ldl, n);
+    if (nb > full) hipLaunchKernelGGL(trinv_ragged_kernel, dim3(1), dim3(64), 0, s, l, X, n, ldl, n, full * CH_NB);
+    for (int64_t sz = CH_NB; sz < n; sz *= 2) {
+        const unsigned pairs = (unsigned)((n + 2 * sz - 1) / (2 * sz)), t = (unsigned)(sz / CH_NB);
+        hipLaunchKernelGGL(trinv_level_kernel<0>, dim3(t, t, pairs), dim3(256), 0, s, l, ldl, X, n, T, n, sz);
+        hipLaunchKernelGGL(trinv_level_kernel<1>, dim3(t, t, pairs), dim3(256), 0, s, l, ldl, X, n, T, n, sz);
+    }
+    hipLaunchKernelGGL(lauum_kernel, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, s, X, n, out, ldo, n);
+    ECO_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* stream) {
     if (n < 0 || lda < n || n > (1 << 20)) return ECOFLAP_ESIZE;
     if (!info) return ECOFLAP_ENULL;

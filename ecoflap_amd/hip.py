@@ -35,6 +35,7 @@ EXPORTS = [
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block", "ecoflap_sparsegpt_block_nm",
     "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum", "ecoflap_cholesky_f32",
+    "ecoflap_cholesky_inverse_workspace_bytes", "ecoflap_cholesky_inverse_f32",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_global_prune_protected_workspace_bytes",
     "ecoflap_global_threshold_prune_protected", "ecoflap_count_zeros_multi",
@@ -148,6 +149,9 @@ def load_library():
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
     lib.ecoflap_cholesky_f32.argtypes = [vp, i64, i64, ci, vp, vp]
+    lib.ecoflap_cholesky_inverse_workspace_bytes.restype = sz
+    lib.ecoflap_cholesky_inverse_workspace_bytes.argtypes = [i64]
+    lib.ecoflap_cholesky_inverse_f32.argtypes = [vp, i64, i64, vp, i64, vp, sz, vp]
     lib.ecoflap_sparsegpt_block.argtypes = [vp, i64, i64, vp, i64, i64, ci, i64, vp, vp, vp, vp, sz, vp]
     lib.ecoflap_sparsegpt_block_nm.argtypes = [vp, i64, i64, vp, i64, i64, ci, ci, ci, vp, vp, vp]
     lib.ecoflap_hessian_workspace_bytes.restype = sz
@@ -816,6 +820,22 @@ class HipKernels:
         _check(self.lib.ecoflap_cholesky_f32(_ptr(L), L.shape[0], L.stride(0), int(bool(upper)), _ptr(info),
                                              _stream()), "ecoflap_cholesky_f32")
         return L, int(info.item())
+
+    def cholesky_inverse(self, L):
+        """torch.cholesky_inverse(L) for a lower fp32 factor on the GPU (csrc/cholesky.hip): a new,
+        symmetric, row-major tensor."""
+        if not isinstance(L, torch.Tensor) or L.device.type != "cuda":
+            _gpu(L, "L")
+        if L.dim() != 2 or L.shape[0] != L.shape[1] or L.dtype != torch.float32:
+            raise EcoflapHipError("cholesky_inverse: a square fp32 matrix")
+        Lc = L if L.is_contiguous() else L.contiguous()
+        n = Lc.shape[0]
+        out = torch.empty((n, n), dtype=torch.float32, device=L.device)
+        nb = int(self.lib.ecoflap_cholesky_inverse_workspace_bytes(n))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=L.device)
+        _check(self.lib.ecoflap_cholesky_inverse_f32(_ptr(Lc), n, Lc.stride(0), _ptr(out), out.stride(0), _ptr(ws),
+                                                     ws.numel(), _stream()), "ecoflap_cholesky_inverse_f32")
+        return out
 
     def hessian_accum(self, H, x2d, nsamples_before, batch):
         """H <- n/(n+b) H + 2/(n+b) x^T x on the matrix cores (fp16 / bf16 x, fp32 H)."""

@@ -101,6 +101,12 @@ class SparseGPT:
     # that both sides factor with the same library call (as they do for `use_mfma_hessian`).
     use_own_cholesky = True
 
+    def _cholesky_inverse(self, L):
+        if (self.use_own_cholesky and L.is_cuda and L.dtype == torch.float32
+                and hasattr(self.kernels, "cholesky_inverse")):
+            return self.kernels.cholesky_inverse(L)
+        return torch.cholesky_inverse(L)
+
     def _damped_cholesky(self, H, damp, upper):
         diag = torch.arange(H.shape[0], device=H.device)
         own = (self.use_own_cholesky and H.is_cuda and H.dtype == torch.float32
@@ -147,7 +153,7 @@ class SparseGPT:
         self._clamp_inf(H)
         damp = percdamp * torch.mean(torch.diag(H))
         H = self._damped_cholesky(H, damp, upper=False)
-        H = torch.cholesky_inverse(H)
+        H = self._cholesky_inverse(H)
         self._clamp_inf(H)
         damp = percdamp * torch.mean(torch.diag(H).abs())
         self.factor = (dead, self._damped_cholesky(H, damp, upper=True).contiguous())
@@ -181,7 +187,7 @@ class SparseGPT:
                 with PhaseTimer.span("sparsegpt.factor.cholesky_lower"):
                     H = self._damped_cholesky(H, damp, upper=False)
                 with PhaseTimer.span("sparsegpt.factor.cholesky_inverse"):
-                    H = torch.cholesky_inverse(H)
+                    H = self._cholesky_inverse(H)
                 with PhaseTimer.span("sparsegpt.factor.clamp_inf (isinf scans + host syncs)"):
                     self._clamp_inf(H)
                 damp = percdamp * torch.mean(torch.diag(H).abs())

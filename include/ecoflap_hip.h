@@ -434,6 +434,17 @@ int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, int64_t cols,
  * Agreement with rocSOLVER's factor: a few 1e-7 relative (fp32 factorisations re-associate). */
 int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* stream);
 
+/* replaces torch.cholesky_inverse(L)   sparsegpt_pruner.py:134
+ * out[n, ldo] <- (L L^T)^-1, both triangles, from the LOWER Cholesky factor l[n, ldl] (fp32,
+ * row-major; only its lower triangle is read; out may not alias l).  X = L^-1 by the 64 x 64
+ * diagonal blocks (one wave each, in registers) and doubling below them (X21 = -X22 L21 X11, tile
+ * GEMMs on v_mfma_f32_32x32x2_f32), then out = X^T X.  workspace: caller-owned scratch of
+ * ecoflap_cholesky_inverse_workspace_bytes(n) bytes (1.5 n^2 floats), contents undefined
+ * afterwards.  Fixed summation order; nothing shared between calls. */
+size_t ecoflap_cholesky_inverse_workspace_bytes(int64_t n);
+int ecoflap_cholesky_inverse_f32(const float* l, int64_t n, int64_t ldl, float* out, int64_t ldo,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * "Real-*" global iterative pruning
  * replaces, in layer_single_base_pruner.py:156-245 / :446-471, the per-element accumulator

@@ -49,14 +49,19 @@ def main():
         sc = float(ref.abs().max())
         e_lib, e_own = float((L_lib.double() - ref).abs().max()) / sc, float((L_own.double() - ref).abs().max()) / sc
         t_inv, Hi = timed(lambda: torch.cholesky_inverse(L_own))
+        t_inv_own, Hi_own = timed(lambda: kern.cholesky_inverse(L_own))
+        ref_i = torch.cholesky_inverse(L_own.double())
+        sci = float(ref_i.abs().max())
+        ei_lib, ei_own = float((Hi.double() - ref_i).abs().max()) / sci, float((Hi_own.double() - ref_i).abs().max()) / sci
+        del ref_i
         t_ulib, _ = timed(lambda: torch.linalg.cholesky_ex(Hi, upper=True)[0])
         t_uown, U_own = timed(lambda: own(Hi, True))
         assert int(info) == 0
         chain_lib = t_lib + t_inv + t_ulib
-        chain_own = t_own + t_inv + t_uown
+        chain_own = t_own + t_inv_own + t_uown
         print(f"n={n:5d}: cholesky lower  library {t_lib:7.2f} ms (err {e_lib:.1e})  own {t_own:7.2f} ms (err {e_own:.1e}) "
               f"= {n ** 3 / 3 / t_own / 1e9:5.2f} TFLOP/s | upper  library {t_ulib:7.2f}  own {t_uown:7.2f} | "
-              f"cholesky_inverse (library) {t_inv:6.2f} | chain  library {chain_lib:7.2f} ms  own {chain_own:7.2f} ms", flush=True)
+              f"inverse  library {t_inv:6.2f} (err {ei_lib:.1e})  own {t_inv_own:6.2f} (err {ei_own:.1e}) | chain  library {chain_lib:7.2f} ms  own {chain_own:7.2f} ms", flush=True)
         del X, H, ref, L_lib, L_own, Hi, U_own
         torch.cuda.empty_cache()
 
