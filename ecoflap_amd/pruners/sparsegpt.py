@@ -177,7 +177,7 @@ class SparseGPT:
             dead, Hinv = self.factor
             W[:, dead] = 0
         else:
-            with PhaseTimer.span("sparsegpt.factor (clamp, 2 damped Cholesky, inverse: torch.linalg)"):
+            with PhaseTimer.span("sparsegpt.factor (clamp, 2 damped Cholesky, inverse: csrc/cholesky.hip)"):
                 dead = torch.diag(H) == 0
                 H[dead, dead] = 1
                 W[:, dead] = 0

@@ -585,7 +585,7 @@ class _BlockwiseWanda:
                                 break
             if sparsegpt and getattr(self.owner, "sparsegpt_factor_side_by_side", True):
                 # the block's factorisations up front, one at a time (pruners/sparsegpt.py: why not side by side)
-                with PhaseTimer.span("sparsegpt.factor (all Linears of a block, one at a time: torch.linalg)"):
+                with PhaseTimer.span("sparsegpt.factor (all Linears of a block, one at a time: csrc/cholesky.hip)"):
                     SparseGPT.factor_all([wrapped[n] for n in subset if n not in twins], percdamp=0.01)
             block_items = []
             for name in subset:
