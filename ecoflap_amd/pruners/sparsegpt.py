@@ -140,7 +140,15 @@ class SparseGPT:
         in 160 one-by-one, with a lock around the Cholesky calls alone and around the inverse
         alone as well: two solver calls in flight in one process are not safe on this stack,
         whoever makes them.  So: sequential, on the caller's stream (4.5 s of the BLIP-2 run given
-        back); what stays of the round's SparseGPT work is the graph replays of both block passes."""
+        back); what stays of the round's SparseGPT work is the graph replays of both block passes.
+
+        Round 6: the factorisations themselves are this build's own kernels now (csrc/cholesky.hip:
+        no solver handle, no shared workspace; 10.2 -> 2.8 s of the BLIP-2 run's stage 2).  Four of
+        THOSE in flight on four streams equal their one-by-one results bit for bit
+        (tests/test_gpu_parity.py::test_own_cholesky_side_by_side_on_streams_equals_one_by_one), so
+        the side-by-side form would be safe again; it is not rebuilt: the retry loop's host syncs
+        (`info`, the inf scans) would have to move behind one sync per stage for less than a second
+        of a 65 s run."""
         for it in items:
             if it.factor is None:
                 it.flush()
