@@ -6,7 +6,7 @@
 // bytes: 4.0 / 6.0 / 16.3 / 20.3 ms at n = 1408 / 2048 / 5120 / 6144 (0.2 - 3.8 TFLOP/s,
 // profiles/r05_sparsegpt/cholesky_bench.log), half of SparseGPT's stage 2 on the BLIP-2 shape —
 // and two of its calls in flight in one process corrupt each other (profiles/r05_sparsegpt/README.md).
-// This one keeps no state outside its arguments: no handle, no workspace.
+// This one keeps no state outside its arguments: no handle; 16 KB of caller-owned scratch per call.
 //
 // Right-looking, 64 columns per step, in place on the LOWER triangle of a row-major matrix:
 //   panel launch     one single-wave workgroup per 64 rows from the diagonal block down.  EVERY
@@ -124,7 +124,8 @@ struct SolveStep<CH_NB> {
 };
 
 __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ A, int64_t n, int64_t lda,
-                                                        int64_t k0, int* __restrict__ info) {
+                                                        int64_t k0, int* __restrict__ info,
+                                                        float* __restrict__ Dk) {
     // (host: k0 + 64 <= n — a ragged last block goes to chol_ragged_kernel)
     const int lane = threadIdx.x;
     const bool vec = (lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;      // (k0 is a multiple of 64)
@@ -148,7 +149,13 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ A, i
     FactorStep<0>::run(a, lane, bad);
     if (blockIdx.x == 0) {
         if (bad && lane == 0 && info[0] == 0) info[0] = (int)(k0 + bad);
-        float* p = A + (k0 + lane) * lda + k0;
+        // The factored block must NOT go into A while the other waves of this launch may still be
+        // loading the unfactored one (they start when the chip has room for them: with several
+        // factorisations in flight some start after wave 0 is done — measured: one factor in ~12
+        // came out different side by side): it waits in the call's own 16 KB scratch and the
+        // trailing launch — which starts when this one is over — puts it in place.  A launch of
+        // one wave (the last block) writes in place.
+        float* p = gridDim.x == 1 ? A + (k0 + lane) * lda + k0 : Dk + lane * CH_NB;
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c)
             if (c <= lane) p[c] = a[c];
@@ -223,9 +230,15 @@ __global__ __launch_bounds__(256) void chol_ragged_kernel(float* __restrict__ A,
 
 // ---- trailing update on the matrix cores --------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_trailing_kernel(float* __restrict__ A, int64_t n, int64_t lda,
-                                                            int64_t k0) {
+                                                            int64_t k0, const float* __restrict__ Dk) {
     const int I = blockIdx.y, J = blockIdx.x;
     if (J > I) return;
+    if (I == 0 && J == 0) {       // the panel launch's factored diagonal block goes home (see there)
+        for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            if (c <= r) A[(k0 + r) * lda + k0 + c] = Dk[r * CH_NB + c];
+        }
+    }
     __shared__ __attribute__((aligned(16))) float Pa[CH_NB * CH_PK];
     __shared__ __attribute__((aligned(16))) float Pb[CH_NB * CH_PK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,9 +555,14 @@ extern "C" int ecoflap_cholesky_inverse_f32(const float* l, int64_t n, int64_t l
     return 0;
 }
 
-extern "C" int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* stream) {
+extern "C" size_t ecoflap_cholesky_workspace_bytes(void) { return CH_NB * CH_NB * sizeof(float); }
+
+extern "C" int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     if (n < 0 || lda < n || n > (1 << 20)) return ECOFLAP_ESIZE;
-    if (!info) return ECOFLAP_ENULL;
+    if (!info || !workspace) return ECOFLAP_ENULL;
+    if (workspace_bytes < ecoflap_cholesky_workspace_bytes()) return ECOFLAP_ESIZE;
+    float* Dk = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return ECOFLAP_ENULL;
     if (n == 0) return 0;
@@ -552,11 +570,11 @@ extern "C" int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper,
     for (int64_t k0 = 0; k0 < n; k0 += CH_NB) {
         const unsigned chunks = (unsigned)((n - k0 + CH_NB - 1) / CH_NB);
         if (k0 + CH_NB <= n)
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(chunks), dim3(64), 0, s, a, n, lda, k0, info);
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(chunks), dim3(64), 0, s, a, n, lda, k0, info, Dk);
         else
             hipLaunchKernelGGL(chol_ragged_kernel, dim3(1), dim3(256), 0, s, a, n, lda, k0, info);
         if (chunks > 1)
-            hipLaunchKernelGGL(chol_trailing_kernel, dim3(chunks - 1, chunks - 1), dim3(256), 0, s, a, n, lda, k0);
+            hipLaunchKernelGGL(chol_trailing_kernel, dim3(chunks - 1, chunks - 1), dim3(256), 0, s, a, n, lda, k0, Dk);
     }
     const unsigned tiles = (unsigned)((n + CH_NB - 1) / CH_NB);
     hipLaunchKernelGGL(chol_finalize_kernel, dim3(tiles, tiles), dim3(256), 0, s, a, n, lda, upper ? 1 : 0);

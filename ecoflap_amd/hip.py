@@ -34,7 +34,7 @@ EXPORTS = [
     "ecoflap_wanda_prune_block", "ecoflap_wanda_fallback_counts",
     "ecoflap_mask_mul", "ecoflap_allocate_sparsity",
     "ecoflap_sparsegpt_workspace_bytes", "ecoflap_sparsegpt_block", "ecoflap_sparsegpt_block_nm",
-    "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum", "ecoflap_cholesky_f32",
+    "ecoflap_hessian_workspace_bytes", "ecoflap_hessian_accum", "ecoflap_cholesky_workspace_bytes", "ecoflap_cholesky_f32",
     "ecoflap_cholesky_inverse_workspace_bytes", "ecoflap_cholesky_inverse_f32",
     "ecoflap_grad_accum_multi", "ecoflap_global_prune_workspace_bytes",
     "ecoflap_global_threshold_prune", "ecoflap_global_prune_protected_workspace_bytes",
@@ -148,7 +148,9 @@ def load_library():
     lib.ecoflap_global_threshold_prune_protected.argtypes = [vp, ci, ci, f32, i64, i64, vp, vp, sz, vp]
     lib.ecoflap_count_zeros_multi.argtypes = [vp, ci, vp, vp]
     lib.ecoflap_sparsegpt_workspace_bytes.restype = sz
-    lib.ecoflap_cholesky_f32.argtypes = [vp, i64, i64, ci, vp, vp]
+    lib.ecoflap_cholesky_workspace_bytes.restype = sz
+    lib.ecoflap_cholesky_workspace_bytes.argtypes = []
+    lib.ecoflap_cholesky_f32.argtypes = [vp, i64, i64, ci, vp, vp, sz, vp]
     lib.ecoflap_cholesky_inverse_workspace_bytes.restype = sz
     lib.ecoflap_cholesky_inverse_workspace_bytes.argtypes = [i64]
     lib.ecoflap_cholesky_inverse_f32.argtypes = [vp, i64, i64, vp, i64, vp, sz, vp]
@@ -817,8 +819,9 @@ class HipKernels:
         # (torch.cholesky_inverse hands back a column-major tensor: the copy is row-major either way)
         L = H.clone(memory_format=torch.contiguous_format)
         info = torch.empty(1, dtype=torch.int32, device=H.device)
+        ws = torch.empty(int(self.lib.ecoflap_cholesky_workspace_bytes()), dtype=torch.uint8, device=H.device)
         _check(self.lib.ecoflap_cholesky_f32(_ptr(L), L.shape[0], L.stride(0), int(bool(upper)), _ptr(info),
-                                             _stream()), "ecoflap_cholesky_f32")
+                                             _ptr(ws), ws.numel(), _stream()), "ecoflap_cholesky_f32")
         return L, int(info.item())
 
     def cholesky_inverse(self, L):

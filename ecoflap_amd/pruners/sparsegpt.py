@@ -125,34 +125,74 @@ class SparseGPT:
         raise RuntimeError("Hessian could not be made positive definite")
 
     # ---- the factorisations of a block's Linears ---------------------------------------------------
+    _pool = None
+    _pool_streams = {}
+
+    def _own_factorisations(self):
+        return (self.use_own_cholesky and self.H is not None and self.H.is_cuda and self.H.dtype == torch.float32
+                and hasattr(self.kernels, "cholesky") and hasattr(self.kernels, "cholesky_inverse"))
+
     @classmethod
     def factor_all(cls, items, percdamp=.01):
-        """`factor` (dead columns, Hinv) for every SparseGPT in `items` — the three torch.linalg
-        calls of `fasterprune` (:84-110) — up front for a whole transformer block, ONE AT A TIME.
+        """`factor` (dead columns, Hinv) for every SparseGPT in `items` — the three factorisation
+        calls of `fasterprune` (:84-110) — up front for a whole transformer block.
 
-        Round 5 first ran them side by side (rocSOLVER's potrf is latency-bound at these sizes:
-        4.0 ms at 1408, 20 ms at 6144, `profiles/r05_sparsegpt/cholesky_bench.log`; a block's
-        Hessians are independent): on several streams from one thread the factors came out
-        corrupted at once (one solver handle, one workspace), with one host thread + stream + handle
-        per Linear they matched the one-by-one results in every test run — until a suite run in
-        which one did not.  `tools/diag/factor_determinism.py` then showed 4-8 corrupted factors
-        (differences of 1e-4 .. 1e-2, not rounding) per 400 side-by-side factorisations against 0
-        in 160 one-by-one, with a lock around the Cholesky calls alone and around the inverse
-        alone as well: two solver calls in flight in one process are not safe on this stack,
-        whoever makes them.  So: sequential, on the caller's stream (4.5 s of the BLIP-2 run given
-        back); what stays of the round's SparseGPT work is the graph replays of both block passes.
+        History.  Round 5 ran them side by side on rocSOLVER (latency-bound at these sizes: 4.0 ms
+        at 1408, 20 ms at 6144; a block's Hessians are independent), one host thread + stream +
+        solver handle per Linear — and withdrew it: `tools/diag/factor_determinism.py` showed 4-8
+        corrupted factors (1e-4 .. 1e-2, not rounding) per 400 side-by-side factorisations against
+        0 in 160 one-by-one, with locks around the Cholesky calls alone and around the inverse
+        alone as well: two solver calls in flight in one process are not safe on this stack
+        (`profiles/r05_sparsegpt/README.md`).
 
-        Round 6: the factorisations themselves are this build's own kernels now (csrc/cholesky.hip:
-        no solver handle, no shared workspace; 10.2 -> 2.8 s of the BLIP-2 run's stage 2).  Four of
-        THOSE in flight on four streams equal their one-by-one results bit for bit
-        (tests/test_gpu_parity.py::test_own_cholesky_side_by_side_on_streams_equals_one_by_one), so
-        the side-by-side form would be safe again; it is not rebuilt: the retry loop's host syncs
-        (`info`, the inf scans) would have to move behind one sync per stage for less than a second
-        of a 65 s run."""
+        Round 6: the factorisations are this build's own kernels (csrc/cholesky.hip: no solver
+        handle, no workspace outside the call; 10.2 -> 2.8 s of the BLIP-2 run's stage 2 one by
+        one), and with THOSE the side-by-side form is back: one host thread and one HIP stream per
+        Linear, each running exactly `_factor_alone` — the reference's sequence with its own
+        host-side tests (`info`, the inf scans), which then wait on that thread's stream only —
+        so every factor is the one-by-one factor bit for bit (the same probe: 0 of 400;
+        tests/test_sparsegpt_parity.py).  A backend without the own kernels (the oracle backend,
+        `use_own_cholesky = False`) factors one at a time on the caller's stream, as before."""
+        items = [it for it in items if it.factor is None]
+        if not items:
+            return
         for it in items:
-            if it.factor is None:
-                it.flush()
+            it.flush()
+        if not (len(items) > 1 and cls.side_by_side and all(it._own_factorisations() for it in items)):
+            for it in items:
                 it._factor_alone(percdamp)
+            return
+        import concurrent.futures as cf
+        import threading
+        if cls._pool is None:
+            cls._pool = cf.ThreadPoolExecutor(max_workers=8, thread_name_prefix="sparsegpt-factor")
+        main = torch.cuda.current_stream()
+        device = torch.cuda.current_device()
+        done_streams = []
+
+        def work(it):
+            torch.cuda.set_device(device)
+            tid = threading.get_ident()
+            st = cls._pool_streams.get((tid, device))
+            if st is None:
+                st = cls._pool_streams[(tid, device)] = torch.cuda.Stream()
+            st.wait_stream(main)
+            with torch.cuda.stream(st), torch.no_grad():
+                it._factor_alone(percdamp)
+                st.synchronize()
+            done_streams.append(st)
+
+        # (largest first: the block's 5120 / 6144 Hessian is the critical path)
+        order = sorted(items, key=lambda it: -it.columns)
+        for f in [cls._pool.submit(work, it) for it in order]:
+            f.result()
+        for st in done_streams:
+            main.wait_stream(st)
+        for it in items:
+            for t in it.factor:          # made on a side stream, read by the sweep on this one
+                t.record_stream(main)
+
+    side_by_side = True
 
     def _factor_alone(self, percdamp):
         H = self.H

@@ -428,11 +428,15 @@ int ecoflap_hessian_accum(float* H, const void* x, int64_t tokens, int64_t cols,
  * with a = U^T U, strict lower triangle zeroed (torch.linalg.cholesky's two forms).
  * *info (device int): 0, or LAPACK's potrf convention — the 1-based index of the first pivot
  * that was not positive (or not a number): the matrix is not numerically positive definite and
- * the contents of a are undefined.  No workspace, no handle, nothing shared between calls: two
- * factorisations may be in flight on two streams.  Blocked right-looking, 64 columns per step,
+ * the contents of a are undefined.  workspace: ecoflap_cholesky_workspace_bytes() (16 KB) of
+ * caller-owned device scratch PER CALL IN FLIGHT (the factored diagonal block waits there for the
+ * end of its panel launch).  No handle, nothing else shared between calls: factorisations may be
+ * in flight side by side on several streams, from several host threads.  Blocked right-looking, 64 columns per step,
  * trailing updates on v_mfma_f32_32x32x2_f32, every sum in a fixed order (bit-repeatable).
  * Agreement with rocSOLVER's factor: a few 1e-7 relative (fp32 factorisations re-associate). */
-int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* stream);
+size_t ecoflap_cholesky_workspace_bytes(void);
+int ecoflap_cholesky_f32(float* a, int64_t n, int64_t lda, int upper, int* info, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* replaces torch.cholesky_inverse(L)   sparsegpt_pruner.py:134
  * out[n, ldo] <- (L L^T)^-1, both triangles, from the LOWER Cholesky factor l[n, ldl] (fp32,

@@ -1719,8 +1719,9 @@ def test_own_cholesky_side_by_side_on_streams_equals_one_by_one(kern):
             with torch.cuda.stream(st):
                 L = H.clone()
                 info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                ws = torch.empty(16384, dtype=torch.uint8, device="cuda")     # (its own scratch per call in flight)
                 rc = kern.lib.ecoflap_cholesky_f32(L.data_ptr(), L.shape[0], L.stride(0), i & 1, info.data_ptr(),
-                                                   st.cuda_stream)
+                                                   ws.data_ptr(), ws.numel(), st.cuda_stream)
                 assert rc == 0
                 outs.append(L)
                 infos.append(info)

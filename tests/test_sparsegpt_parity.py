@@ -134,10 +134,13 @@ def test_sparsegpt_pruner_n_m_end_to_end(golden_dir):
 def test_block_factorisations_up_front_equal_fasterprunes_own():
     """`SparseGPT.factor_all` (the Linears of a block factored up front) == `fasterprune`'s own
     factorisation, bit for bit: dead columns, Hinv and the pruned weights; including a Hessian
-    with dead columns and one that needs the damping loop, three times over.  The first form of
-    `factor_all` ran the block's factorisations side by side on per-thread streams and returned a
-    corrupted factor once in ~50 (tools/diag/factor_determinism.py) — two rocSOLVER calls in flight
-    in one process are not safe here; it is sequential now and this test holds it to that."""
+    with dead columns and one that needs the damping loop, twenty times over.  Round 5's first form
+    of `factor_all` ran the block's factorisations side by side on per-thread streams over rocSOLVER
+    and returned a corrupted factor once in ~50 (tools/diag/factor_determinism.py) — two solver
+    calls in flight in one process are not safe here.  Round 6: the factorisations are the build's
+    own kernels (no handle, nothing shared) and run side by side again; `side_by_side = False` and
+    `use_own_cholesky = False` (the library, one at a time) are held to the same equality with
+    their own one-by-one results."""
     import torch.nn as nn
     from ecoflap_amd import hip
     from ecoflap_amd.pruners.sparsegpt import SparseGPT
@@ -159,17 +162,23 @@ def test_block_factorisations_up_front_equal_fasterprunes_own():
             out.append(w)
         return out
 
-    one_by_one = build()
-    for w in one_by_one:
-        w.fasterprune(0.5)
-    for rep in range(3):
-        together = build()
-        SparseGPT.factor_all(together)
-        assert all(w.factor is not None and w.H is None for w in together)
-        for a, b in zip(one_by_one, together):
-            assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1]), rep
-            b.fasterprune(0.5)
-            assert torch.equal(a.layer.weight.data, b.layer.weight.data), rep
+    saved = (SparseGPT.use_own_cholesky, SparseGPT.side_by_side)
+    try:
+        for own, side, reps in ((True, True, 20), (True, False, 2), (False, True, 2)):
+            SparseGPT.use_own_cholesky, SparseGPT.side_by_side = own, side
+            one_by_one = build()
+            for w in one_by_one:
+                w.fasterprune(0.5)
+            for rep in range(reps):
+                together = build()
+                SparseGPT.factor_all(together)
+                assert all(w.factor is not None and w.H is None for w in together)
+                for a, b in zip(one_by_one, together):
+                    assert torch.equal(a.factor[0], b.factor[0]) and torch.equal(a.factor[1], b.factor[1]), (own, side, rep)
+                    b.fasterprune(0.5)
+                    assert torch.equal(a.layer.weight.data, b.layer.weight.data), (own, side, rep)
+    finally:
+        SparseGPT.use_own_cholesky, SparseGPT.side_by_side = saved
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Is SparseGPT's factorisation chain (2 damped Cholesky + inverse, torch.linalg on rocSOLVER) bit-
+"""Is SparseGPT's factorisation chain (2 damped Cholesky + inverse; round 6: the build's own kernels,
+`ECOFLAP_FACTOR_LIBRARY=1`: torch.linalg on rocSOLVER as in round 5) bit-
 reproducible (a) one matrix at a time, run after run, (b) with a block's matrices side by side on
 per-thread streams (`SparseGPT.factor_all`)?  Prints, per repetition that differs from the first
 one-by-one result, which matrix differs and by how much."""
@@ -37,6 +38,9 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     mode = sys.argv[2] if len(sys.argv) > 2 else "both"
     kern = hip.HipKernels()
+    if os.environ.get("ECOFLAP_FACTOR_LIBRARY"):
+        SparseGPT.use_own_cholesky = False
+        SparseGPT._own_factorisations = lambda self: True     # (force the threaded form over the library: round 5's experiment)
     ref = build(kern)
     h0 = [w.H.clone() for w in ref]
     for w in ref:

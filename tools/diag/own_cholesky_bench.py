@@ -30,11 +30,12 @@ def main():
     kern = hip.HipKernels()
     torch.manual_seed(0)
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws16 = torch.empty(16384, dtype=torch.uint8, device="cuda")
 
     def own(H, upper):
         L = H.clone(memory_format=torch.contiguous_format)
         rc = kern.lib.ecoflap_cholesky_f32(L.data_ptr(), L.shape[0], L.stride(0), int(upper), info.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream)
+                                           ws16.data_ptr(), ws16.numel(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         return L
 
