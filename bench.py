@@ -199,7 +199,7 @@ class TimedKernels:
         # kernel queued first keeps the stream busy while the host enqueues start-event, kernel
         # and stop-event back to back; it is not part of the timed span and, unlike the GEMMs
         # round 1 used here, leaves the chip's power state alone (the same bf16 K1 launch:
-        # 156 us right after four 4096^3 GEMMs, 119 us after the spin; tools/k1_time.py).
+        # 156 us right after four 4096^3 GEMMs, 119 us after the spin; round 1, the tool is in the history).
         if self.blocker == "spin":
             torch.cuda._sleep(self.spin_cycles)
         elif self.blocker is not None:

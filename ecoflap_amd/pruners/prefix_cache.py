@@ -835,7 +835,7 @@ class PrefixCachedLoss:
                 # off by ~7e-3 in the loss: ViT-g matrices only, either lane, any position of a
                 # group, theta loaded by memcpy or by a kernel alike, every other chunk of the run
                 # clean and the final table identical.  The library GEMMs are bit-reproducible call
-                # to call (tools/diag/gemm_determinism.py); what is left as a suspect sits below
+                # to call (round 2, tools/diag/gemm_determinism.py in the history); what is left as a suspect sits below
                 # this file (graph replays of the fp16 ViT-g block on two streams).  A one-off is
                 # not a property of the batched path: only a mismatch that REPEATS switches a
                 # feature off; the chunk's losses are the sequential ones either way.
