@@ -172,7 +172,7 @@ class HookedPrefixLoss:
     requires_static_weights = False       # no graphs: theta is re-pointed / applied per slot
 
     def __init__(self, model, loss_func, block_lists, extra_modules=(), max_batches=256, eval_batch=1,
-                 verify_batched="entries", use_graphs=True):
+                 verify_batched="entries", use_graphs=True, defer_guard=False):
         self.model = model
         # batches whose recorded activations are kept (least recently used goes first).
         # `LayerSparsity` takes the calibration prefix ONCE and re-uses those batch objects for
@@ -224,6 +224,16 @@ class HookedPrefixLoss:
         self._lens = {}                       # id(samples) -> batch length, for `multi`'s result
         self._value_shared = set()            # (family, event, leaf) tensors equal across evaluations
         self._assumed = None                  # device flag: such a tensor differed after all
+        # defer_guard (or ECOFLAP_LOCKSTEP_DEFER_GUARD=1): the per-entry-block guard compares on the
+        # device and is read back without stopping the host (round 6; `_guard_deferred`).  OFF by
+        # default: measured on the bench's matrices it takes 4-5 ms of blocked time off a 100 ms
+        # step that is bound by the host's own 72-80 ms (9.8-10.2 against 9.5-10.1 layers/s, config
+        # 3 inside the box-to-box spread; profiles/NOTES_r06.md section 6), and a difference found
+        # a chunk late can only be an error, where the synchronous form falls back to
+        # per-evaluation forwards and carries on
+        self.defer_guard = bool(defer_guard) or os.environ.get("ECOFLAP_LOCKSTEP_DEFER_GUARD", "0") == "1"
+        self._probes = []                     # (event on the read-back stream, pinned host copy of the flag, what)
+        self._probe_stream = None
         self.stats = {"events_total": 0, "events_served": 0, "forwards": 0}
 
     # ---- hooks of LayerSparsity ------------------------------------------------------------
@@ -296,13 +306,51 @@ class HookedPrefixLoss:
         """`LayerSparsity` calls this when a pass dies: the instances get their forwards back."""
         self._keep_patched = False
         self._uninstall()
+        self._probes = []
 
     def finish_run(self):
         """Called by `LayerSparsity` before it reads the loss table: the instances get their
         forwards back and the assumptions made without a host sync must have held."""
         self._keep_patched = False
         self._uninstall()
+        self._probes = []             # (the blocking read below covers whatever they would have shown)
         self.check_assumed()
+
+    def _guard_deferred(self, got, want, what):
+        """The guard's comparison without stopping the host: one compare launch ORs into the flag
+        `check_assumed` reads (before every stage-1 checkpoint and at the end of the run), and a
+        copy of the flag travels to pinned host memory on a side stream behind it; `_poll_assumed`
+        — at the start of every later chunk — looks at the copies that have ARRIVED (an event
+        query, no wait) and raises on the first non-zero one, i.e. a chunk or two after the
+        difference happened.  Why: the host-side `torch.equal` drained the launch queue once per
+        entry block (and `check_assumed` behind it again), after which the device idled until the
+        host had refilled it — a quarter of the un-staged path's step was spent in those syncs
+        (profiles/NOTES_r06.md section 6).  What it costs: a difference is an ERROR here ("rerun
+        with eval_batch=1"), as for every other check queued without a sync; the graceful
+        fall-back of the synchronous form (`defer_guard=False`) cannot be offered a chunk late."""
+        from .prefix_cache import _differ_flag
+        self._assumed = _differ_flag([t.reshape(1) for t in got], [t.reshape(1) for t in want], self._assumed)
+        self._assumed_what = what
+        done_main = torch.cuda.Event()
+        done_main.record()
+        if self._probe_stream is None:
+            self._probe_stream = torch.cuda.Stream()
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        with torch.cuda.stream(self._probe_stream):
+            self._probe_stream.wait_event(done_main)
+            host.copy_(self._assumed, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(self._probe_stream)
+        self._probes.append((arrived, host, what))
+        self.stats["lockstep_checks_deferred"] = self.stats.get("lockstep_checks_deferred", 0) + 1
+
+    def _poll_assumed(self):
+        while self._probes and self._probes[0][0].query():
+            _, host, what = self._probes.pop(0)
+            if int(host[0]) != 0:
+                self._probes = []
+                raise RuntimeError("HookedPrefixLoss: a check that was queued without a host sync failed — last "
+                                   f"queued when it was read: {what}; rerun with eval_batch=1")
 
     def check_assumed(self):
         """Read the checks that were queued without a host sync (one sync); raises if one failed.
@@ -612,6 +660,7 @@ class HookedPrefixLoss:
             # a batch never seen before: one plain forward tells its length (and records it)
             return None
         thetas = [theta for _, theta in evals]
+        self._poll_assumed()
         t0 = time.time()
         losses = self._run_lockstep(model, evals, ctxs, thetas, cuda_enabled, owner_ev, fam, B)
         self.stats["lockstep_seconds"] = self.stats.get("lockstep_seconds", 0.0) + time.time() - t0
@@ -626,6 +675,10 @@ class HookedPrefixLoss:
             sel = list(range(k)) if every else [self.stats.get("lockstep_checks", 0) % k]
             want = self._sequential(model, [evals[i] for i in sel], cuda_enabled)
             self.stats["lockstep_checks"] = self.stats.get("lockstep_checks", 0) + 1
+            if self.defer_guard and not every and losses[sel[0]].is_cuda:
+                self._guard_deferred([losses[i] for i in sel], want,
+                                     f"the lock-step guard at {self.paths[self.owner]} ({self._pair_name})")
+                return losses
             t1 = time.time()
             same = all(torch.equal(losses[i], w) for i, w in zip(sel, want))
             self.stats["host_blocked_seconds"] = self.stats.get("host_blocked_seconds", 0.0) + time.time() - t1

@@ -138,3 +138,35 @@ def test_reference_style_forward_equals_the_staged_composition_on_the_gpu():
                 assert torch.equal(a["loss"], r["loss"]) and torch.equal(a["logits"], r["logits"])
         del m
         torch.cuda.empty_cache()
+
+
+def test_deferred_guard_reports_a_difference_without_stopping_the_host():
+    """Round 6, opt-in (`defer_guard=True`): the per-entry-block guard of the lock-step path compares on the device and its flag
+    travels to the host on a side stream (`HookedPrefixLoss._guard_deferred`, `_poll_assumed`):
+    equal losses leave the flag clear; a loss that differs in its last bit is an error at the next
+    poll after the copy has arrived, and at `check_assumed` (which LayerSparsity calls before every
+    stage-1 checkpoint and at the end of the run)."""
+    import torch.nn as nn
+    from ecoflap_amd.pruners.hooked_prefix import HookedPrefixLoss
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = nn.ModuleList([nn.Linear(8, 8) for _ in range(2)])
+
+    hp = HookedPrefixLoss(Toy().cuda(), lambda m, b, c: (None, 0), ["blocks"], eval_batch=4, defer_guard=True)
+    assert hp.defer_guard and not HookedPrefixLoss(Toy().cuda(), lambda m, b, c: (None, 0), ["blocks"]).defer_guard
+    a = [torch.tensor(1.25, device="cuda"), torch.tensor(-3.5, device="cuda")]
+    hp._guard_deferred(a, [t.clone() for t in a], "equal losses")
+    torch.cuda.synchronize()
+    hp._poll_assumed()
+    hp.check_assumed()
+    assert hp.stats["lockstep_checks_deferred"] == 1 and not hp._probes
+    b = [a[0].clone(), torch.nextafter(a[1], torch.tensor(0.0, device="cuda"))]
+    hp._guard_deferred(a, b, "one loss off by an ulp")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="one loss off by an ulp"):
+        hp._poll_assumed()
+    with pytest.raises(RuntimeError, match="eval_batch=1"):
+        hp.check_assumed()
+    hp.close()
