@@ -228,6 +228,7 @@ def main(argv=None, kernels=None):
         with open(os.path.join(args.out_dir, "training_statistics", args.job_id + ".yaml"), "w") as f:
             yaml.dump({"memory": peak, "time": time.time() - start}, f)
     main.last_stage_stats = dict(getattr(pruner, "stage_stats", {}))
+    main.last_loss_table = getattr(pruner, "last_loss_table", None)
     return model, sparsity_dict
 
 

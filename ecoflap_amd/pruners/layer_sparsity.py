@@ -323,6 +323,61 @@ class LayerSparsity:
             h.update(np.float64(t.double().sum().item()).tobytes())
         return h.hexdigest(), head
 
+    def _replica_identity(self, names, params, batches, units):
+        """What every replica of a data-parallel run must hold in common before the pass starts,
+        as one digest per item: the seed of every unit (drawn from the process-global NumPy
+        generator — anything else that draws from it between `np.random.seed` and here shifts
+        them), the starting weights of every scored layer (sum |W|) and every calibration batch
+        (float64 sums: a rank evaluates only its own, but all of them index the same list).  The
+        reference gives each rank `seed + rank` (LAVIS/evaluate_blip.py:287-295) because its ranks
+        never share a table; ranks that fill ONE table need one schedule.  Replicas that differ
+        would still all-reduce a table without any error — rows from different seeds next to each
+        other — so they are compared here and a difference raises.  -> the digests, for the
+        stage statistics (two runs of one command can be compared by them)."""
+        import hashlib
+        seeds = hashlib.sha256(np.asarray([u[3] for u in units], dtype=np.int64).tobytes())
+        seeds.update(repr([str(n) for n in names]).encode())
+        weights = hashlib.sha256()
+        if params and params[0].is_cuda:
+            weights.update(np.asarray(self._weight_sums(params, _hip.RED_ABSW), dtype=np.float64).tobytes())
+        data = hashlib.sha256()
+        for b in batches:
+            vals = b.values() if isinstance(b, dict) else b if isinstance(b, (list, tuple)) else [b]
+            sums = [v.double().sum() for v in vals if torch.is_tensor(v)]
+            if sums:
+                data.update(torch.stack(sums).cpu().numpy().tobytes())
+        out = {"seeds": seeds.hexdigest()[:16], "start_weights": weights.hexdigest()[:16],
+               "calibration": data.hexdigest()[:16]}
+        dist, rank, world = self._dist()
+        if world > 1 and dist is not None and batches:
+            # ... and must COMPUTE alike: the loss of the first batch at the starting weights,
+            # evaluated once by every rank, bit for bit.  Equal inputs are not enough where a
+            # library under the forward picks its kernel per process by measuring (MIOpen's Find
+            # behind `nn.Conv2d` did, between eight ranks sharing one device: see
+            # shapes/eva_vit.py `PatchEmbed`); one forward per rank buys the check.
+            with torch.no_grad():
+                loss0 = self.loss_func(self.model, batches[0], params[0].device.type != "cpu")[0]
+            out["first_loss"] = hashlib.sha256(
+                loss0.detach().float().cpu().numpy().tobytes()).hexdigest()[:16]
+        if world > 1 and dist is not None:
+            mine = torch.tensor([int(v[:15], 16) for v in out.values()], dtype=torch.int64)
+            if dist.get_backend(self.process_group) == "nccl":
+                mine = mine.to(params[0].device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=self.process_group)
+            for r, other in enumerate(every):
+                if not torch.equal(other.cpu(), every[0].cpu()):
+                    bad = [k for k, a, b in zip(out, other.cpu().tolist(), every[0].cpu().tolist()) if a != b]
+                    raise RuntimeError(
+                        f"data-parallel stage 1: rank {r} differs from rank 0 in {bad} — every rank "
+                        "must be started with the same --seed, weights and calibration set (and "
+                        "nothing may draw from the global NumPy generator before the pruner runs); "
+                        "'first_loss' alone: the ranks hold the same model and batch but their "
+                        "forwards round differently — a library picked different kernels per "
+                        "process (a convolution under MIOpen's timed Find: pin it with "
+                        "MIOPEN_DEBUG_FIND_ONLY_SOLVER or run that layer as a GEMM)")
+        return out
+
     def _save_stage1_checkpoint(self, path, done, names, units, table, complete=False):
         """Layers [0, done) are finished: their rows of the loss table (this rank's entries) and
         what identifies the run (layer names, seeds, `_run_fingerprint`).  One stream sync; written
@@ -391,6 +446,7 @@ class LayerSparsity:
         batches, units = self.build_zeroth_order_schedule(names)
         self.seed_schedule = units
         n_units = len(units)
+        identity = self._replica_identity(names, params, batches, units)
         # the loss pair of a unit, in the loss tensor's OWN dtype (fp32 for every loss closure of
         # the reference; a model returning a bf16 / fp16 loss has its subtraction and division
         # done in that dtype, as `(loss1 - loss2) / (2 * zo_eps)` is at :544): allocated on the
@@ -668,7 +724,7 @@ class LayerSparsity:
         else:
             raise ValueError(f"unknown zeroth-order score_method {self.score_method!r}")
         self.stats = {"seconds": time.time() - t0, "layers": len(names), "units": n_units,
-                      "forwards": n_forward, "world_size": world,
+                      "forwards": n_forward, "world_size": world, "run_identity": identity,
                       "host_enqueue_seconds": t_enqueued, "loss_table_allreduce": allreduce,
                       "z_mode": ("philox" if self.z_source == "philox" else
                                  "torch-" + getattr(self, "_torch_z_mode", "materialised")

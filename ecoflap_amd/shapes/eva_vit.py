@@ -129,6 +129,19 @@ class Block(nn.Module):
         return fused.trace("09_out", out)
 
 
+def patches_gemm(proj, x):
+    """`proj(x).flatten(2).transpose(1, 2)` of a Conv2d whose stride is its kernel size, as a
+    GEMM: [B, C, H, W] -> [B, patches, D] (rows and columns the kernel does not cover are left
+    out, as the convolution leaves them out)."""
+    p = proj.kernel_size[0]
+    assert proj.kernel_size == proj.stride == (p, p) and proj.padding == (0, 0) and proj.groups == 1
+    B, C, H, W = x.shape
+    gh, gw = H // p, W // p
+    cols = (x[:, :, :gh * p, :gw * p].reshape(B, C, gh, p, gw, p)
+            .permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p))
+    return F.linear(cols, proj.weight.reshape(proj.out_channels, -1), proj.bias)
+
+
 class PatchEmbed(nn.Module):
     def __init__(self, img_size, patch_size, in_chans, embed_dim):
         super().__init__()
@@ -136,7 +149,19 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        if not x.is_cuda:
+            return self.proj(x).flatten(2).transpose(1, 2)
+        # On the GPU the stride = kernel convolution is run as what it is, ONE GEMM over the
+        # unfolded patches, not as `nn.Conv2d`: torch hands a convolution to MIOpen, whose Find
+        # step TIMES its candidate solvers on first use and keeps the fastest — for this shape two
+        # implicit-GEMM solvers and a plain GEMM that round differently — in a user database
+        # under $HOME that later processes read.  Timing is not a function of the inputs: eight
+        # ranks sharing a device, or a stream busy next to the Find, crowned different solvers,
+        # and stage 1's loss table then differed between ranks and between runs of one command
+        # (profiles/NOTES_r06.md, "the convolution").  `F.linear` goes to the GEMM library's
+        # static heuristic (ecoflap_amd/blas_guard.py keeps that one reproducible).  Same
+        # contraction, same parameters (`proj.weight` stays the [D, C, p, p] checkpoint tensor).
+        return patches_gemm(self.proj, x)
 
 
 class VisionTransformer(nn.Module):

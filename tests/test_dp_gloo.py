@@ -316,3 +316,55 @@ def test_two_ranks_sparsegpt_hessian_allreduce(tmp_path):
     zeros = sum(int((w0[k] == 0).sum()) for k in blocks)
     # toy Hessians are rank-deficient (fewer tokens than columns): OBS amplifies the rounding
     assert agree / total > 0.95 and 0.45 < zeros / total < 0.55
+
+
+# ---- replicas that do not hold or compute the same thing are refused, not all-reduced ------------
+def _divergent_worker(rank, world, port, out_dir, how):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_backend import OracleKernels, torch_cpu_normal
+        from ecoflap_amd.pruners import LayerSparsity
+        from ecoflap_amd.pruners.losses import loss_vision_language
+        from ecoflap_amd.shapes import synthetic as S
+        from ecoflap_amd.shapes.blip2_t5 import blip2_toy
+        torch.set_num_threads(1)
+        torch.manual_seed(4)
+        model = blip2_toy().eval()
+        batches = S.image_text_batches(8, 2, img_size=28, vocab=96, in_len=5, out_len=4, seed=6)
+        mapping = {k: ".".join(k.split(".")[:4 if k.startswith("t5") else 3])
+                   for k, v in model.named_parameters()
+                   if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k}
+        np.random.seed(42)
+        loss = loss_vision_language
+        if how == "seeds" and rank == 1:
+            np.random.randint(10)              # something drew from the global generator on this rank
+        if how == "forward" and rank == 1:
+            # same model, same batch, another rounding: what a per-process kernel choice does
+            def loss(m, b, c):
+                l, n = loss_vision_language(m, b, c)
+                return torch.nextafter(l, l + 1), n
+        ls = LayerSparsity(model, batches, loss, 8, 0.5, 0.6, "MEZO-GradOnly_sum", 1, 1e-3, mapping,
+                           kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form="units")
+        try:
+            ls.return_sparsity()
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("how,named", [("seeds", "['seeds']"), ("forward", "['first_loss']")])
+def test_ranks_that_differ_are_refused_before_the_pass(tmp_path, how, named):
+    """A rank with another seed schedule, or one whose forward rounds differently, would fill
+    its share of ONE loss table with rows of another run and the all-reduce would not notice:
+    every rank raises before the first unit, and says which digest differs."""
+    port = free_port()
+    mp.spawn(_divergent_worker, args=(2, port, str(tmp_path), how), nprocs=2, join=True)
+    for r in range(2):
+        msg = (tmp_path / f"rank{r}.txt").read_text()
+        assert "rank 1 differs from rank 0 in " + named in msg, msg

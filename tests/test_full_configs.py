@@ -16,9 +16,11 @@ pytestmark = pytest.mark.gpu
 
 
 # the hashes of config 3 on this tree ("Which hashes are current"): the table hash
-# is the reference's arithmetic on this GPU and has not moved since round 3; the pruned-weight hash
-# is defined up to K6's summation order (1e-5) and moves when that kernel's order does
-CONFIG3_TABLE_SHA256_PREFIX = "579daf98b0dc"
+# is the reference's arithmetic on this GPU; `579daf98b0dc` from round 3 until the shape's patch
+# embedding stopped being an MIOpen convolution (round 6, profiles/NOTES_r06.md §7: that hash was
+# the fastest-timed solver's rounding, and one of three the same command could produce); the
+# pruned-weight hash is defined up to K6's summation order (1e-5) and moves when that kernel's does
+CONFIG3_TABLE_SHA256_PREFIX = "e9a6da61e7b0"
 
 
 def test_config3_blip2_zeroth_order_full_size():

@@ -56,6 +56,10 @@ def run(which, extra=()):
     total = sum(v.numel() for v in blocks.values())
     vals = sorted(set(round(v, 6) for v in table.values())) if isinstance(table, dict) else []
     import hashlib
+    dump = os.environ.get("ECOFLAP_DUMP_LOSS_TABLE")      # stage 1's [units, 2] fp32 losses, for run-to-run diffs
+    if dump and getattr(harness.main, "last_loss_table", None) is not None:
+        import numpy as np
+        np.save(dump, np.asarray(harness.main.last_loss_table))
     table_sha = (hashlib.sha256(repr(sorted(table.items())).encode()).hexdigest()
                  if isinstance(table, dict) else None)
     weights_sha = hashlib.sha256()
