@@ -112,6 +112,21 @@ class LayerWiseBasePruner(BasePruner):
             # per weight shape (shapes/fused.py; a model built on the CPU and moved over gets it here)
             from ..shapes.fused import pin_linears
             pin_linears(model)
+        if device.type == "cuda" and not hasattr(model, "stage_plan"):
+            # a model the caller owns: its convolutions are MIOpen's on this platform, and MIOpen
+            # picks their kernel by TIMING candidates on first use (round 6: three roundings of one
+            # patch embedding, by process and by what ran on the box before) — said once, up front
+            from ..shapes.fused import unpinned_convs
+            convs = unpinned_convs(model)
+            if convs:
+                import warnings
+                warnings.warn(
+                    f"{len(convs)} convolution(s) ({', '.join(convs[:3])}{', …' if len(convs) > 3 else ''}) "
+                    "run through MIOpen, which selects their kernel by timing: two runs (or two "
+                    "data-parallel ranks) may round them differently and end with different "
+                    "tables.  ecoflap_amd.shapes.fused.pin_patch_convs(model) runs a patch "
+                    "embedding as a GEMM instead; MIOPEN_DEBUG_FIND_ONLY_SOLVER pins MIOpen's choice.",
+                    RuntimeWarning, stacklevel=3)
         if device.type == "cuda":
             # which GEMM each weight shape runs is bound afresh for this run, as in a fresh process
             # (shapes/fused.py: begin_run) — not inherited from whatever the process ran before

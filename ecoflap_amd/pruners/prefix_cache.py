@@ -365,16 +365,22 @@ class PrefixCachedLoss:
         self.stats["advance_batched_replays"] = (self.stats.get("advance_batched_replays", 0)
                                                  + (len(states) + used - 1) // used)
         # the check: one batch of this stage alone (captured chain if it has the stage, else eager)
-        pick = self.stats.get("advance_checks", 0) % len(states)
-        if chain1 is not None and j in chain1.graphs:
-            alone = chain1.advance(j, j + 1, states[pick])
-        else:
-            alone = self.plan[j][2](states[pick])
-        fa, fb = [], []
-        _map_tensors(alone, lambda t: fa.append(t) or t)
-        _map_tensors(outs[pick], lambda t: fb.append(t) or t)
-        self.stats["advance_checks"] = self.stats.get("advance_checks", 0) + 1
-        self._adv_pending.append((fam, j, fa, fb))
+        picks = [self.stats.get("advance_checks", 0) % len(states)]
+        if self.verify_batched == "all" or os.environ.get("ECOFLAP_VERIFY_BATCHED"):
+            picks = list(range(len(states)))          # every slot (A/B and end-to-end checks)
+        for pick in picks:
+            if chain1 is not None and j in chain1.graphs:
+                alone = chain1.advance(j, j + 1, states[pick])
+            else:
+                alone = self.plan[j][2](states[pick])
+            fa, fb = [], []
+            _map_tensors(alone, lambda t: fa.append(t.clone()) or t)
+            _map_tensors(outs[pick], lambda t: fb.append(t) or t)
+            self.stats["advance_checks"] = self.stats.get("advance_checks", 0) + 1
+            self._adv_pending.append((fam, j, fa, fb))
+            if os.environ.get("ECOFLAP_DEBUG_BATCHED"):
+                print(f"[advance] stage {self.plan[j][0]} slot {pick} of {len(states)} "
+                      f"differs={bool(_differ_flag(fa, fb).item())}", flush=True)
         return outs
 
     def _settle_advance_checks(self):

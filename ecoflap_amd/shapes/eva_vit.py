@@ -7,6 +7,8 @@ sparsity-table keys are identical:
   (create_eva_vit_g: patch 14, dim 1408, depth 39, heads 16, mlp 6144, qkv_bias)
 Random-init only; no checkpoint loading, no drop-path, no window bias.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -129,19 +131,6 @@ class Block(nn.Module):
         return fused.trace("09_out", out)
 
 
-def patches_gemm(proj, x):
-    """`proj(x).flatten(2).transpose(1, 2)` of a Conv2d whose stride is its kernel size, as a
-    GEMM: [B, C, H, W] -> [B, patches, D] (rows and columns the kernel does not cover are left
-    out, as the convolution leaves them out)."""
-    p = proj.kernel_size[0]
-    assert proj.kernel_size == proj.stride == (p, p) and proj.padding == (0, 0) and proj.groups == 1
-    B, C, H, W = x.shape
-    gh, gw = H // p, W // p
-    cols = (x[:, :, :gh * p, :gw * p].reshape(B, C, gh, p, gw, p)
-            .permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p))
-    return F.linear(cols, proj.weight.reshape(proj.out_channels, -1), proj.bias)
-
-
 class PatchEmbed(nn.Module):
     def __init__(self, img_size, patch_size, in_chans, embed_dim):
         super().__init__()
@@ -149,7 +138,7 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):
-        if not x.is_cuda:
+        if not x.is_cuda or os.environ.get("ECOFLAP_PATCH_EMBED_CONV") == "1":     # (A/B: MIOpen's convolution)
             return self.proj(x).flatten(2).transpose(1, 2)
         # On the GPU the stride = kernel convolution is run as what it is, ONE GEMM over the
         # unfolded patches, not as `nn.Conv2d`: torch hands a convolution to MIOpen, whose Find
@@ -161,7 +150,8 @@ class PatchEmbed(nn.Module):
         # (profiles/NOTES_r06.md, "the convolution").  `F.linear` goes to the GEMM library's
         # static heuristic (ecoflap_amd/blas_guard.py keeps that one reproducible).  Same
         # contraction, same parameters (`proj.weight` stays the [D, C, p, p] checkpoint tensor).
-        return patches_gemm(self.proj, x)
+        from . import fused
+        return fused.patches_gemm(self.proj, x)
 
 
 class VisionTransformer(nn.Module):

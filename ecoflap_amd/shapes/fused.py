@@ -550,6 +550,63 @@ def bias_add_residual(x, m, bias):
     return y
 
 
+def patches_gemm(proj, x):
+    """`proj(x).flatten(2).transpose(1, 2)` of a Conv2d whose stride is its kernel size, as a
+    GEMM: [B, C, H, W] -> [B, patches, D] (rows and columns the kernel does not cover are left
+    out, as the convolution leaves them out).  Why: shapes/eva_vit.py `PatchEmbed`."""
+    p = proj.kernel_size[0]
+    assert _is_patch_conv(proj)
+    B, C, H, W = x.shape
+    gh, gw = H // p, W // p
+    cols = (x[:, :, :gh * p, :gw * p].reshape(B, C, gh, p, gw, p)
+            .permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p))
+    return torch.nn.functional.linear(cols, proj.weight.reshape(proj.out_channels, -1), proj.bias)
+
+
+def _is_patch_conv(mod):
+    if type(mod) is not torch.nn.Conv2d:
+        return False
+    k = mod.kernel_size
+    return (k[0] == k[1] and tuple(mod.stride) == tuple(k)
+            and tuple(mod.padding) == (0, 0) and tuple(mod.dilation) == (1, 1) and mod.groups == 1
+            and mod.padding_mode == "zeros")
+
+
+def _patch_conv_forward(self, x):
+    if not x.is_cuda or x.dim() != 4:
+        return torch.nn.Conv2d.forward(self, x)
+    p = self.kernel_size[0]
+    y = patches_gemm(self, x)
+    return y.transpose(1, 2).reshape(x.shape[0], self.out_channels, x.shape[2] // p, x.shape[3] // p)
+
+
+def pin_patch_convs(model):
+    """For a model that is NOT one of the build's shape modules (the reference's own
+    `eva_vit.VisionTransformer`, …) and is going to be scored on the GPU by several ranks, or by
+    runs whose tables are compared: every `nn.Conv2d` whose stride is its kernel size (a ViT's
+    patch embedding) gets an instance-level forward that runs it as one GEMM over the unfolded
+    patches instead of handing it to MIOpen, whose timed Find may crown another solver — another
+    rounding — in another process (profiles/NOTES_r06.md §7).  Opt-in: it changes the rounding of
+    that layer (within one 16-bit ulp of each of MIOpen's three).  Same module type, parameters
+    and state_dict keys.  -> how many were pinned; `unpinned_convs(model)` lists the rest."""
+    import types
+    n = 0
+    for mod in model.modules():
+        if _is_patch_conv(mod) and "forward" not in mod.__dict__:
+            mod.forward = types.MethodType(_patch_conv_forward, mod)
+            n += 1
+    return n
+
+
+def unpinned_convs(model):
+    """Names of the convolutions of `model` whose GPU forward is MIOpen's (kernel chosen by
+    timing on first use): what `BasePruner` warns about before a GPU run."""
+    conv_types = (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.ConvTranspose1d,
+                  torch.nn.ConvTranspose2d, torch.nn.ConvTranspose3d)
+    return [name for name, mod in model.named_modules()
+            if isinstance(mod, conv_types) and "forward" not in mod.__dict__]
+
+
 def pin_linears(model):
     """Every nn.Linear of `model` gets an instance-level `forward` that goes through
     `linear_or_torch`: its 16-bit GPU forward runs the pinned solution, everything else (CPU, fp32,
