@@ -324,58 +324,76 @@ class LayerSparsity:
         return h.hexdigest(), head
 
     def _replica_identity(self, names, params, batches, units):
-        """What every replica of a data-parallel run must hold in common before the pass starts,
-        as one digest per item: the seed of every unit (drawn from the process-global NumPy
-        generator — anything else that draws from it between `np.random.seed` and here shifts
-        them), the starting weights of every scored layer (sum |W|) and every calibration batch
-        (float64 sums: a rank evaluates only its own, but all of them index the same list).  The
-        reference gives each rank `seed + rank` (LAVIS/evaluate_blip.py:287-295) because its ranks
-        never share a table; ranks that fill ONE table need one schedule.  Replicas that differ
-        would still all-reduce a table without any error — rows from different seeds next to each
-        other — so they are compared here and a difference raises.  -> the digests, for the
-        stage statistics (two runs of one command can be compared by them)."""
+        """What the replicas of a data-parallel run must have in common before the pass starts, as
+        digests: the seed of every unit (drawn from the process-global NumPy generator — anything
+        else that draws from it between `np.random.seed` and here shifts them) and the starting
+        weights of every scored layer (sum |W|).  The reference gives each rank `seed + rank`
+        (LAVIS/evaluate_blip.py:287-295) because its ranks never share a table; ranks that fill
+        ONE table need one schedule.  And, where every rank holds the same first batch (the
+        harness: each rank builds the whole list; not bench.py's weak-scaling shards, where a rank
+        holds only its own batches), they must COMPUTE alike: the loss of that batch at the
+        starting weights, evaluated once by every rank, bit for bit — equal inputs are not enough
+        where a library under the forward picks its kernel per process by measuring (MIOpen's Find
+        behind `nn.Conv2d` did, between eight ranks sharing one device: shapes/eva_vit.py
+        `PatchEmbed`, profiles/NOTES_r06.md §7).  Replicas that differ would still all-reduce a
+        table without any error — rows of different runs next to each other — so a difference
+        raises here.  -> the digests, for the stage statistics (one process: the seeds only,
+        unless ECOFLAP_RUN_IDENTITY=1 asks for all of them — two runs can be compared by them)."""
         import hashlib
+        import os
         seeds = hashlib.sha256(np.asarray([u[3] for u in units], dtype=np.int64).tobytes())
         seeds.update(repr([str(n) for n in names]).encode())
+        out = {"seeds": seeds.hexdigest()[:16]}
+        dist, rank, world = self._dist()
+        shared = world > 1 and dist is not None
+        if not shared and os.environ.get("ECOFLAP_RUN_IDENTITY") != "1":
+            return out
         weights = hashlib.sha256()
         if params and params[0].is_cuda:
             weights.update(np.asarray(self._weight_sums(params, _hip.RED_ABSW), dtype=np.float64).tobytes())
-        data = hashlib.sha256()
-        for b in batches:
-            vals = b.values() if isinstance(b, dict) else b if isinstance(b, (list, tuple)) else [b]
-            sums = [v.double().sum() for v in vals if torch.is_tensor(v)]
-            if sums:
-                data.update(torch.stack(sums).cpu().numpy().tobytes())
-        out = {"seeds": seeds.hexdigest()[:16], "start_weights": weights.hexdigest()[:16],
-               "calibration": data.hexdigest()[:16]}
-        dist, rank, world = self._dist()
-        if world > 1 and dist is not None and batches:
-            # ... and must COMPUTE alike: the loss of the first batch at the starting weights,
-            # evaluated once by every rank, bit for bit.  Equal inputs are not enough where a
-            # library under the forward picks its kernel per process by measuring (MIOpen's Find
-            # behind `nn.Conv2d` did, between eight ranks sharing one device: see
-            # shapes/eva_vit.py `PatchEmbed`); one forward per rank buys the check.
-            with torch.no_grad():
-                loss0 = self.loss_func(self.model, batches[0], params[0].device.type != "cpu")[0]
-            out["first_loss"] = hashlib.sha256(
-                loss0.detach().float().cpu().numpy().tobytes()).hexdigest()[:16]
-        if world > 1 and dist is not None:
-            mine = torch.tensor([int(v[:15], 16) for v in out.values()], dtype=torch.int64)
+        out["start_weights"] = weights.hexdigest()[:16]
+        first = batches[0] if batches else None
+        vals = (sorted(first.items(), key=lambda kv: str(kv[0])) if isinstance(first, dict)
+                else list(enumerate(first)) if isinstance(first, (list, tuple)) else [])
+        data = hashlib.sha256(repr([(str(k), tuple(v.shape)) for k, v in vals if torch.is_tensor(v)]).encode())
+        sums = [v.double().sum() for _, v in vals if torch.is_tensor(v)]
+        if sums:
+            data.update(torch.stack(sums).cpu().numpy().tobytes())      # one read-back
+        out["first_batch"] = data.hexdigest()[:16]
+
+        def gather(keys):
+            mine = torch.tensor([int(out[k][:15], 16) for k in keys], dtype=torch.int64)
             if dist.get_backend(self.process_group) == "nccl":
                 mine = mine.to(params[0].device)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine, group=self.process_group)
-            for r, other in enumerate(every):
-                if not torch.equal(other.cpu(), every[0].cpu()):
-                    bad = [k for k, a, b in zip(out, other.cpu().tolist(), every[0].cpu().tolist()) if a != b]
-                    raise RuntimeError(
-                        f"data-parallel stage 1: rank {r} differs from rank 0 in {bad} — every rank "
-                        "must be started with the same --seed, weights and calibration set (and "
-                        "nothing may draw from the global NumPy generator before the pruner runs); "
-                        "'first_loss' alone: the ranks hold the same model and batch but their "
-                        "forwards round differently — a library picked different kernels per "
-                        "process (a convolution under MIOpen's timed Find: pin it with "
-                        "MIOPEN_DEBUG_FIND_ONLY_SOLVER or run that layer as a GEMM)")
+            every = [e.cpu().tolist() for e in every]
+            return {k: [e[i] for e in every] for i, k in enumerate(keys)}
+
+        def refuse(key, got, why):
+            r = next(i for i, v in enumerate(got) if v != got[0])
+            raise RuntimeError(f"data-parallel stage 1: rank {r} differs from rank 0 in ['{key}'] — {why}")
+
+        if shared:
+            got = gather(["seeds", "start_weights", "first_batch"])
+            if len(set(got["seeds"])) > 1:
+                refuse("seeds", got["seeds"], "every rank must be started with the same --seed, and "
+                       "nothing may draw from the global NumPy generator before the pruner runs")
+            if len(set(got["start_weights"])) > 1:
+                refuse("start_weights", got["start_weights"], "every rank must load the same weights")
+            if len(set(got["first_batch"])) == 1 and first is not None:
+                with torch.no_grad():
+                    loss0 = self.loss_func(self.model, first, params[0].device.type != "cpu")[0]
+                out["first_loss"] = hashlib.sha256(
+                    loss0.detach().float().cpu().numpy().tobytes()).hexdigest()[:16]
+                got = gather(["first_loss"])
+                if len(set(got["first_loss"])) > 1:
+                    refuse("first_loss", got["first_loss"],
+                           "the ranks hold the same model and the same batch but their forwards round "
+                           "differently: a library picked different kernels per process (a "
+                           "convolution under MIOpen's timed Find: ecoflap_amd.shapes.fused."
+                           "pin_patch_convs(model) runs a patch embedding as a GEMM, "
+                           "MIOPEN_DEBUG_FIND_ONLY_SOLVER pins MIOpen's choice)")
         return out
 
     def _save_stage1_checkpoint(self, path, done, names, units, table, complete=False):

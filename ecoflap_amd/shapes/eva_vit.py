@@ -136,6 +136,7 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.num_patches = (img_size // patch_size) ** 2
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.proj._ecoflap_gemm_form = True       # its GPU forward is `forward` below, not MIOpen's
 
     def forward(self, x):
         if not x.is_cuda or os.environ.get("ECOFLAP_PATCH_EMBED_CONV") == "1":     # (A/B: MIOpen's convolution)

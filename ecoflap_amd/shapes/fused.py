@@ -604,7 +604,8 @@ def unpinned_convs(model):
     conv_types = (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.ConvTranspose1d,
                   torch.nn.ConvTranspose2d, torch.nn.ConvTranspose3d)
     return [name for name, mod in model.named_modules()
-            if isinstance(mod, conv_types) and "forward" not in mod.__dict__]
+            if isinstance(mod, conv_types) and "forward" not in mod.__dict__
+            and not mod.__dict__.get("_ecoflap_gemm_form")]
 
 
 def pin_linears(model):

@@ -1840,8 +1840,10 @@ def test_real_global_iterative_hip_equals_oracle(kern, golden_dir, tag, method, 
     assert np.array_equal(got_h, got_o)
     # GPU forward/backward differs from the CPU golden in the last bits, which moves a few
     # elements of these 16..64-wide toy matrices across the threshold: sanity bound only
-    # (exactness is HIP == oracle above, and host logic == golden in test_host_parity)
-    assert np.mean(np.abs(got_h - want)) < 0.01 and np.max(np.abs(got_h - want)) < 0.15
+    # (exactness is HIP == oracle above, and host logic == golden in test_host_parity; round 6:
+    # the GPU patch embedding is a GEMM, not MIOpen's convolution — mean 0.0102 and one 16-wide
+    # layer at 0.177 in the gradient-only case, whose scores are the most sensitive of the three)
+    assert np.mean(np.abs(got_h - want)) < 0.015 and np.max(np.abs(got_h - want)) < 0.25
 
 
 def test_real_low_precision_hip_equals_oracle(kern):
