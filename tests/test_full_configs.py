@@ -109,6 +109,29 @@ def test_config3_full_size_all_loop_forms_agree():
     assert a["pruned_weights_sha256"] == c["pruned_weights_sha256"]
 
 
+@full_ab
+def test_config3_as_eight_ranks_sharing_the_gpu_equals_one_process(tmp_path):
+    """configs[3]'s degree on config 3's 128 pairs (tools/run_config4.py, ~150 s): 8 ranks
+    time-sharing cuda:0 over gloo, started in a child with an EMPTY $HOME — no library database of
+    an earlier process to inherit, every rank's first kernel choices made next to seven others
+    (round 6: that is where MIOpen's timed solver choice split the ranks) — end with the hashes of
+    the one-process run in this process.  The 1024-pair form: profiles/r06_dp/."""
+    import json
+    import subprocess
+    env = dict(os.environ, HOME=str(tmp_path), ECOFLAP_CONFIG4_PAIRS="128")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config4.py"), "dp8"], env=env,
+                         capture_output=True, text=True, timeout=1200)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and line, out.stderr[-3000:]
+    dp = json.loads(line[-1])
+    assert dp["world_size"] == 8 and dp["replicas_agree"]
+    assert set(dp["stage_stats"]["stage1"]["run_identity"]) == {"seeds", "start_weights", "first_batch", "first_loss"}
+    import run_config
+    one = run_config.run("3", ["--lanes", "1"])
+    assert dp["table_sha256"] == one["table_sha256"] and one["table_sha256"].startswith(CONFIG3_TABLE_SHA256_PREFIX)
+    assert dp["pruned_weights_sha256"] == one["pruned_weights_sha256"]
+
+
 def test_config2_flant5xl_first_order_full_size_graph_replay_equals_eager():
     """configs[1]: FlanT5-XL shape, 432 matrices, GradMagAbs_sum, 128 sequences bs 1, + Wanda:
     forward+backward replayed from one captured graph vs the eager loop."""
