@@ -365,7 +365,8 @@ class _BlockwiseWanda:
     def _run(self, model, dataloader, module_to_process, n_samples, sparsity_ratio, forward_fn,
              cache_keys, autocast, take_first, mode, optional_keys=False, batch_len=None,
              count_factor=1):
-        with torch.no_grad():
+        from .phase_timer import PhaseTimer
+        with torch.no_grad(), PhaseTimer.span("stage2.capture (the model's forward up to block 0, per sample)"):
             blocks = get_module_recursive(model, module_to_process)
             inps, outs, caches = self.capture(model, dataloader, blocks, forward_fn, cache_keys,
                                               n_samples, optional_keys, batch_len)
