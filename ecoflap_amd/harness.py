@@ -63,9 +63,10 @@ def build_parser():
     p.add_argument("--k1_form", default="block", choices=["block", "units", "triple", "single"],
                    help="K1 launch form (bit-identical results): one launch per transformer block "
                         "(default), per layer, per unit, or the reference's three in-place passes")
-    p.add_argument("--eval_batch", type=int, default=16,
+    p.add_argument("--eval_batch", type=int, default=0,
                    help="loss evaluations of a layer per pass of the batch-invariant suffix (1: one "
-                        "suffix per evaluation)")
+                        "suffix per evaluation; 0, the default: sized from the calibration set — 16 "
+                        "to 64, all of a layer's evaluations in one pass up to ~256 samples)")
     p.add_argument("--lanes", type=int, default=2, help="concurrent evaluation lanes (weight replicas)")
     p.add_argument("--unstaged", action="store_true",
                    help="hide the shape module's stage_plan(): the pruners then see what a reference "
@@ -177,7 +178,7 @@ def config_dict(args):
         "iteration": args.iteration,
         "z_source": getattr(args, "z_source", "torch"),      # build-side extras (kw-only)
         "k1_form": getattr(args, "k1_form", "block"),
-        "eval_batch": getattr(args, "eval_batch", 16),
+        "eval_batch": getattr(args, "eval_batch", 0),
         "n_lanes": getattr(args, "lanes", 2),
         "stage1_checkpoint": getattr(args, "stage1_checkpoint", None),
     }

@@ -62,7 +62,7 @@ class LayerWiseBasePruner(BasePruner):
                  max_sparsity_per_layer=0.8, score_method="GradMagSquare_avg",
                  num_data_first_stage=128, num_noise=1, sparsity_dict=None, noise_eps=1e-3,
                  prune_per_model=False, kernels=None, z_source="torch", process_group=None,
-                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=16, k1_form="block",
+                 prefix_cache=True, use_graphs=True, n_lanes=2, eval_batch=0, k1_form="block",
                  k6_immediate=False, stage1_checkpoint=None, **kwargs):
         super().__init__(model=model, data_loader=data_loader, is_strct_pruning=is_strct_pruning,
                          importance_scores_cache=importance_scores_cache,
@@ -88,6 +88,8 @@ class LayerWiseBasePruner(BasePruner):
         self.prefix_cache = prefix_cache
         self.use_graphs = use_graphs
         self.n_lanes = n_lanes
+        # loss evaluations of a layer per pass of the shared suffix; 0: sized from the calibration
+        # set where stage 1 starts (pruners/wanda.py::_eval_batch)
         self.eval_batch = eval_batch
         self.k1_form = k1_form
         # stage 2: reduce each hooked Linear input inside its hook (one launch per input, as the
@@ -135,7 +137,7 @@ class LayerWiseBasePruner(BasePruner):
             from .. import blas_guard
             # the GEMM library must be in its reproducible mode; batch invariance on top only
             # when evaluations are going to be concatenated
-            blas_guard.verify(device, need_batch_invariance=int(getattr(self, "eval_batch", 1) or 1) > 1)
+            blas_guard.verify(device, need_batch_invariance=int(getattr(self, "eval_batch", 1)) != 1)
         return dtype_record, requires_grad_record, device
 
     def model_reset(self, model, dtype_record, requires_grad_record, device):

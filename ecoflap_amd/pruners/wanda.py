@@ -680,6 +680,36 @@ class _StageOneMixin:
         extra = [n for n, _ in self.model.named_children() if n not in roots]
         return lists, extra
 
+    def _eval_batch(self):
+        """Evaluations of a layer per pass of the shared suffix.  What the caller set, or — 0, the
+        default — sized from the calibration set: a layer has 2 x (its units on this rank)
+        evaluations, and a pass should carry all of them up to ~256 samples (16 evaluations of
+        batch-8 pairs were this build's tuning point: 128 samples; the launchers' batch size 1
+        with 32 calibration samples leaves a 16-evaluation pass at 16 samples, where the suffix
+        is launch-bound — round 6: ECoFLaP + SparseGPT's stage 1 48.6 s at 16, 33.0 s at 32,
+        24.5 s at 64, 39.6 s at 128 (half the slots padding), the same table every time).  Powers
+        of two in [16, 64]; the result does not depend on it (every pass is checked batch
+        invariant, pruners/prefix_cache.py)."""
+        eb = int(getattr(self, "eval_batch", 1))
+        if eb:
+            return eb
+        try:
+            first = self.data_loader[0]
+            n = int(first["image"].shape[0]) if isinstance(first, dict) and "image" in first \
+                else int(_default_batch_len(first))
+        except Exception:
+            return 16
+        n = max(n, 1)
+        units = -(-int(self.num_data_first_stage) // n) * max(int(self.num_noise), 1)
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group) if dist.is_available() and dist.is_initialized() else 1
+        evals = 2 * -(-units // world)
+        upper = min(64, max(16, 256 // n))
+        eb = 16
+        while eb < evals and eb < upper:
+            eb *= 2
+        return eb
+
     def _layer_sparsity(self, loss_func, original_sparsity, mapping, per_model_group=()):
         if (getattr(self, "prefix_cache", True) and not hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO") and mapping):
@@ -688,8 +718,10 @@ class _StageOneMixin:
             lists, extra = self._hook_plan()
             if lists:
                 from .hooked_prefix import HookedPrefixLoss
+                # (the lock-step path runs one Python thread per evaluation: it stays at 16)
                 loss_func = HookedPrefixLoss(self.model, loss_func, lists, extra,
-                                             eval_batch=int(getattr(self, "eval_batch", 1)))
+                                             eval_batch=min(self._eval_batch(), 16)
+                                             if not int(getattr(self, "eval_batch", 1)) else self._eval_batch())
         if (getattr(self, "prefix_cache", True) and hasattr(self.model, "stage_plan")
                 and str(self.score_method).startswith("MEZO") and mapping):
             # same losses, bit for bit, from the owning block onwards only
@@ -699,7 +731,7 @@ class _StageOneMixin:
                 self.model, kind="vision" if loss_func is loss_vision else "vision_language",
                 use_graphs=bool(getattr(self, "use_graphs", True)) and on_gpu,
                 n_lanes=int(getattr(self, "n_lanes", 2)),
-                eval_batch=int(getattr(self, "eval_batch", 1)))
+                eval_batch=self._eval_batch())
         ls = LayerSparsity(
             self.model, self.data_loader, loss_func, self.num_data_first_stage, original_sparsity,
             self.max_sparsity_per_layer, self.score_method, self.num_noise, self.noise_eps,

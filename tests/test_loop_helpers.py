@@ -770,3 +770,28 @@ def test_lock_step_hands_an_error_of_the_models_own_code_to_the_caller_and_recov
     import time
     time.sleep(0.3)
     assert {t.ident for t in threading.enumerate()} <= before
+
+
+def test_evaluations_per_pass_are_sized_from_the_calibration_set():
+    """eval_batch=0 (the default): all of a layer's evaluations in one pass up to ~256 samples,
+    powers of two in [16, 64]; an explicit value is taken as it is."""
+    import torch
+    from ecoflap_amd.pruners.wanda import BLIPT5LayerWandaPruner as BLIPT5WandaPruner
+
+    def rule(batch, n_first, noise=1, explicit=0):
+        p = BLIPT5WandaPruner.__new__(BLIPT5WandaPruner)
+        p.eval_batch, p.num_data_first_stage, p.num_noise, p.process_group = explicit, n_first, noise, None
+        p.data_loader = [{"image": torch.zeros(batch, 3, 2, 2), "text_input": torch.zeros(batch, 3)}]
+        return p._eval_batch()
+
+    assert rule(8, 128) == 32          # config 3: 16 units -> 32 evaluations of 8 pairs
+    assert rule(8, 1024) == 32         # configs[3]: capped at 256 samples per pass
+    assert rule(1, 32) == 64           # the launchers' batch size 1, 32 samples: one pass per layer
+    assert rule(1, 128) == 64          # capped at 64 evaluations
+    assert rule(8, 8) == 16 and rule(2, 8) == 16        # toy sets: the floor
+    assert rule(4, 64, noise=2) == 64
+    assert rule(8, 128, explicit=4) == 4 and rule(1, 32, explicit=1) == 1
+    p = BLIPT5WandaPruner.__new__(BLIPT5WandaPruner)
+    p.eval_batch, p.num_data_first_stage, p.num_noise, p.process_group = 0, 128, 1, None
+    p.data_loader = iter([])           # not indexable: the old default
+    assert p._eval_batch() == 16
