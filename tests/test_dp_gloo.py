@@ -340,6 +340,11 @@ def _divergent_worker(rank, world, port, out_dir, how):
         loss = loss_vision_language
         if how == "seeds" and rank == 1:
             np.random.randint(10)              # something drew from the global generator on this rank
+        if how == "shards":
+            # bench.py's weak scaling: a rank holds only its own batches, placeholders elsewhere —
+            # no batch is common to all ranks, so no first loss can be compared (and none is run)
+            batches = [b if (i % world) == rank else {"text_input": b["text_input"]}
+                       for i, b in enumerate(batches)]
         if how == "forward" and rank == 1:
             # same model, same batch, another rounding: what a per-process kernel choice does
             def loss(m, b, c):
@@ -349,7 +354,7 @@ def _divergent_worker(rank, world, port, out_dir, how):
                            kernels=OracleKernels(), z_source=torch_cpu_normal, k1_form="units")
         try:
             ls.return_sparsity()
-            msg = "no error"
+            msg = "no error " + repr(sorted(ls.stats["run_identity"]))
         except RuntimeError as e:
             msg = str(e)
         with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
@@ -368,3 +373,11 @@ def test_ranks_that_differ_are_refused_before_the_pass(tmp_path, how, named):
     for r in range(2):
         msg = (tmp_path / f"rank{r}.txt").read_text()
         assert "rank 1 differs from rank 0 in " + named in msg, msg
+
+
+def test_rank_local_shards_pass_the_replica_check_without_a_first_loss(tmp_path):
+    port = free_port()
+    mp.spawn(_divergent_worker, args=(2, port, str(tmp_path), "shards"), nprocs=2, join=True)
+    for r in range(2):
+        msg = (tmp_path / f"rank{r}.txt").read_text()
+        assert msg == "no error ['first_batch', 'seeds', 'start_weights']", msg
