@@ -395,6 +395,129 @@ class _BlockwiseWanda:
         # the pruning has no hooks and replays like Wanda's (round 5: 3.9 s of 128-sample eager
         # block forwards at batch 1 in the BLIP-2 run)
         graphed = graphed_plain and getattr(self.owner, "local_method", "wanda") != "sparsegpt"
+        # Batch-1 calibration samples (the launchers' default) leave a replayed block forward at
+        # ~40 kernels of a few microseconds: G samples ride one replay where the block gives
+        # every slot of the stacked input the bits it gives that sample alone (checked on the
+        # first group of every block: slots 0 and G-1 against their batch-1 forwards; a part
+        # whose check fails once goes back to one replay per sample).  round 6: 7.1 s of
+        # SparseGPT's 15 s of stage 2 on the BLIP-2 shape were these forwards.
+        G = int(getattr(self.owner, "stage2_group", 8))
+        group_ok = [graphed_plain and G > 1 and int(inps[0].shape[0]) == 1 and n_batches >= 2 * G
+                    and all((not torch.is_tensor(v)) or (v.dim() > 0 and int(v.shape[0]) == 1)
+                            for v in caches[0].values())]
+
+        def stacked_inputs():
+            sx = torch.cat([inps[j] for j in range(G)], 0)
+            skw = {k: (torch.cat([caches[j][k] for j in range(G)], 0) if torch.is_tensor(v) else v)
+                   for k, v in caches[0].items()}
+            return sx, skw
+
+        def load_group(sx, skw, g):
+            from ..shapes import fused
+            pairs = []
+            for i in range(G):
+                j = g * G + i
+                pairs.append((sx[i:i + 1], inps[j]))
+                pairs += [(skw[k][i:i + 1], v) for k, v in caches[j].items() if torch.is_tensor(v)]
+            fused.multi_copy(pairs)
+
+        def graph_pass_grouped(block):
+            """The plain pass (no hooks) with G samples per replay -> False: not slot invariant
+            here (nothing kept; the caller runs `graph_pass`)."""
+            y_first, y_last = call(block, 0), call(block, G - 1)
+            sx, skw = stacked_inputs()
+            with torch.no_grad(), autocast():
+                block(sx, **skw)                                  # warm-up at this width
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
+                with autocast():
+                    y = block(sx, **skw)
+                y = y[0] if take_first else y
+            graph.replay()
+            if not (torch.equal(y[0:1], y_first) and torch.equal(y[G - 1:G], y_last)):
+                torch.cuda.current_stream().synchronize()
+                del graph
+                return False
+            n_full = n_batches // G
+            for g in range(n_full):
+                if g:
+                    load_group(sx, skw, g)
+                    graph.replay()
+                yc = y.clone()
+                for i in range(G):
+                    outs[g * G + i] = yc[i:i + 1]
+            for j in range(n_full * G, n_batches):
+                outs[j] = call(block, j)
+            torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
+            del graph
+            self.owner.stage_stats["stage2_grouped_passes"] = (
+                self.owner.stage_stats.get("stage2_grouped_passes", 0) + 1)
+            return True
+
+        def graph_pass_hessian_grouped(block, wrapped):
+            """SparseGPT's hooked pass with G = `samples_per_call` samples per replay: the static
+            input each Linear read IS the concatenated [G x tokens, cols] operand of one
+            `hessian_accum` call — the calls, their rows and their order are those of
+            `graph_pass_hessian`.  Checked per block: every Linear's rows of slot 0 and of slot
+            G-1 against the inputs it sees in batch-1 forwards of samples 0 and G-1.
+            -> False (nothing accumulated) when they differ or a Linear is off the MFMA path."""
+            from .sparsegpt import SparseGPT
+            if G != int(SparseGPT.samples_per_call):
+                return False
+            seen = {}
+
+            def noting(name):
+                def add_batch(inp, out):
+                    seen[name] = inp.reshape((-1, inp.shape[-1])).clone(memory_format=torch.contiguous_format)
+                return add_batch
+
+            if any(w_.nsamples != 0 or w_._pending for w_ in wrapped.values()):
+                return False
+            for name, w_ in wrapped.items():
+                w_.add_batch = noting(name)
+            try:
+                call(block, 0)
+                ref_first, seen = seen, {}
+                call(block, G - 1)
+                ref_last, seen = seen, {}
+                sx, skw = stacked_inputs()
+                with torch.no_grad(), autocast():
+                    block(sx, **skw)                              # warm-up at this width
+                seen = {}
+                graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
+                    with autocast():
+                        block(sx, **skw)
+            finally:
+                for w_ in wrapped.values():
+                    del w_.add_batch
+            static = seen
+            graph.replay()
+            ok = set(static) == set(wrapped) == set(ref_first)
+            for name in (static if ok else ()):
+                t = ref_first[name].shape[0]
+                ok = (ok and static[name].shape[0] == G * t and static[name].dtype in (torch.float16, torch.bfloat16)
+                      and torch.equal(static[name][:t], ref_first[name])
+                      and torch.equal(static[name][(G - 1) * t:], ref_last[name]))
+            if not ok:
+                torch.cuda.current_stream().synchronize()
+                del graph
+                return False
+            n_full = n_batches // G
+            for g in range(n_full):
+                if g:
+                    load_group(sx, skw, g)
+                    graph.replay()
+                for name, w_ in wrapped.items():
+                    w_.kernels.hessian_accum(w_.H, static[name], w_.nsamples, G)
+                    w_.nsamples += G
+            for j in range(n_full * G, n_batches):
+                call(block, j)                                    # the ordinary hooks; flushed by the caller
+            torch.cuda.current_stream().synchronize()
+            del graph
+            self.owner.stage_stats["stage2_grouped_passes"] = (
+                self.owner.stage_stats.get("stage2_grouped_passes", 0) + 1)
+            return True
 
         def graph_pass(block, wrapped, keep):
             """All n_batches samples through `block`: sample 0 eagerly (warm-up), one capture,
@@ -546,10 +669,16 @@ class _BlockwiseWanda:
                     w_.sink = collector[0]
             from .phase_timer import PhaseTimer
             with PhaseTimer.span("stage2.block_forward_with_hooks (incl. K6 / Hessian updates)"):
+                hess_graphs = sparsegpt and graphed_plain and getattr(self.owner, "sparsegpt_graph_hooks", True)
+                grouped = False
+                if hess_graphs and group_ok[0]:
+                    grouped = graph_pass_hessian_grouped(block, wrapped)
+                    group_ok[0] = grouped
                 if graphed:
                     graph_pass(block, wrapped, keep=False)
-                elif not (sparsegpt and graphed_plain and getattr(self.owner, "sparsegpt_graph_hooks", True)
-                          and graph_pass_hessian(block, wrapped)):
+                elif grouped:
+                    pass
+                elif not (hess_graphs and graph_pass_hessian(block, wrapped)):
                     # (a refused graph pass has run sample 0 already: its hooks have fired)
                     done0 = sparsegpt and any(w_.nsamples or w_._pending for w_ in wrapped.values())
                     for j in range(1 if done0 else 0, n_batches):
@@ -616,7 +745,10 @@ class _BlockwiseWanda:
                 for w_ in wrapped.values():
                     w_.free()
             with PhaseTimer.span("stage2.block_forward_after_prune"):
-                if graphed_plain:
+                if group_ok[0] and graph_pass_grouped(block):
+                    pass
+                elif graphed_plain:
+                    group_ok[0] = False
                     graph_pass(block, None, keep=True)
                 else:
                     for j in range(n_batches):
