@@ -402,6 +402,7 @@ class _BlockwiseWanda:
         # whose check fails once goes back to one replay per sample).  round 6: 7.1 s of
         # SparseGPT's 15 s of stage 2 on the BLIP-2 shape were these forwards.
         G = int(getattr(self.owner, "stage2_group", 8))
+        min_values = int(getattr(self.owner, "stage2_group_min_values", 65536))
         group_ok = [graphed_plain and G > 1 and int(inps[0].shape[0]) == 1 and n_batches >= 2 * G
                     and all((not torch.is_tensor(v)) or (v.dim() > 0 and int(v.shape[0]) == 1)
                             for v in caches[0].values())]
@@ -438,15 +439,27 @@ class _BlockwiseWanda:
                 torch.cuda.current_stream().synchronize()
                 del graph
                 return False
+            # too few values for two slots to rule out a lucky agreement (toy shapes: a handful
+            # of short dot products round alike in two kernels most of the time): every sample
+            # is then also run alone and compared, and the first difference ends the grouping
+            verify_all = 2 * y_first.numel() < min_values
             n_full = n_batches // G
+            rest_from = n_full * G
             for g in range(n_full):
                 if g:
                     load_group(sx, skw, g)
                     graph.replay()
                 yc = y.clone()
+                if verify_all:
+                    alone = [call(block, g * G + i) for i in range(G)]
+                    if not all(torch.equal(yc[i:i + 1], alone[i]) for i in range(G)):
+                        for i in range(G):
+                            outs[g * G + i] = alone[i]
+                        rest_from, group_ok[0] = (g + 1) * G, False
+                        break
                 for i in range(G):
                     outs[g * G + i] = yc[i:i + 1]
-            for j in range(n_full * G, n_batches):
+            for j in range(rest_from, n_batches):
                 outs[j] = call(block, j)
             torch.cuda.current_stream().synchronize()     # the graph's buffers go away with it
             del graph
@@ -488,30 +501,44 @@ class _BlockwiseWanda:
                 with torch.no_grad(), capture_graph(graph, capture_error_mode="thread_local"):
                     with autocast():
                         block(sx, **skw)
+                static, seen = seen, {}
+                graph.replay()
+                ok = set(static) == set(wrapped) == set(ref_first)
+                for name in (static if ok else ()):
+                    t = ref_first[name].shape[0]
+                    ok = (ok and static[name].shape[0] == G * t
+                          and static[name].dtype in (torch.float16, torch.bfloat16)
+                          and torch.equal(static[name][:t], ref_first[name])
+                          and torch.equal(static[name][(G - 1) * t:], ref_last[name]))
+                if not ok:
+                    torch.cuda.current_stream().synchronize()
+                    del graph
+                    return False
+                verify_all = 2 * sum(v.numel() for v in ref_first.values()) < min_values   # (see graph_pass_grouped)
+                n_full = n_batches // G
+                rest_from = n_full * G
+                for g in range(n_full):
+                    if g:
+                        load_group(sx, skw, g)
+                        graph.replay()
+                    if verify_all:
+                        same = True
+                        for i in range(G):
+                            seen = {}
+                            call(block, g * G + i)               # the noting hooks: this sample alone
+                            same = same and all(
+                                torch.equal(static[n][i * seen[n].shape[0]:(i + 1) * seen[n].shape[0]], seen[n])
+                                for n in static)
+                        if not same:
+                            rest_from, group_ok[0] = g * G, False
+                            break
+                    for name, w_ in wrapped.items():
+                        w_.kernels.hessian_accum(w_.H, static[name], w_.nsamples, G)
+                        w_.nsamples += G
             finally:
                 for w_ in wrapped.values():
                     del w_.add_batch
-            static = seen
-            graph.replay()
-            ok = set(static) == set(wrapped) == set(ref_first)
-            for name in (static if ok else ()):
-                t = ref_first[name].shape[0]
-                ok = (ok and static[name].shape[0] == G * t and static[name].dtype in (torch.float16, torch.bfloat16)
-                      and torch.equal(static[name][:t], ref_first[name])
-                      and torch.equal(static[name][(G - 1) * t:], ref_last[name]))
-            if not ok:
-                torch.cuda.current_stream().synchronize()
-                del graph
-                return False
-            n_full = n_batches // G
-            for g in range(n_full):
-                if g:
-                    load_group(sx, skw, g)
-                    graph.replay()
-                for name, w_ in wrapped.items():
-                    w_.kernels.hessian_accum(w_.H, static[name], w_.nsamples, G)
-                    w_.nsamples += G
-            for j in range(n_full * G, n_batches):
+            for j in range(rest_from, n_batches):
                 call(block, j)                                    # the ordinary hooks; flushed by the caller
             torch.cuda.current_stream().synchronize()
             del graph

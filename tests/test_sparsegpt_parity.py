@@ -189,22 +189,37 @@ def test_sparsegpt_hooked_pass_from_graph_replays_equals_eager():
     bit, production dtypes."""
     from ecoflap_amd import hip
 
-    def run(graphs):
+    def run(graphs, name="blipt5_sparsegpt_pruner", group=None):
         torch.manual_seed(4)
         model = blip2_toy(fp32=False).eval().to("cuda")
         batches = S.image_text_batches(20, 1, img_size=28, vocab=96, in_len=5, out_len=4, seed=6, device="cuda")
         cfg = dict(t5_prune_spec="2-0.5-1.0-1.0", vit_prune_spec="2-0.5-1.0-1.0",
                    t5_pruning_method="none", vit_pruning_method="none", num_samples=20,
                    kernels=hip.HipKernels(), use_graphs=graphs)
-        pruner = load_pruner("blipt5_sparsegpt_pruner", model, batches, cfg=cfg)
+        pruner = load_pruner(name, model, batches, cfg=cfg)
         pruner.graph_min_batches = 4
+        if group is not None:
+            pruner.stage2_group = group
         model, _ = pruner.prune()
         torch.cuda.synchronize()
-        return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        return ({k: v.detach().cpu() for k, v in model.state_dict().items()},
+                pruner.stage_stats.get("stage2_grouped_passes", 0))
 
-    eager, graphed = run(False), run(True)
+    (eager, n0), (graphed, n8), (single, n1) = run(False), run(True), run(True, group=1)
+    # round 6: batch-1 samples ride 8 per replay (two full groups + four samples one by one here),
+    # the hooked pass and the pass behind the pruning of all 2 + 2 + 2 blocks, where the block is
+    # slot invariant (checked per block; a part that is not falls back to one replay per sample)
+    assert n0 == 0 and n1 == 0 and 0 < n8 <= 12, (n0, n8, n1)
     for k in eager:
         assert torch.equal(eager[k], graphed[k]), k
+        assert torch.equal(eager[k], single[k]), k
+    # Wanda's pass behind the pruning rides the same way (its hooked pass keeps one K6 launch per sample)
+    (w_eager, _), (w_graphed, m8), (w_single, m1) = (run(False, "blipt5_wanda_pruner"), run(True, "blipt5_wanda_pruner"),
+                                                      run(True, "blipt5_wanda_pruner", group=1))
+    assert m1 == 0 and 0 < m8 <= 6, (m8, m1)
+    for k in w_eager:
+        assert torch.equal(w_eager[k], w_graphed[k]), k
+        assert torch.equal(w_eager[k], w_single[k]), k
     blocks = [k for k, v in eager.items() if v.dim() == 2 and ".block" in k and "relative_attention_bias" not in k]
     zeros = sum(int((eager[k] == 0).sum()) for k in blocks) / sum(eager[k].numel() for k in blocks)
     assert 0.45 < zeros < 0.55
